@@ -1,0 +1,667 @@
+"""ctypes binding of libfvad_hip.so (include/fvad.h).
+
+Plumbing only: the arithmetic lives in the HIP kernels and the C++ host code behind the C ABI.
+There is NO fallback: if the shared library is missing this module raises, and every GPU entry
+point returns FVAD_ERR_NO_DEVICE (-101) when no gfx950 device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfvad_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+vp = C.c_void_p
+sz = C.c_size_t
+
+FVAD_OK = 0
+FVAD_ERR_NO_DEVICE = -101
+
+
+class FvadError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        name = lib().fvad_status_name(status).decode()
+        super().__init__(f"{where}: error.{name} ({status}) {detail}".strip())
+
+
+class Complex(C.Structure):
+    _fields_ = [("r", C.c_float), ("i", C.c_float)]
+
+
+class Weights(C.Structure):
+    _fields_ = [("n_bins", C.c_int32), ("n_fc1", C.c_int32), ("n_hidden", C.c_int32),
+                ("n_fc2", C.c_int32), ("n_fc3", C.c_int32)] + [
+        (n, c_float_p) for n in (
+            "fc1_w", "fc1_b", "gru1_w", "gru1_r", "gru1_b", "gru2_w", "gru2_r", "gru2_b",
+            "fc2_w", "fc2_b", "fc3_w", "fc3_b", "fc4_w", "fc4_b")]
+
+
+WEIGHT_NAMES = ("fc1_w", "fc1_b", "gru1_w", "gru1_r", "gru1_b", "gru2_w", "gru2_r", "gru2_b",
+                "fc2_w", "fc2_b", "fc3_w", "fc3_b", "fc4_w", "fc4_b")
+
+
+def weight_shapes(nb, f1, h, f2, f3):
+    return {"fc1_w": (f1, nb), "fc1_b": (f1,),
+            "gru1_w": (3 * h, f1), "gru1_r": (3 * h, h), "gru1_b": (6 * h,),
+            "gru2_w": (3 * h, h), "gru2_r": (3 * h, h), "gru2_b": (6 * h,),
+            "fc2_w": (f2, h), "fc2_b": (f2,), "fc3_w": (f3, f2), "fc3_b": (f3,),
+            "fc4_w": (nb, f3), "fc4_b": (nb,)}
+
+
+class VadConfig(C.Structure):
+    _fields_ = [("speech_min_freq", C.c_float), ("speech_max_freq", C.c_float),
+                ("long_term_speech_avg_sec", C.c_float),
+                ("has_initial_long_term_avg", C.c_int32),
+                ("initial_long_term_avg", C.c_double),
+                ("short_term_speech_avg_sec", C.c_float),
+                ("speech_threshold_factor", C.c_float),
+                ("channel_vol_ratio_avg_sec", C.c_float),
+                ("channel_vol_ratio_threshold", C.c_float),
+                ("min_consecutive_sec_to_open", C.c_float),
+                ("max_speech_gap_sec", C.c_float),
+                ("min_vad_duration_sec", C.c_float)]
+
+
+class SpeechSegment(C.Structure):
+    _fields_ = [("sample_from", C.c_uint64), ("sample_to", C.c_uint64),
+                ("avg_channel_vol_ratio", C.c_float), ("vad_met_sec", C.c_float)]
+
+
+class VadResult(C.Structure):
+    _fields_ = [("recording_state", C.c_int32), ("sample_number", C.c_uint64)]
+
+
+class VadAudit(C.Structure):
+    _fields_ = [("min_rel_threshold_margin", C.c_double), ("min_abs_ratio_margin", C.c_double),
+                ("n_frames", C.c_uint64)]
+
+
+class Lane(C.Structure):
+    _fields_ = [("pcm", c_float_p), ("n_samples", sz), ("state", vp), ("denoised", c_float_p),
+                ("band_sum", c_float_p), ("band_sum_capacity", sz),
+                ("chunk_rms", c_float_p), ("chunk_rms_capacity", sz),
+                ("fft_bins", c_float_p),
+                ("n_chunks", sz), ("n_fft_frames", sz), ("first_frame_index", C.c_uint64)]
+
+
+class EngineOpts(C.Structure):
+    _fields_ = [("on_device", C.c_int32), ("min_bin", C.c_int32), ("max_bin", C.c_int32),
+                ("max_chunks_per_launch", C.c_int32)]
+
+
+RecordingCb = C.CFUNCTYPE(None, vp, vp)
+
+
+class Callbacks(C.Structure):
+    _fields_ = [("ctx", vp), ("on_original_recording", RecordingCb),
+                ("on_denoised_recording", RecordingCb)]
+
+
+class PipelineConfig(C.Structure):
+    _fields_ = [("sample_rate", sz), ("n_channels", sz), ("buffer_length", sz),
+                ("skip_processing", C.c_int32), ("fft_size", sz),
+                ("vad_machine_config", VadConfig),
+                ("alt_vad_machine_configs", C.POINTER(VadConfig)),
+                ("n_alt_vad_machine_configs", sz)]
+
+
+class SingleStats(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "total_positives_sec", "true_positives_sec", "false_positives_sec", "false_negatives_sec",
+        "true_positive_rate", "false_negative_rate", "false_discovery_rate", "precision",
+        "fm_index", "f_score", "f_score_beta")]
+
+
+class AggStat(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("overall", "min", "max", "avg")]
+
+
+class AggregateStats(C.Structure):
+    _fields_ = [("total_positives_sec", C.c_float), ("true_positives_sec", C.c_float),
+                ("false_positives_sec", C.c_float), ("false_negatives_sec", C.c_float),
+                ("true_positive_rate", AggStat), ("false_negative_rate", AggStat),
+                ("false_discovery_rate", AggStat), ("precision", AggStat),
+                ("fm_index", C.c_float), ("f_score", C.c_float), ("f_score_beta", C.c_float)]
+
+
+class StatConfig(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("ignore_shorter_than_sec", "extrude_start",
+                                         "extrude_end", "fill_gaps")]
+
+
+class SegmentSec(C.Structure):
+    _fields_ = [("from_sec", C.c_float), ("to_sec", C.c_float)]
+
+
+# every symbol include/fvad.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "fvad_status_name": (C.c_char_p, [C.c_int]),
+    "fvad_abi_version": (C.c_int, []),
+    "fvad_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "fvad_ctx_destroy": (None, [vp]),
+    "fvad_last_error": (C.c_char_p, [vp]),
+    "fvad_ctx_synchronize": (C.c_int, [vp]),
+    "fvad_ctx_stream": (vp, [vp]),
+    "fvad_load_nsnet2_onnx": (C.c_int, [vp, C.c_char_p]),
+    "fvad_load_nsnet2_weights": (C.c_int, [vp, C.POINTER(Weights)]),
+    "fvad_load_nsnet2_synth": (C.c_int, [vp, C.c_uint64]),
+    "fvad_get_nsnet2_weights": (C.c_int, [vp, C.POINTER(Weights)]),
+    "fvad_onnx_read_nsnet2": (C.c_int, [C.c_char_p, C.POINTER(Weights), C.POINTER(vp)]),
+    "fvad_synth_nsnet2": (C.c_int, [C.c_uint64, C.POINTER(Weights), C.POINTER(vp)]),
+    "fvad_weights_free": (None, [vp]),
+    "fvad_fft_create": (C.c_int, [vp, sz, sz, C.c_int, C.POINTER(vp)]),
+    "fvad_fft_destroy": (None, [vp]),
+    "fvad_fft_forward": (C.c_int, [vp, c_float_p, sz, c_float_p, sz, c_float_p, sz,
+                                   C.POINTER(Complex), sz]),
+    "fvad_fft_inverse": (C.c_int, [vp, C.POINTER(Complex), sz, c_float_p, sz]),
+    "fvad_fft_bin_count": (sz, [vp]),
+    "fvad_fft_bin_width": (C.c_float, [vp]),
+    "fvad_fft_nyquist_freq": (C.c_float, [vp]),
+    "fvad_fft_freq_to_bin": (C.c_int, [vp, C.c_float, C.POINTER(sz)]),
+    "fvad_fft_bin_to_freq": (C.c_int, [vp, sz, c_float_p]),
+    "fvad_fft_forward_batch": (C.c_int, [vp, vp, sz, vp, vp, vp, C.c_int]),
+    "fvad_hann_window_periodic": (None, [c_float_p, sz]),
+    "fvad_hann_window_symmetric": (None, [c_float_p, sz]),
+    "fvad_window_norm_factor": (C.c_float, [c_float_p, sz]),
+    "fvad_nsnet2_window": (None, [c_float_p]),
+    "fvad_nsnet2_create": (C.c_int, [vp, sz, C.POINTER(vp)]),
+    "fvad_nsnet2_destroy": (None, [vp]),
+    "fvad_nsnet2_chunk_size": (sz, [sz]),
+    "fvad_nsnet2_denoise": (C.c_int, [vp, c_float_p, sz, c_float_p, sz, c_float_p, sz]),
+    "fvad_lane_state_create": (C.c_int, [vp, C.POINTER(vp)]),
+    "fvad_lane_state_reset": (None, [vp]),
+    "fvad_lane_state_destroy": (None, [vp]),
+    "fvad_engine_opts_default": (None, [C.POINTER(EngineOpts)]),
+    "fvad_engine_run": (C.c_int, [vp, C.POINTER(Lane), sz, C.POINTER(EngineOpts)]),
+    "fvad_engine_enqueue_device": (C.c_int, [vp, vp, sz, sz, sz, vp, vp, vp,
+                                             C.POINTER(EngineOpts)]),
+    "fvad_nsnet2_forward": (C.c_int, [vp, c_float_p, sz, sz, c_float_p]),
+    "fvad_ctx_enable_timing": (C.c_int, [vp, C.c_int]),
+    "fvad_ctx_kernel_times": (C.c_int, [vp, C.POINTER(C.c_char_p), c_float_p, sz,
+                                        C.POINTER(sz)]),
+    "fvad_vad_config_default": (None, [C.POINTER(VadConfig)]),
+    "fvad_vad_create": (C.c_int, [C.POINTER(VadConfig), sz, sz, sz, C.POINTER(vp)]),
+    "fvad_vad_destroy": (None, [vp]),
+    "fvad_vad_run": (C.c_int, [vp, C.c_uint64, c_float_p, C.c_int, C.c_float,
+                               C.POINTER(VadResult)]),
+    "fvad_vad_segment_count": (sz, [vp]),
+    "fvad_vad_segments": (C.c_int, [vp, C.POINTER(SpeechSegment), sz, C.POINTER(sz)]),
+    "fvad_vad_audit_get": (C.c_int, [vp, C.POINTER(VadAudit)]),
+    "fvad_vad_run_many": (C.c_int, [C.POINTER(vp), sz, C.POINTER(c_float_p),
+                                    C.POINTER(c_float_p), C.POINTER(sz), sz,
+                                    C.POINTER(C.c_uint64), sz, C.c_int]),
+    "fvad_ra_create": (C.c_int, [sz, C.c_int, C.c_double, C.POINTER(vp)]),
+    "fvad_ra_destroy": (None, [vp]),
+    "fvad_ra_push": (C.c_double, [vp, C.c_float]),
+    "fvad_ra_last_avg": (C.c_int, [vp, C.POINTER(C.c_double)]),
+    "fvad_pipeline_config_default": (None, [C.POINTER(PipelineConfig)]),
+    "fvad_pipeline_create": (C.c_int, [vp, C.POINTER(PipelineConfig), C.POINTER(Callbacks),
+                                       C.POINTER(vp)]),
+    "fvad_pipeline_destroy": (None, [vp]),
+    "fvad_pipeline_push_samples": (C.c_int, [vp, C.POINTER(c_float_p), sz,
+                                             C.POINTER(C.c_uint64)]),
+    "fvad_pipeline_total_write_count": (C.c_uint64, [vp]),
+    "fvad_pipeline_segment_count": (sz, [vp]),
+    "fvad_pipeline_segments": (C.c_int, [vp, C.POINTER(SpeechSegment), sz, C.POINTER(sz)]),
+    "fvad_pipeline_alt_segments": (C.c_int, [vp, sz, C.POINTER(SpeechSegment), sz,
+                                             C.POINTER(sz)]),
+    "fvad_pipeline_audit": (C.c_int, [vp, C.POINTER(VadAudit)]),
+    "fvad_pipeline_n_fft_frames": (sz, [vp]),
+    "fvad_pipeline_trace": (C.c_int, [vp, c_float_p, c_float_p, sz]),
+    "fvad_segment_to_sec": (SegmentSec, [C.POINTER(SpeechSegment), sz]),
+    "fvad_stats_from_segments": (C.c_int, [C.POINTER(SegmentSec), sz, C.POINTER(SegmentSec), sz,
+                                           C.POINTER(StatConfig), C.POINTER(SingleStats)]),
+    "fvad_stats_aggregate": (C.c_int, [C.POINTER(SingleStats), sz, C.POINTER(AggregateStats)]),
+    "fvad_parse_audacity": (C.c_int, [C.c_char_p, sz, C.POINTER(SegmentSec), sz, C.POINTER(sz)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libfvad_hip.so (built in-tree by formula-vad_amd/csrc/Makefile). Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `make -C formula-vad_amd/csrc` "
+                "(__graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def fptr(a):
+    if a is None:
+        return None
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_float_p)
+
+
+def check(status, where, ctx=None):
+    if status != FVAD_OK:
+        detail = lib().fvad_last_error(ctx).decode() if ctx else ""
+        raise FvadError(status, where, detail)
+
+
+def weights_to_dict(w):
+    """Weights struct (borrowed pointers) -> dict of numpy copies"""
+    shapes = weight_shapes(w.n_bins, w.n_fc1, w.n_hidden, w.n_fc2, w.n_fc3)
+    return {k: np.ctypeslib.as_array(getattr(w, k), shape=shapes[k]).copy() for k in WEIGHT_NAMES}
+
+
+def dict_to_weights(wd):
+    w = Weights()
+    w.n_bins = wd["fc1_w"].shape[1]
+    w.n_fc1 = wd["fc1_w"].shape[0]
+    w.n_hidden = wd["gru1_r"].shape[1]
+    w.n_fc2 = wd["fc2_w"].shape[0]
+    w.n_fc3 = wd["fc3_w"].shape[0]
+    keep = {}
+    for k in WEIGHT_NAMES:
+        keep[k] = np.ascontiguousarray(wd[k], dtype=np.float32)
+        setattr(w, k, fptr(keep[k]))
+    return w, keep
+
+
+def synth_weights(seed):
+    """Host-only: the library's seeded NSNet2-shaped weights as a dict of numpy arrays"""
+    w = Weights()
+    owner = vp()
+    check(lib().fvad_synth_nsnet2(seed, C.byref(w), C.byref(owner)), "fvad_synth_nsnet2")
+    try:
+        return weights_to_dict(w)
+    finally:
+        lib().fvad_weights_free(owner)
+
+
+def read_onnx(path):
+    w = Weights()
+    owner = vp()
+    check(lib().fvad_onnx_read_nsnet2(path.encode(), C.byref(w), C.byref(owner)),
+          "fvad_onnx_read_nsnet2")
+    try:
+        return weights_to_dict(w)
+    finally:
+        lib().fvad_weights_free(owner)
+
+
+class Context:
+    """fvad_ctx: one HIP device + stream (+ the loaded NSNet2 model)"""
+
+    def __init__(self, device=0):
+        self.h = vp()
+        check(lib().fvad_ctx_create(device, C.byref(self.h)), "fvad_ctx_create")
+
+    def close(self):
+        if self.h:
+            lib().fvad_ctx_destroy(self.h)
+            self.h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, status, where):
+        check(status, where, self.h)
+
+    def load_synth(self, seed):
+        self._ck(lib().fvad_load_nsnet2_synth(self.h, seed), "fvad_load_nsnet2_synth")
+
+    def load_weights(self, wd):
+        w, keep = dict_to_weights(wd)
+        self._ck(lib().fvad_load_nsnet2_weights(self.h, C.byref(w)), "fvad_load_nsnet2_weights")
+
+    def load_onnx(self, path):
+        self._ck(lib().fvad_load_nsnet2_onnx(self.h, path.encode()), "fvad_load_nsnet2_onnx")
+
+    def weights(self):
+        w = Weights()
+        self._ck(lib().fvad_get_nsnet2_weights(self.h, C.byref(w)), "fvad_get_nsnet2_weights")
+        return weights_to_dict(w)
+
+    def synchronize(self):
+        self._ck(lib().fvad_ctx_synchronize(self.h), "fvad_ctx_synchronize")
+
+    def enable_timing(self, on=True):
+        self._ck(lib().fvad_ctx_enable_timing(self.h, 1 if on else 0), "fvad_ctx_enable_timing")
+
+    def kernel_times(self):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        n = sz()
+        self._ck(lib().fvad_ctx_kernel_times(self.h, names, ms, cap, C.byref(n)),
+                 "fvad_ctx_kernel_times")
+        return {names[i].decode(): ms[i] for i in range(min(n.value, cap))}
+
+    def nsnet2_forward(self, features):
+        f = np.ascontiguousarray(features, dtype=np.float32)
+        assert f.ndim == 3 and f.shape[2] == 161
+        g = np.zeros_like(f)
+        self._ck(lib().fvad_nsnet2_forward(self.h, fptr(f), f.shape[0], f.shape[1], fptr(g)),
+                 "fvad_nsnet2_forward")
+        return g
+
+    def engine_run(self, lanes_pcm, want_denoised=False, want_bins=False, states=None,
+                   max_chunks_per_launch=0, min_bin=11, max_bin=43):
+        """lanes_pcm: list of float32 1-D arrays (host). Returns list of dicts."""
+        n = len(lanes_pcm)
+        arr = (Lane * n)()
+        keep = []
+        for i, x in enumerate(lanes_pcm):
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            n_chunks = x.shape[0] // 24000
+            cap_frames = (n_chunks * 24000 + 1024) // 1024 + 1
+            band = np.zeros(cap_frames, np.float32)
+            rms = np.zeros(max(n_chunks, 1), np.float32)
+            den = np.zeros(n_chunks * 24000, np.float32) if want_denoised else None
+            bins = np.zeros((cap_frames, 513), np.float32) if want_bins else None
+            keep.append((x, band, rms, den, bins))
+            L = arr[i]
+            L.pcm = fptr(x)
+            L.n_samples = x.shape[0]
+            L.state = states[i] if states else None
+            L.denoised = fptr(den) if den is not None and den.size else None
+            L.band_sum = fptr(band)
+            L.band_sum_capacity = cap_frames
+            L.chunk_rms = fptr(rms)
+            L.chunk_rms_capacity = rms.shape[0]
+            L.fft_bins = fptr(bins) if bins is not None else None
+        opts = EngineOpts()
+        lib().fvad_engine_opts_default(C.byref(opts))
+        opts.max_chunks_per_launch = max_chunks_per_launch
+        opts.min_bin = min_bin
+        opts.max_bin = max_bin
+        self._ck(lib().fvad_engine_run(self.h, arr, n, C.byref(opts)), "fvad_engine_run")
+        out = []
+        for i in range(n):
+            x, band, rms, den, bins = keep[i]
+            nf = arr[i].n_fft_frames
+            nc = arr[i].n_chunks
+            out.append({"n_chunks": nc, "n_fft_frames": nf,
+                        "first_frame_index": arr[i].first_frame_index,
+                        "band_sum": band[:nf].copy(), "chunk_rms": rms[:nc].copy(),
+                        "denoised": den, "fft_bins": None if bins is None else bins[:nf].copy()})
+        return out
+
+    def lane_state(self):
+        s = vp()
+        self._ck(lib().fvad_lane_state_create(self.h, C.byref(s)), "fvad_lane_state_create")
+        return s
+
+
+class FFT:
+    """fvad_fft <-> reference src/FFT.zig"""
+
+    def __init__(self, ctx, n_fft, sample_rate, inverse=False):
+        self.ctx = ctx
+        self.h = vp()
+        ctx._ck(lib().fvad_fft_create(ctx.h, n_fft, sample_rate, 1 if inverse else 0,
+                                      C.byref(self.h)), "FFT.init")
+        self.n_fft = n_fft
+
+    def bin_count(self):
+        return lib().fvad_fft_bin_count(self.h)
+
+    def fft(self, first, window, second=None, n_bins=None):
+        first = np.ascontiguousarray(first, np.float32)
+        second = np.ascontiguousarray(second, np.float32) if second is not None else None
+        window = np.ascontiguousarray(window, np.float32)
+        nb = self.bin_count() if n_bins is None else n_bins
+        out = np.zeros((nb, 2), np.float32)
+        rc = lib().fvad_fft_forward(self.h, fptr(first), first.shape[0],
+                                    fptr(second) if second is not None else None,
+                                    0 if second is None else second.shape[0],
+                                    fptr(window), window.shape[0],
+                                    out.ctypes.data_as(C.POINTER(Complex)), nb)
+        self.ctx._ck(rc, "FFT.fft")
+        return out.view(np.complex64)[:, 0]
+
+    def inv_fft(self, bins, n_result=None):
+        b = np.ascontiguousarray(np.asarray(bins, np.complex64)).view(np.float32).reshape(-1, 2)
+        n = self.n_fft if n_result is None else n_result
+        out = np.zeros(n, np.float32)
+        rc = lib().fvad_fft_inverse(self.h, b.ctypes.data_as(C.POINTER(Complex)), b.shape[0],
+                                    fptr(out), n)
+        self.ctx._ck(rc, "FFT.invFft")
+        return out
+
+    def fft_batch(self, frames, window, want_bins=True, want_mag=True):
+        frames = np.ascontiguousarray(frames, np.float32)
+        window = np.ascontiguousarray(window, np.float32)
+        nb = self.bin_count()
+        bins = np.zeros((frames.shape[0], nb, 2), np.float32) if want_bins else None
+        mag = np.zeros((frames.shape[0], nb), np.float32) if want_mag else None
+        rc = lib().fvad_fft_forward_batch(
+            self.h, frames.ctypes.data, frames.shape[0], window.ctypes.data,
+            bins.ctypes.data if bins is not None else None,
+            mag.ctypes.data if mag is not None else None, 0)
+        self.ctx._ck(rc, "FFT.fft(batch)")
+        return (bins.view(np.complex64)[..., 0] if bins is not None else None), mag
+
+    def freq_to_bin(self, freq):
+        b = sz()
+        rc = lib().fvad_fft_freq_to_bin(self.h, freq, C.byref(b))
+        if rc != FVAD_OK:
+            raise FvadError(rc, "FFT.freqToBin")
+        return b.value
+
+    def close(self):
+        if self.h:
+            lib().fvad_fft_destroy(self.h)
+            self.h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NSNet2:
+    """fvad_nsnet2 <-> reference src/NSNet2.zig (one object per channel)"""
+
+    def __init__(self, ctx, sample_rate=48000):
+        self.ctx = ctx
+        self.h = vp()
+        ctx._ck(lib().fvad_nsnet2_create(ctx.h, sample_rate, C.byref(self.h)), "NSNet2.init")
+        self.chunk = lib().fvad_nsnet2_chunk_size(sample_rate)
+
+    def denoise(self, x, split=None):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros(self.chunk, np.float32)
+        if split is None:
+            rc = lib().fvad_nsnet2_denoise(self.h, fptr(x), x.shape[0], None, 0, fptr(out),
+                                           out.shape[0])
+        else:
+            a, b = np.ascontiguousarray(x[:split]), np.ascontiguousarray(x[split:])
+            rc = lib().fvad_nsnet2_denoise(self.h, fptr(a), a.shape[0], fptr(b), b.shape[0],
+                                           fptr(out), out.shape[0])
+        self.ctx._ck(rc, "NSNet2.denoise")
+        return out
+
+    def close(self):
+        if self.h:
+            lib().fvad_nsnet2_destroy(self.h)
+            self.h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class AudioPipeline:
+    """fvad_pipeline <-> reference src/AudioPipeline.zig"""
+
+    def __init__(self, ctx, n_channels=1, sample_rate=48000, fft_size=1024, vad_overrides=None,
+                 alt_configs=None, skip_processing=False):
+        self.ctx = ctx
+        cfg = PipelineConfig()
+        lib().fvad_pipeline_config_default(C.byref(cfg))
+        cfg.n_channels = n_channels
+        cfg.sample_rate = sample_rate
+        cfg.fft_size = fft_size
+        cfg.skip_processing = 1 if skip_processing else 0
+        for k, v in (vad_overrides or {}).items():
+            setattr(cfg.vad_machine_config, k, v)
+        self._alts = None
+        if alt_configs:
+            self._alts = (VadConfig * len(alt_configs))()
+            for i, ov in enumerate(alt_configs):
+                lib().fvad_vad_config_default(C.byref(self._alts[i]))
+                for k, v in ov.items():
+                    setattr(self._alts[i], k, v)
+            cfg.alt_vad_machine_configs = self._alts
+            cfg.n_alt_vad_machine_configs = len(alt_configs)
+        self.h = vp()
+        ctx._ck(lib().fvad_pipeline_create(ctx.h, C.byref(cfg), None, C.byref(self.h)),
+                "AudioPipeline.init")
+        self.n_channels = n_channels
+
+    def push_samples(self, pcm):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        assert pcm.ndim == 2 and pcm.shape[0] == self.n_channels
+        ptrs = (c_float_p * self.n_channels)(*[fptr(pcm[c]) for c in range(self.n_channels)])
+        first = C.c_uint64()
+        self.ctx._ck(lib().fvad_pipeline_push_samples(self.h, ptrs, pcm.shape[1], C.byref(first)),
+                     "AudioPipeline.pushSamples")
+        return first.value
+
+    def segments(self, alt=None):
+        n = sz()
+        cap = 4096
+        buf = (SpeechSegment * cap)()
+        if alt is None:
+            rc = lib().fvad_pipeline_segments(self.h, buf, cap, C.byref(n))
+        else:
+            rc = lib().fvad_pipeline_alt_segments(self.h, alt, buf, cap, C.byref(n))
+        self.ctx._ck(rc, "vad_segments")
+        return [(buf[i].sample_from, buf[i].sample_to, buf[i].avg_channel_vol_ratio,
+                 buf[i].vad_met_sec) for i in range(n.value)]
+
+    def trace(self):
+        n = lib().fvad_pipeline_n_fft_frames(self.h)
+        band = np.zeros((max(n, 1), self.n_channels), np.float32)
+        ratio = np.zeros(max(n, 1), np.float32)
+        self.ctx._ck(lib().fvad_pipeline_trace(self.h, fptr(band), fptr(ratio), max(n, 1)),
+                     "trace")
+        return band[:n], ratio[:n]
+
+    def audit(self):
+        a = VadAudit()
+        self.ctx._ck(lib().fvad_pipeline_audit(self.h, C.byref(a)), "audit")
+        return a.min_rel_threshold_margin, a.min_abs_ratio_margin, a.n_frames
+
+    def close(self):
+        if self.h:
+            lib().fvad_pipeline_destroy(self.h)
+            self.h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class VadMachine:
+    """fvad_vad <-> reference src/AudioPipeline/VADMachine.zig (host)"""
+
+    def __init__(self, n_channels=1, sample_rate=48000, fft_size=1024, overrides=None):
+        cfg = VadConfig()
+        lib().fvad_vad_config_default(C.byref(cfg))
+        for k, v in (overrides or {}).items():
+            setattr(cfg, k, v)
+        self.h = vp()
+        check(lib().fvad_vad_create(C.byref(cfg), sample_rate, n_channels, fft_size,
+                                    C.byref(self.h)), "VADMachine.init")
+        self.n_channels = n_channels
+
+    def run(self, index, volumes, ratio):
+        v = np.ascontiguousarray(volumes, np.float32)
+        res = VadResult()
+        has = 0 if ratio is None else 1
+        check(lib().fvad_vad_run(self.h, index, fptr(v), has, 0.0 if ratio is None else ratio,
+                                 C.byref(res)), "VADMachine.run")
+        return res.recording_state, res.sample_number
+
+    def segments(self):
+        n = sz()
+        cap = 4096
+        buf = (SpeechSegment * cap)()
+        check(lib().fvad_vad_segments(self.h, buf, cap, C.byref(n)), "vad_segments")
+        return [(buf[i].sample_from, buf[i].sample_to, buf[i].avg_channel_vol_ratio,
+                 buf[i].vad_met_sec) for i in range(n.value)]
+
+    def audit(self):
+        a = VadAudit()
+        check(lib().fvad_vad_audit_get(self.h, C.byref(a)), "audit")
+        return a.min_rel_threshold_margin, a.min_abs_ratio_margin, a.n_frames
+
+    def close(self):
+        if self.h:
+            lib().fvad_vad_destroy(self.h)
+            self.h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def vad_run_many(machines, bands, ratios, first_index=None, fft_size=1024, n_threads=1):
+    """machines: list[VadMachine]; bands[s]: [n_frames][C] f32; ratios[s]: [n_frames] f32 (NaN=null)"""
+    n = len(machines)
+    C_ = machines[0].n_channels
+    hs = (vp * n)(*[m.h for m in machines])
+    bands = [np.ascontiguousarray(b, np.float32).reshape(-1, C_) for b in bands]
+    ratios = [np.ascontiguousarray(r, np.float32) for r in ratios]
+    bp = (c_float_p * n)(*[fptr(b) for b in bands])
+    rp = (c_float_p * n)(*[fptr(r) for r in ratios])
+    nf = (sz * n)(*[b.shape[0] for b in bands])
+    fi = (C.c_uint64 * n)(*(first_index or [0] * n))
+    check(lib().fvad_vad_run_many(hs, n, bp, rp, nf, C_, fi, fft_size, n_threads),
+          "fvad_vad_run_many")
+
+
+def stats_from_segments(vad, ref, cfg):
+    """vad/ref: lists of (from_sec, to_sec); cfg: dict -> SingleStats"""
+    v = (SegmentSec * max(len(vad), 1))(*[SegmentSec(a, b) for a, b in vad])
+    r = (SegmentSec * max(len(ref), 1))(*[SegmentSec(a, b) for a, b in ref])
+    sc = StatConfig(cfg.get("ignore_shorter_than_sec", 0.0), cfg.get("extrude_start", 0.0),
+                    cfg.get("extrude_end", 0.0), cfg.get("fill_gaps", 0.0))
+    out = SingleStats()
+    check(lib().fvad_stats_from_segments(v, len(vad), r, len(ref), C.byref(sc), C.byref(out)),
+          "statistics.fromEvaluator")
+    return out
+
+
+def stats_aggregate(stats):
+    arr = (SingleStats * max(len(stats), 1))(*stats)
+    out = AggregateStats()
+    check(lib().fvad_stats_aggregate(arr, len(stats), C.byref(out)), "statistics.aggregate")
+    return out
+
+
+def single_stats_to_array(s):
+    return np.array([getattr(s, n) for n, _ in SingleStats._fields_], np.float32)
+
+
+def array_to_single_stats(a):
+    s = SingleStats()
+    for (n, _), v in zip(SingleStats._fields_, a):
+        setattr(s, n, float(v))
+    return s

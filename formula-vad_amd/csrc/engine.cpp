@@ -1,0 +1,696 @@
+// engine.cpp -- context, device model, workspace and the batched engine of libfvad_hip.so.
+//
+// Batch formulation: the NSNet2 GRU state is reset for every 0.5 s chunk
+// and every other stage is feed-forward, so all chunks of all lanes (lane = one channel of one
+// stream) are processed together; cross-chunk effects (160-sample input hop, 4 warm-up feature
+// rows, overlap-add tail, upsampler's last sample: src/NSNet2.zig:27-33,175-203) are either
+// recomputed from the contiguous lane audio or, at the first chunk of a launch, read from the
+// lane's LaneCarry.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "internal.h"
+
+namespace fvad {
+
+int set_err(const fvad_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+int hip_fail(const fvad_ctx* ctx, hipError_t e, const char* what)
+{
+    return set_err(ctx, FVAD_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+static int dev_alloc(fvad_ctx* ctx, float** p, size_t n_floats, bool zero)
+{
+    FVAD_HIP(ctx, hipMalloc((void**)p, n_floats * sizeof(float)));
+    if (zero) FVAD_HIP(ctx, hipMemsetAsync(*p, 0, n_floats * sizeof(float), ctx->stream));
+    return FVAD_OK;
+}
+
+static int upload(fvad_ctx* ctx, DevBuf& b, const std::vector<float>& v)
+{
+    if (b.p) { hipFree(b.p); b.p = nullptr; }
+    b.n = v.size();
+    FVAD_HIP(ctx, hipMalloc((void**)&b.p, v.size() * sizeof(float)));
+    FVAD_HIP(ctx, hipMemcpy(b.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return FVAD_OK;
+}
+
+static std::vector<float> padded(const float* b, size_t n, size_t n_pad)
+{
+    std::vector<float> v(n_pad, 0.0f);
+    std::copy(b, b + n, v.begin());
+    return v;
+}
+
+int upload_model(fvad_ctx* ctx)
+{
+    const HostWeights& w = ctx->hw;
+    std::string err;
+    if (!w.check_dims(err)) return set_err(ctx, FVAD_ERR_MODEL_FORMAT, err);
+    DeviceModel& m = ctx->dm;
+    const int H = 400;
+    std::vector<float> f;
+    int rc;
+    // fc1: 161 -> 400, K padded to 176 (11 super-steps), one block of 25 tiles
+    pack_panel(w.fc1_w.data(), 400, 161, 1, 25, 11, f);
+    if ((rc = upload(ctx, m.fc1_w, f))) return rc;
+    if ((rc = upload(ctx, m.fc1_b, w.fc1_b))) return rc;
+    // GRU input projections: 400 -> 1200 as 3 blocks (z, r, h) of 25 tiles; bias = Wb
+    pack_panel(w.gru1_w.data(), 1200, 400, 3, 25, 25, f);
+    if ((rc = upload(ctx, m.gi1_w, f))) return rc;
+    if ((rc = upload(ctx, m.gi1_b, std::vector<float>(w.gru1_b.begin(), w.gru1_b.begin() + 3 * H)))) return rc;
+    pack_gru_r(w.gru1_r.data(), H, f);
+    if ((rc = upload(ctx, m.r1, f))) return rc;
+    if ((rc = upload(ctx, m.br1, std::vector<float>(w.gru1_b.begin() + 3 * H, w.gru1_b.end())))) return rc;
+    pack_panel(w.gru2_w.data(), 1200, 400, 3, 25, 25, f);
+    if ((rc = upload(ctx, m.gi2_w, f))) return rc;
+    if ((rc = upload(ctx, m.gi2_b, std::vector<float>(w.gru2_b.begin(), w.gru2_b.begin() + 3 * H)))) return rc;
+    pack_gru_r(w.gru2_r.data(), H, f);
+    if ((rc = upload(ctx, m.r2, f))) return rc;
+    if ((rc = upload(ctx, m.br2, std::vector<float>(w.gru2_b.begin() + 3 * H, w.gru2_b.end())))) return rc;
+    // fc2: 400 -> 600 (N padded to 608 = 2 blocks of 19 tiles)
+    pack_panel(w.fc2_w.data(), 600, 400, 2, 19, 25, f);
+    if ((rc = upload(ctx, m.fc2_w, f))) return rc;
+    if ((rc = upload(ctx, m.fc2_b, padded(w.fc2_b.data(), 600, 608)))) return rc;
+    // fc3: 600 -> 600 (K padded to 608 = 38 super-steps)
+    pack_panel(w.fc3_w.data(), 600, 600, 2, 19, 38, f);
+    if ((rc = upload(ctx, m.fc3_w, f))) return rc;
+    if ((rc = upload(ctx, m.fc3_b, padded(w.fc3_b.data(), 600, 608)))) return rc;
+    // fc4: 600 -> 161 (N padded to 176 = 11 tiles)
+    pack_panel(w.fc4_w.data(), 161, 600, 1, 11, 38, f);
+    if ((rc = upload(ctx, m.fc4_w, f))) return rc;
+    if ((rc = upload(ctx, m.fc4_b, padded(w.fc4_b.data(), 161, 176)))) return rc;
+    m.loaded = true;
+    return FVAD_OK;
+}
+
+static void free_workspace_nn(Workspace& ws)
+{
+    float** bufs[] = {&ws.feat, &ws.spec, &ws.rms, &ws.a1, &ws.gi, &ws.h1, &ws.h2, &ws.f2, &ws.f3, &ws.gains};
+    for (float** b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
+    if (ws.descs) hipFree(ws.descs);
+    if (ws.h_descs) hipHostFree(ws.h_descs);
+    ws.descs = nullptr; ws.h_descs = nullptr;
+    ws.cap_chunks = 0;
+}
+
+int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
+{
+    Workspace& ws = ctx->ws;
+    const long need = ((n_chunks + 127) / 128) * 128;
+    if (need <= ws.cap_chunks && T <= ws.T) return FVAD_OK;
+    hipStreamSynchronize(ctx->stream);
+    free_workspace_nn(ws);
+    const long G = std::max(need, ws.cap_chunks);
+    const int TT = std::max(T, ws.T);
+    const size_t rows = (size_t)G * TT;
+    int rc;
+    FVAD_HIP(ctx, hipMalloc((void**)&ws.descs, (size_t)G * sizeof(ChunkDesc)));
+    FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_descs, (size_t)G * sizeof(ChunkDesc), hipHostMallocDefault));
+    // zero-filled: padded rows / padded columns are read by the GEMMs and must stay finite
+    if ((rc = dev_alloc(ctx, &ws.feat, rows * kFeatStride, true))) return rc;
+    if ((rc = dev_alloc(ctx, &ws.spec, (size_t)G * kFramesPerChunk * kNBins * 2, true))) return rc;
+    if ((rc = dev_alloc(ctx, &ws.rms, (size_t)G, true))) return rc;
+    if ((rc = dev_alloc(ctx, &ws.a1, rows * 400, true))) return rc;
+    if ((rc = dev_alloc(ctx, &ws.gi, rows * 1200, true))) return rc;
+    if ((rc = dev_alloc(ctx, &ws.h1, rows * 400, true))) return rc;
+    if ((rc = dev_alloc(ctx, &ws.h2, rows * 400, true))) return rc;
+    if ((rc = dev_alloc(ctx, &ws.f2, rows * 608, true))) return rc;
+    if ((rc = dev_alloc(ctx, &ws.f3, rows * 608, true))) return rc;
+    if ((rc = dev_alloc(ctx, &ws.gains, rows * kFeatStride, true))) return rc;
+    ws.cap_chunks = G;
+    ws.T = TT;
+    return FVAD_OK;
+}
+
+void time_begin(fvad_ctx* ctx, const char* name)
+{
+    if (!ctx->timing) return;
+    KernelTime kt;
+    kt.name = name;
+    hipEventCreate(&kt.e0);
+    hipEventCreate(&kt.e1);
+    hipEventRecord(kt.e0, ctx->stream);
+    ctx->times.push_back(kt);
+}
+void time_end(fvad_ctx* ctx)
+{
+    if (!ctx->timing) return;
+    hipEventRecord(ctx->times.back().e1, ctx->stream);
+}
+
+static int gru_waves_for(long n_pad)
+{
+    // most chunks per workgroup that still leaves >= 256 workgroups (one per CU); R is streamed
+    // from L2 once per workgroup per step, so wider workgroups amortise it over more chunks
+    if (n_pad / 128 >= 256) return 8;
+    if (n_pad / 64 >= 256) return 4;
+    if (n_pad / 64 >= 64) return 4;
+    return 1;
+}
+
+int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
+{
+    if (!ctx->dm.loaded) return set_err(ctx, FVAD_ERR_NO_MODEL, "NSNet2 weights not loaded");
+    Workspace& ws = ctx->ws;
+    const DeviceModel& m = ctx->dm;
+    hipStream_t st = ctx->stream;
+    const long rows = n_pad * T;
+    const long rows_out = n_pad * (T - skip);
+    int rc = 0;
+    time_begin(ctx, "fc1_gemm");
+    rc |= fvad_launch_panel_gemm(ws.feat, kFeatStride, m.fc1_w.p, m.fc1_b.p, ws.a1, 400, rows, 25, 1, 11, FVAD_ACT_NONE, 0, 0, st);
+    time_end(ctx);
+    time_begin(ctx, "gru1_in_gemm");
+    rc |= fvad_launch_panel_gemm(ws.a1, 400, m.gi1_w.p, m.gi1_b.p, ws.gi, 1200, rows, 25, 3, 25, FVAD_ACT_NONE, 0, 0, st);
+    time_end(ctx);
+    const int waves = gru_waves_for(n_pad);
+    time_begin(ctx, "gru1_rec");
+    rc |= fvad_launch_gru_rec(ws.gi, m.r1.p, m.br1.p, ws.h1, n_pad, T, waves, st);
+    time_end(ctx);
+    time_begin(ctx, "gru2_in_gemm");
+    rc |= fvad_launch_panel_gemm(ws.h1, 400, m.gi2_w.p, m.gi2_b.p, ws.gi, 1200, rows, 25, 3, 25, FVAD_ACT_NONE, 0, 0, st);
+    time_end(ctx);
+    time_begin(ctx, "gru2_rec");
+    rc |= fvad_launch_gru_rec(ws.gi, m.r2.p, m.br2.p, ws.h2, n_pad, T, waves, st);
+    time_end(ctx);
+    time_begin(ctx, "fc2_gemm");
+    rc |= fvad_launch_panel_gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, skip ? T : 0, skip, st);
+    time_end(ctx);
+    time_begin(ctx, "fc3_gemm");
+    rc |= fvad_launch_panel_gemm(ws.f2, 608, m.fc3_w.p, m.fc3_b.p, ws.f3, 608, rows_out, 19, 2, 38, FVAD_ACT_RELU, 0, 0, st);
+    time_end(ctx);
+    time_begin(ctx, "fc4_gemm");
+    rc |= fvad_launch_panel_gemm(ws.f3, 608, m.fc4_w.p, m.fc4_b.p, ws.gains, kFeatStride, rows_out, 11, 1, 38, FVAD_ACT_SIGMOID, 0, 0, st);
+    time_end(ctx);
+    if (rc) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "no kernel instance for this layer shape");
+    FVAD_HIP(ctx, hipGetLastError());
+    return FVAD_OK;
+}
+
+// K1 -> NSNet2 -> K3 over every chunk of every job, in launches of <= max_chunks chunks.
+int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks)
+{
+    if (max_chunks <= 0) max_chunks = 16384;
+    long total = 0;
+    for (auto& j : jobs) total += (long)j.n_chunks;
+    if (total == 0) return FVAD_OK;
+    int rc = ensure_workspace(ctx, std::min(total, max_chunks), kRowsPerChunk);
+    if (rc) return rc;
+    Workspace& ws = ctx->ws;
+    const long cap = std::min<long>(max_chunks, ws.cap_chunks);
+
+    size_t job = 0, chunk_in_job = 0;
+    while (job < jobs.size()) {
+        // fill one launch, lane-contiguous
+        long n = 0;
+        std::vector<size_t> touched;
+        ChunkDesc* hd = ws.h_descs;
+        size_t j = job, c = chunk_in_job;
+        while (j < jobs.size() && n < cap) {
+            LaneJob& lj = jobs[j];
+            if (lj.n_chunks == 0) { ++j; c = 0; continue; }
+            const size_t take = std::min<size_t>(lj.n_chunks - c, (size_t)(cap - n));
+            for (size_t k = 0; k < take; ++k) {
+                ChunkDesc& d = hd[n + (long)k];
+                d.in = lj.d_in + (c + k) * (size_t)kChunk48;
+                d.den = lj.d_den + (c + k) * (size_t)kChunk48;
+                d.carry_in = lj.carry[lj.cur];
+                d.carry_out = lj.carry[lj.cur ^ 1];
+                d.first = (k == 0);
+                d.last = (k + 1 == take);
+            }
+            touched.push_back(j);
+            // per-chunk RMS lands in ws.rms[n..]; remember where to copy it
+            n += (long)take;
+            c += take;
+            if (c == lj.n_chunks) { ++j; c = 0; }
+        }
+        // the stream orders this copy after the previous launch's kernels
+        FVAD_HIP(ctx, hipMemcpyAsync(ws.descs, hd, (size_t)n * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
+        time_begin(ctx, "stft320_logpow");
+        fvad_launch_stft(ws.descs, (int)n, ctx->tb, ws.feat, ws.spec, ws.rms, ctx->stream);
+        time_end(ctx);
+        const long n_pad = ((n + 127) / 128) * 128;
+        rc = run_nn(ctx, n_pad, kRowsPerChunk, kWarmupRows);
+        if (rc) return rc;
+        time_begin(ctx, "istft320_ola_up3");
+        fvad_launch_istft(ws.descs, (int)n, ctx->tb, ws.spec, ws.gains, kFramesPerChunk, 0, ctx->stream);
+        time_end(ctx);
+        // scatter the RMS values to the jobs
+        {
+            long off = 0;
+            size_t jj = job, cc = chunk_in_job;
+            while (off < n) {
+                LaneJob& lj = jobs[jj];
+                if (lj.n_chunks == 0) { ++jj; cc = 0; continue; }
+                const size_t take = std::min<size_t>(lj.n_chunks - cc, (size_t)(n - off));
+                if (lj.d_rms)
+                    FVAD_HIP(ctx, hipMemcpyAsync(lj.d_rms + cc, ws.rms + off, take * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+                off += (long)take;
+                cc += take;
+                if (cc == lj.n_chunks) { ++jj; cc = 0; }
+            }
+        }
+        for (size_t t : touched) jobs[t].cur ^= 1;
+        // the pinned descriptor table is reused by the next launch
+        FVAD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        job = j;
+        chunk_in_job = c;
+    }
+    FVAD_HIP(ctx, hipGetLastError());
+    return FVAD_OK;
+}
+
+} // namespace fvad
+
+using namespace fvad;
+
+// ------------------------------------------------------------------ C ABI: context + model
+extern "C" {
+
+int fvad_abi_version(void) { return FVAD_ABI_VERSION; }
+
+const char* fvad_status_name(int s)
+{
+    switch (s) {
+    case FVAD_OK: return "Ok";
+    case FVAD_ERR_INVALID_FFT_SIZE: return "InvalidFFTSize";
+    case FVAD_ERR_INVALID_SAMPLES_LENGTH: return "InvalidSamplesLength";
+    case FVAD_ERR_INVALID_WINDOW_LENGTH: return "InvalidWindowLength";
+    case FVAD_ERR_INVALID_RESULT_LENGTH: return "InvalidResultLength";
+    case FVAD_ERR_INVALID_BINS_LENGTH: return "InvalidBinsLength";
+    case FVAD_ERR_OUT_OF_RANGE: return "OutOfRange";
+    case FVAD_ERR_NEGATIVE_FREQUENCY: return "NegativeFrequency";
+    case FVAD_ERR_INVALID_INPUT_LENGTH: return "InvalidInputLength";
+    case FVAD_ERR_INVALID_SAMPLE_RATE: return "InvalidSampleRate";
+    case FVAD_ERR_CHANNEL_COUNT_MISMATCH: return "ChannelCountMismatch";
+    case FVAD_ERR_ALLOC_FAILED: return "OutOfMemory";
+    case FVAD_ERR_INVALID_ARGUMENT: return "InvalidArgument";
+    case FVAD_ERR_NO_DEVICE: return "NoDevice";
+    case FVAD_ERR_HIP: return "HipError";
+    case FVAD_ERR_NO_MODEL: return "NoModel";
+    case FVAD_ERR_MODEL_FORMAT: return "ModelFormat";
+    case FVAD_ERR_IO: return "IoError";
+    case FVAD_ERR_BUFFER_TOO_SMALL: return "BufferTooSmall";
+    default: return "Unknown";
+    }
+}
+
+int fvad_ctx_create(int device, fvad_ctx** out)
+{
+    if (!out) return FVAD_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) return FVAD_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return FVAD_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FVAD_ERR_NO_DEVICE; // code objects are gfx950-only
+    if (hipSetDevice(device) != hipSuccess) return FVAD_ERR_NO_DEVICE;
+    auto* ctx = new (std::nothrow) fvad_ctx();
+    if (!ctx) return FVAD_ERR_ALLOC_FAILED;
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return FVAD_ERR_HIP; }
+
+    // constant tables: one device allocation, sub-ranges 64-float aligned
+    std::vector<float> win320(320), win320n(320), win1024(1024), tw160, st320, tw512, st1024;
+    nsnet2_window(win320.data());
+    const float vol_norm_factor = 1 / (float)kNFft; // NSNet2.zig:323
+    for (int i = 0; i < 320; ++i) win320n[i] = win320[i] * vol_norm_factor;
+    hann_window_periodic(win1024.data(), 1024);
+    make_twiddles(160, tw160);
+    make_super_twiddles(160, st320);
+    make_twiddles(512, tw512);
+    make_super_twiddles(512, st1024);
+    ctx->h_win320 = win320;
+    ctx->h_win1024 = win1024;
+    std::vector<float> all;
+    auto put = [&](const std::vector<float>& v) { const size_t o = all.size(); all.insert(all.end(), v.begin(), v.end()); all.resize((all.size() + 63) / 64 * 64); return o; };
+    const size_t o_w320 = put(win320), o_w320n = put(win320n), o_tw160 = put(tw160), o_st320 = put(st320),
+                 o_w1024 = put(win1024), o_tw512 = put(tw512), o_st1024 = put(st1024);
+    if (hipMalloc((void**)&ctx->d_tables, all.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(ctx->d_tables, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        fvad_ctx_destroy(ctx);
+        return FVAD_ERR_HIP;
+    }
+    ctx->tb.win320 = ctx->d_tables + o_w320;
+    ctx->tb.win320n = ctx->d_tables + o_w320n;
+    ctx->tb.tw160 = ctx->d_tables + o_tw160;
+    ctx->tb.st320 = ctx->d_tables + o_st320;
+    ctx->tb.win1024 = ctx->d_tables + o_w1024;
+    ctx->tb.tw512 = ctx->d_tables + o_tw512;
+    ctx->tb.st1024 = ctx->d_tables + o_st1024;
+    ctx->tb.norm1024 = window_norm_factor(win1024.data(), 1024) / (float)1024; // BufferedFFT.zig:99
+    *out = ctx;
+    return FVAD_OK;
+}
+
+void fvad_ctx_destroy(fvad_ctx* ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    free_workspace_nn(ctx->ws);
+    Workspace& ws = ctx->ws;
+    if (ws.in) hipFree(ws.in);
+    if (ws.den) hipFree(ws.den);
+    if (ws.band) hipFree(ws.band);
+    if (ws.bins) hipFree(ws.bins);
+    if (ws.carries) hipFree(ws.carries);
+    DeviceModel& m = ctx->dm;
+    DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.gi1_w, &m.gi1_b, &m.r1, &m.br1, &m.gi2_w, &m.gi2_b, &m.r2, &m.br2,
+                      &m.fc2_w, &m.fc2_b, &m.fc3_w, &m.fc3_b, &m.fc4_w, &m.fc4_b};
+    for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+    if (ctx->d_tables) hipFree(ctx->d_tables);
+    for (auto& kt : ctx->times) { hipEventDestroy(kt.e0); hipEventDestroy(kt.e1); }
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* fvad_last_error(const fvad_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int fvad_ctx_synchronize(fvad_ctx* ctx)
+{
+    if (!ctx) return FVAD_ERR_INVALID_ARGUMENT;
+    FVAD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FVAD_OK;
+}
+void* fvad_ctx_stream(fvad_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int fvad_ctx_enable_timing(fvad_ctx* ctx, int on)
+{
+    if (!ctx) return FVAD_ERR_INVALID_ARGUMENT;
+    ctx->timing = on != 0;
+    return FVAD_OK;
+}
+
+int fvad_ctx_kernel_times(fvad_ctx* ctx, const char** names, float* ms, size_t cap, size_t* n)
+{
+    if (!ctx || !n) return FVAD_ERR_INVALID_ARGUMENT;
+    FVAD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // fold repeated names (several launches per call) into one sum per kernel, in first-seen order
+    ctx->time_names.clear();
+    ctx->time_ms.clear();
+    for (auto& kt : ctx->times) {
+        float t = 0;
+        hipEventElapsedTime(&t, kt.e0, kt.e1);
+        size_t i = 0;
+        for (; i < ctx->time_names.size(); ++i) if (ctx->time_names[i] == kt.name) break;
+        if (i == ctx->time_names.size()) { ctx->time_names.push_back(kt.name); ctx->time_ms.push_back(0); }
+        ctx->time_ms[i] += t;
+        hipEventDestroy(kt.e0);
+        hipEventDestroy(kt.e1);
+    }
+    ctx->times.clear();
+    *n = ctx->time_names.size();
+    for (size_t i = 0; i < *n && i < cap; ++i) {
+        if (names) names[i] = ctx->time_names[i].c_str();
+        if (ms) ms[i] = ctx->time_ms[i];
+    }
+    return FVAD_OK;
+}
+
+int fvad_load_nsnet2_weights(fvad_ctx* ctx, const fvad_nsnet2_weights* w)
+{
+    if (!ctx) return FVAD_ERR_INVALID_ARGUMENT;
+    std::string err;
+    if (!ctx->hw.from_view(w, err)) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, err);
+    hipSetDevice(ctx->device);
+    return upload_model(ctx);
+}
+
+int fvad_load_nsnet2_synth(fvad_ctx* ctx, uint64_t seed)
+{
+    if (!ctx) return FVAD_ERR_INVALID_ARGUMENT;
+    synth_weights(seed, ctx->hw);
+    hipSetDevice(ctx->device);
+    return upload_model(ctx);
+}
+
+int fvad_load_nsnet2_onnx(fvad_ctx* ctx, const char* path)
+{
+    if (!ctx || !path) return FVAD_ERR_INVALID_ARGUMENT;
+    std::string err;
+    const int rc = read_onnx_nsnet2(path, ctx->hw, err);
+    if (rc) return set_err(ctx, rc, err);
+    hipSetDevice(ctx->device);
+    return upload_model(ctx);
+}
+
+int fvad_get_nsnet2_weights(const fvad_ctx* ctx, fvad_nsnet2_weights* out)
+{
+    if (!ctx || !out) return FVAD_ERR_INVALID_ARGUMENT;
+    if (!ctx->dm.loaded) return set_err(ctx, FVAD_ERR_NO_MODEL, "NSNet2 weights not loaded");
+    ctx->hw.view(out);
+    return FVAD_OK;
+}
+
+// ------------------------------------------------------------------ NSNet2 graph only
+int fvad_nsnet2_forward(fvad_ctx* ctx, const float* features, size_t n_seq, size_t T, float* gains)
+{
+    if (!ctx || !features || !gains || n_seq == 0 || T == 0) return FVAD_ERR_INVALID_ARGUMENT;
+    hipSetDevice(ctx->device);
+    int rc = ensure_workspace(ctx, (long)n_seq, (int)T);
+    if (rc) return rc;
+    Workspace& ws = ctx->ws;
+    const long n_pad = (((long)n_seq + 127) / 128) * 128;
+    // rows are [n_seq*T][161] on the host, [.][176] on the device
+    FVAD_HIP(ctx, hipMemsetAsync(ws.feat, 0, (size_t)n_pad * T * kFeatStride * sizeof(float), ctx->stream));
+    FVAD_HIP(ctx, hipMemcpy2DAsync(ws.feat, kFeatStride * sizeof(float), features, kNBins * sizeof(float),
+                                   kNBins * sizeof(float), n_seq * T, hipMemcpyHostToDevice, ctx->stream));
+    rc = run_nn(ctx, n_pad, (int)T, 0);
+    if (rc) return rc;
+    FVAD_HIP(ctx, hipMemcpy2DAsync(gains, kNBins * sizeof(float), ws.gains, kFeatStride * sizeof(float),
+                                   kNBins * sizeof(float), n_seq * T, hipMemcpyDeviceToHost, ctx->stream));
+    FVAD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FVAD_OK;
+}
+
+// ------------------------------------------------------------------ lane state
+int fvad_lane_state_create(fvad_ctx* ctx, fvad_lane_state** out)
+{
+    if (!ctx || !out) return FVAD_ERR_INVALID_ARGUMENT;
+    hipSetDevice(ctx->device);
+    auto* s = new (std::nothrow) fvad_lane_state();
+    if (!s) return FVAD_ERR_ALLOC_FAILED;
+    s->ctx = ctx;
+    for (int i = 0; i < 2; ++i)
+        if (hipMalloc((void**)&s->carry[i], sizeof(LaneCarry)) != hipSuccess) { fvad_lane_state_destroy(s); return FVAD_ERR_HIP; }
+    if (hipMalloc((void**)&s->den_rem, kVadFft * sizeof(float)) != hipSuccess) { fvad_lane_state_destroy(s); return FVAD_ERR_HIP; }
+    fvad_lane_state_reset(s);
+    *out = s;
+    return FVAD_OK;
+}
+
+void fvad_lane_state_reset(fvad_lane_state* s)
+{
+    if (!s) return;
+    hipSetDevice(s->ctx->device);
+    // zero history == the reference's freshly initialised NSNet2 (NSNet2.zig:79,116,120,33)
+    for (int i = 0; i < 2; ++i) hipMemsetAsync(s->carry[i], 0, sizeof(LaneCarry), s->ctx->stream);
+    hipMemsetAsync(s->den_rem, 0, kVadFft * sizeof(float), s->ctx->stream);
+    hipStreamSynchronize(s->ctx->stream);
+    s->cur = 0;
+    s->n_rem = 0;
+    s->samples_consumed = 0;
+    s->next_frame_index = 0;
+}
+
+void fvad_lane_state_destroy(fvad_lane_state* s)
+{
+    if (!s) return;
+    for (int i = 0; i < 2; ++i) if (s->carry[i]) hipFree(s->carry[i]);
+    if (s->den_rem) hipFree(s->den_rem);
+    delete s;
+}
+
+void fvad_engine_opts_default(fvad_engine_opts* o)
+{
+    o->on_device = 0;
+    o->min_bin = 11; // FFT.freqToBin(500) at 48 kHz / 1024 (FFT.zig:156-167)
+    o->max_bin = 43; // FFT.freqToBin(2000)
+    o->max_chunks_per_launch = 0;
+}
+
+static int grow(fvad_ctx* ctx, float** p, size_t* cap, size_t need)
+{
+    if (need <= *cap) return FVAD_OK;
+    hipStreamSynchronize(ctx->stream);
+    if (*p) hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    FVAD_HIP(ctx, hipMalloc((void**)p, need * sizeof(float)));
+    *cap = need;
+    return FVAD_OK;
+}
+
+int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_engine_opts* opts_in)
+{
+    if (!ctx || (n_lanes && !lanes)) return FVAD_ERR_INVALID_ARGUMENT;
+    fvad_engine_opts opts;
+    if (opts_in) opts = *opts_in; else fvad_engine_opts_default(&opts);
+    if (opts.min_bin < 0 || opts.max_bin > 512 || opts.max_bin < opts.min_bin) return set_err(ctx, FVAD_ERR_OUT_OF_RANGE, "band bins out of range");
+    if (!ctx->dm.loaded) return set_err(ctx, FVAD_ERR_NO_MODEL, "NSNet2 weights not loaded");
+    hipSetDevice(ctx->device);
+    Workspace& ws = ctx->ws;
+    hipStream_t st = ctx->stream;
+
+    // ---- sizes and staging layout (every lane region 64-float aligned)
+    size_t in_total = 0, den_total = 0, frames_total = 0, chunks_total = 0;
+    std::vector<size_t> in_off(n_lanes), den_off(n_lanes), band_off(n_lanes), rms_off(n_lanes), n_rem(n_lanes);
+    bool want_bins = false;
+    for (size_t l = 0; l < n_lanes; ++l) {
+        fvad_lane& L = lanes[l];
+        if (!L.pcm && L.n_samples) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "lane without pcm");
+        L.n_chunks = L.n_samples / kChunk48;
+        n_rem[l] = L.state ? L.state->n_rem : 0;
+        const size_t n_den = n_rem[l] + L.n_chunks * kChunk48;
+        L.n_fft_frames = n_den / kVadFft;
+        L.first_frame_index = L.state ? L.state->next_frame_index : 0;
+        if (L.n_fft_frames > L.band_sum_capacity || L.n_chunks > L.chunk_rms_capacity)
+            return set_err(ctx, FVAD_ERR_BUFFER_TOO_SMALL, "band_sum / chunk_rms capacity too small");
+        if (L.fft_bins) want_bins = true;
+        in_off[l] = in_total;
+        in_total += (L.n_chunks * kChunk48 + 63) / 64 * 64;
+        den_off[l] = den_total;
+        den_total += (kVadFft + L.n_chunks * kChunk48 + 63) / 64 * 64;
+        band_off[l] = frames_total;
+        frames_total += L.n_fft_frames;
+        rms_off[l] = chunks_total;
+        chunks_total += L.n_chunks;
+    }
+    int rc;
+    if (!opts.on_device && (rc = grow(ctx, &ws.in, &ws.in_cap, in_total))) return rc;
+    if ((rc = grow(ctx, &ws.den, &ws.den_cap, den_total))) return rc;
+    if ((rc = grow(ctx, &ws.band, &ws.band_cap, frames_total + chunks_total + 64))) return rc;
+    if (want_bins && (rc = grow(ctx, &ws.bins, &ws.bins_cap, frames_total * kVadBins))) return rc;
+    // scratch carries for stateless lanes
+    size_t n_scratch = 0;
+    for (size_t l = 0; l < n_lanes; ++l) if (!lanes[l].state) n_scratch += 2;
+    if (n_scratch * sizeof(LaneCarry) > ws.carries_cap) {
+        hipStreamSynchronize(st);
+        if (ws.carries) hipFree(ws.carries);
+        ws.carries = nullptr; ws.carries_cap = 0;
+        FVAD_HIP(ctx, hipMalloc((void**)&ws.carries, n_scratch * sizeof(LaneCarry)));
+        ws.carries_cap = n_scratch * sizeof(LaneCarry);
+    }
+    if (n_scratch) FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
+
+    float* d_rms = ws.band + frames_total;
+    std::vector<LaneJob> jobs(n_lanes);
+    size_t scratch_i = 0;
+    for (size_t l = 0; l < n_lanes; ++l) {
+        fvad_lane& L = lanes[l];
+        LaneJob& j = jobs[l];
+        const size_t n_in = L.n_chunks * kChunk48;
+        if (opts.on_device) j.d_in = L.pcm;
+        else {
+            if (n_in) FVAD_HIP(ctx, hipMemcpyAsync(ws.in + in_off[l], L.pcm, n_in * sizeof(float), hipMemcpyHostToDevice, st));
+            j.d_in = ws.in + in_off[l];
+        }
+        // denoised region: [1024-float prefix | chunks]; the not-yet-FFT'd remainder of the previous
+        // call sits right in front of the new audio so that K4 sees one contiguous signal
+        float* den_base = ws.den + den_off[l] + kVadFft;
+        j.d_den = den_base;
+        j.n_chunks = L.n_chunks;
+        j.d_rms = d_rms + rms_off[l];
+        if (L.state) {
+            j.carry[0] = L.state->carry[0]; j.carry[1] = L.state->carry[1]; j.cur = L.state->cur;
+            if (n_rem[l]) FVAD_HIP(ctx, hipMemcpyAsync(den_base - n_rem[l], L.state->den_rem, n_rem[l] * sizeof(float), hipMemcpyDeviceToDevice, st));
+        } else {
+            j.carry[0] = ws.carries + scratch_i; j.carry[1] = ws.carries + scratch_i + 1; j.cur = 0;
+            scratch_i += 2;
+        }
+    }
+    if ((rc = run_chunks(ctx, jobs, opts.max_chunks_per_launch))) return rc;
+
+    // ---- K4 per lane + outputs
+    for (size_t l = 0; l < n_lanes; ++l) {
+        fvad_lane& L = lanes[l];
+        const float* den_start = jobs[l].d_den - n_rem[l];
+        if (L.n_fft_frames) {
+            time_begin(ctx, "fft1024_bandsum");
+            fvad_launch_vadfft(den_start, (long)L.n_fft_frames, ctx->tb, opts.min_bin, opts.max_bin, ws.band + band_off[l],
+                               L.fft_bins ? ws.bins + band_off[l] * kVadBins : nullptr, st);
+            time_end(ctx);
+            FVAD_HIP(ctx, hipMemcpyAsync(L.band_sum, ws.band + band_off[l], L.n_fft_frames * sizeof(float), hipMemcpyDeviceToHost, st));
+            if (L.fft_bins)
+                FVAD_HIP(ctx, hipMemcpyAsync(L.fft_bins, ws.bins + band_off[l] * kVadBins, L.n_fft_frames * kVadBins * sizeof(float), hipMemcpyDeviceToHost, st));
+        }
+        if (L.n_chunks) {
+            FVAD_HIP(ctx, hipMemcpyAsync(L.chunk_rms, d_rms + rms_off[l], L.n_chunks * sizeof(float), hipMemcpyDeviceToHost, st));
+            if (L.denoised)
+                FVAD_HIP(ctx, hipMemcpyAsync(L.denoised, jobs[l].d_den, L.n_chunks * kChunk48 * sizeof(float),
+                                             opts.on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+        }
+        if (L.state) {
+            const size_t n_den = n_rem[l] + L.n_chunks * kChunk48;
+            const size_t rem = n_den - L.n_fft_frames * kVadFft;
+            if (rem) FVAD_HIP(ctx, hipMemcpyAsync(L.state->den_rem, den_start + L.n_fft_frames * kVadFft, rem * sizeof(float), hipMemcpyDeviceToDevice, st));
+            L.state->n_rem = rem;
+            L.state->cur = jobs[l].cur;
+            L.state->samples_consumed += L.n_chunks * kChunk48;
+            L.state->next_frame_index += L.n_fft_frames * (uint64_t)kVadFft;
+        }
+    }
+    FVAD_HIP(ctx, hipStreamSynchronize(st));
+    FVAD_HIP(ctx, hipGetLastError());
+    return FVAD_OK;
+}
+
+int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes, size_t lane_stride, size_t n_samples,
+                               float* d_denoised, float* d_band_sum, float* d_chunk_rms, const fvad_engine_opts* opts_in)
+{
+    if (!ctx || !d_pcm || !d_band_sum || n_lanes == 0) return FVAD_ERR_INVALID_ARGUMENT;
+    fvad_engine_opts opts;
+    if (opts_in) opts = *opts_in; else fvad_engine_opts_default(&opts);
+    if (!ctx->dm.loaded) return set_err(ctx, FVAD_ERR_NO_MODEL, "NSNet2 weights not loaded");
+    if (lane_stride % 4) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "lane_stride must be a multiple of 4 floats");
+    hipSetDevice(ctx->device);
+    Workspace& ws = ctx->ws;
+    hipStream_t st = ctx->stream;
+    const size_t n_chunks = n_samples / kChunk48;
+    const size_t n_den = n_chunks * kChunk48;
+    const size_t n_frames = n_den / kVadFft;
+    if (n_chunks == 0) return FVAD_OK;
+    int rc;
+    float* den = d_denoised;
+    if (!den) {
+        if ((rc = grow(ctx, &ws.den, &ws.den_cap, n_lanes * n_den))) return rc;
+        den = ws.den;
+    }
+    const size_t n_scratch = 2 * n_lanes;
+    if (n_scratch * sizeof(LaneCarry) > ws.carries_cap) {
+        hipStreamSynchronize(st);
+        if (ws.carries) hipFree(ws.carries);
+        ws.carries = nullptr; ws.carries_cap = 0;
+        FVAD_HIP(ctx, hipMalloc((void**)&ws.carries, n_scratch * sizeof(LaneCarry)));
+        ws.carries_cap = n_scratch * sizeof(LaneCarry);
+    }
+    FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
+    std::vector<LaneJob> jobs(n_lanes);
+    for (size_t l = 0; l < n_lanes; ++l) {
+        jobs[l].d_in = d_pcm + l * lane_stride;
+        jobs[l].d_den = den + l * n_den;
+        jobs[l].n_chunks = n_chunks;
+        jobs[l].carry[0] = ws.carries + 2 * l;
+        jobs[l].carry[1] = ws.carries + 2 * l + 1;
+        jobs[l].cur = 0;
+        jobs[l].d_rms = d_chunk_rms ? d_chunk_rms + l * n_chunks : nullptr;
+    }
+    if ((rc = run_chunks(ctx, jobs, opts.max_chunks_per_launch))) return rc;
+    time_begin(ctx, "fft1024_bandsum");
+    for (size_t l = 0; l < n_lanes; ++l)
+        fvad_launch_vadfft(den + l * n_den, (long)n_frames, ctx->tb, opts.min_bin, opts.max_bin, d_band_sum + l * n_frames, nullptr, st);
+    time_end(ctx);
+    FVAD_HIP(ctx, hipGetLastError());
+    return FVAD_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,447 @@
+// host_vad.cpp -- the sequential tail of the path, on the host by design.
+//
+// Mirrors src/structures/RollingAverage.zig, src/AudioPipeline/VADMetadata.zig and
+// src/AudioPipeline/VADMachine.zig of the reference: f64 rolling averages re-summed in index
+// order on every push (RollingAverage.zig:45-56), integer sample arithmetic, @intFromFloat
+// truncations.  Segment boundaries are integers decided by `short_term > threshold`
+// (VADMachine.zig:171), so this code keeps the reference's exact operation order; the GPU only
+// supplies the per-frame band sums and per-chunk RMS values that feed it.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "host_vad.h"
+
+namespace fvad {
+
+// ------------------------------------------------------------------ RollingAverage
+RollingAverage::RollingAverage(size_t count, bool has_initial, double initial_val)
+    : data(count ? count : 1, 0.0), len(count)
+{
+    if (has_initial) { // RollingAverage.zig:20-26
+        std::fill(data.begin(), data.begin() + (long)count, initial_val);
+        written_count = count;
+        avg();
+    }
+}
+
+double RollingAverage::avg() // RollingAverage.zig:45-56
+{
+    double a = 0.0;
+    const double scalar = 1.0 / (double)written_count;
+    const double* d = data.data();
+    for (size_t i = 0; i < written_count; ++i) a += d[i] * scalar;
+    last_avg = a;
+    has_last_avg = true;
+    return a;
+}
+
+double RollingAverage::push(float sample) // RollingAverage.zig:34-43
+{
+    data[write_idx] = (double)sample;
+    write_idx = (write_idx + 1) % len;
+    if (written_count < len) written_count += 1;
+    return avg();
+}
+
+// ------------------------------------------------------------------ VADMetadata
+void Metadata::push(const MetaResult& v, float weight) // VADMetadata.zig:29-60
+{
+    if (v.has_ratio) {
+        if (!has_ratio) { has_ratio = true; ratio_sum = 0.0f; ratio_weight = 0.0f; }
+        ratio_sum += v.volume_ratio * weight;
+        ratio_weight += weight;
+    }
+    if (v.has_min && (!has_min || v.volume_min < volume_min)) { has_min = true; volume_min = v.volume_min; }
+    if (v.has_max && (!has_max || v.volume_max > volume_max)) { has_max = true; volume_max = v.volume_max; }
+}
+
+MetaResult Metadata::to_result() const // VADMetadata.zig:16-27
+{
+    MetaResult r;
+    r.has_min = has_min; r.volume_min = volume_min;
+    r.has_max = has_max; r.volume_max = volume_max;
+    if (has_ratio) { r.has_ratio = true; r.volume_ratio = ratio_sum / ratio_weight; }
+    return r;
+}
+
+// BufferedVolumeAnalyzer.analyseVolume (BufferedVolumeAnalyzer.zig:48-69) from per-channel RMS
+MetaResult analyse_volume(const float* channel_rms, size_t n_channels)
+{
+    float vol_min = 1, vol_max = 0;
+    for (size_t c = 0; c < n_channels; ++c) {
+        const float vol = channel_rms[c];
+        if (vol < vol_min) vol_min = vol;
+        if (vol > vol_max) vol_max = vol;
+    }
+    MetaResult r;
+    r.has_ratio = r.has_min = r.has_max = true;
+    r.volume_ratio = (vol_max == 0) ? 0 : vol_min / vol_max;
+    r.volume_min = vol_min;
+    r.volume_max = vol_max;
+    return r;
+}
+
+// ------------------------------------------------------------------ VADMachine
+VadMachine::VadMachine(const fvad_vad_config& c, size_t sample_rate_, size_t n_channels_, size_t fft_size_)
+    : cfg(c), sample_rate(sample_rate_), n_channels(n_channels_), fft_size(fft_size_),
+      long_term(1, false, 0), short_term(1, false, 0), ch_ratio(1, false, 0)
+{
+    // VADMachine.zig:75-106
+    const float sample_rate_f = (float)sample_rate;
+    const float fft_size_f = (float)fft_size;
+    const float eval_per_sec = sample_rate_f / fft_size_f;
+    size_t long_len = (size_t)(eval_per_sec * cfg.long_term_speech_avg_sec);
+    size_t short_len = (size_t)(eval_per_sec * cfg.short_term_speech_avg_sec);
+    const size_t ratio_len = (size_t)(eval_per_sec * cfg.channel_vol_ratio_avg_sec);
+    long_len = std::max<size_t>(1, long_len);
+    short_len = std::max<size_t>(1, short_len);
+    long_term = RollingAverage(long_len, cfg.has_initial_long_term_avg != 0, cfg.initial_long_term_avg);
+    short_term = RollingAverage(short_len, false, 0);
+    ch_ratio = RollingAverage(ratio_len, false, 0);
+    segments.reserve(100); // :111
+    audit.min_rel_threshold_margin = INFINITY;
+    audit.min_abs_ratio_margin = INFINITY;
+    audit.n_frames = 0;
+}
+
+uint64_t VadMachine::offset_start(uint64_t vad_from) const // :312-317
+{
+    const uint64_t start_buffer = (uint64_t)((float)sample_rate * 2);
+    return vad_from - std::min(start_buffer, vad_from);
+}
+uint64_t VadMachine::offset_end(uint64_t vad_to) const // :320-325
+{
+    const uint64_t end_buffer = (uint64_t)((float)sample_rate * 2);
+    return vad_to + end_buffer;
+}
+
+fvad_vad_result VadMachine::on_speech_end() // :265-309
+{
+    const float sample_rate_f = (float)sample_rate;
+    const uint64_t sample_from = speech_start_index, sample_to = speech_end_index;
+    const uint64_t length_samples = sample_to - sample_from;
+    const float length_sec = (float)length_samples / sample_rate_f;
+    const bool speech_duration_met = length_sec >= cfg.min_vad_duration_sec;
+    const float avg_ratio = channel_vol_ratio_sum / (float)channel_vol_ratio_count;
+    if (speech_duration_met) {
+        fvad_speech_segment s;
+        s.sample_from = offset_start(sample_from);
+        s.sample_to = offset_end(sample_to);
+        s.avg_channel_vol_ratio = avg_ratio;
+        s.vad_met_sec = vad_threshold_met_cumulative_sec;
+        segments.push_back(s);
+        return {FVAD_REC_COMPLETED, offset_end(sample_to)};
+    }
+    return {FVAD_REC_ABORTED, 0};
+}
+
+fvad_vad_result VadMachine::finish_step(uint64_t index, bool threshold_met, bool has_ratio, float ratio)
+{
+    const float sample_rate_f = (float)sample_rate;
+    const uint64_t min_consecutive_to_open = (uint64_t)(sample_rate_f * cfg.min_consecutive_sec_to_open); // :161
+    const uint64_t max_gap_samples = (uint64_t)(sample_rate_f * cfg.max_speech_gap_sec);                 // :163
+    fvad_vad_result result = {FVAD_REC_NONE, 0};
+    const State from_state = state;
+    switch (state) { // :189-233
+    case CLOSED:
+        if (threshold_met) { state = OPENING; speech_start_index = index; }
+        break;
+    case OPENING: {
+        const uint64_t since = index - speech_start_index;
+        const bool met = since >= min_consecutive_to_open;
+        if (threshold_met && met) {
+            state = OPEN;
+            result = {FVAD_REC_STARTED, offset_start(speech_start_index)};
+        } else if (!threshold_met) {
+            state = CLOSED;
+        }
+        break;
+    }
+    case OPEN:
+        if (!threshold_met) { state = CLOSING; speech_end_index = index; }
+        break;
+    case CLOSING: {
+        const uint64_t since = index - speech_end_index;
+        const bool met = since >= max_gap_samples;
+        if (threshold_met) state = OPEN;
+        else if (met) { state = CLOSED; result = on_speech_end(); }
+        break;
+    }
+    }
+    // trackSpeechStats, :241-263
+    const float input_length_sec = (float)fft_size / sample_rate_f;
+    const float r = has_ratio ? ratio : 0;
+    if (from_state == CLOSED && state == OPENING) {
+        channel_vol_ratio_sum = r;
+        channel_vol_ratio_count = 1;
+        vad_threshold_met_cumulative_sec = input_length_sec;
+    } else if (from_state == OPEN) {
+        channel_vol_ratio_sum += r;
+        channel_vol_ratio_count += 1;
+        if (threshold_met) vad_threshold_met_cumulative_sec += input_length_sec;
+    }
+    return result;
+}
+
+bool VadMachine::decide(double short_term_avg, double ratio_avg, double* threshold_out)
+{
+    double base; // :169  last_avg orelse initial_long_term_avg orelse short_term
+    if (long_term.has_last_avg) base = long_term.last_avg;
+    else if (cfg.has_initial_long_term_avg) base = cfg.initial_long_term_avg;
+    else base = short_term_avg;
+    const double threshold = base * (double)cfg.speech_threshold_factor; // :170
+    const bool met = short_term_avg > threshold && ratio_avg > (double)cfg.channel_vol_ratio_threshold; // :171
+    // margin audit: how close was this frame to flipping?
+    if (threshold > 0) {
+        const double m = std::fabs(short_term_avg - threshold) / threshold;
+        if (m < audit.min_rel_threshold_margin) audit.min_rel_threshold_margin = m;
+    }
+    const double rm = std::fabs(ratio_avg - (double)cfg.channel_vol_ratio_threshold);
+    if (rm < audit.min_abs_ratio_margin) audit.min_abs_ratio_margin = rm;
+    audit.n_frames++;
+    if (threshold_out) *threshold_out = threshold;
+    return met;
+}
+
+float VadMachine::min_volume(const float* channel_volumes) const // :153-158
+{
+    float min_v = 999, max_v = 0;
+    for (size_t c = 0; c < n_channels; ++c) {
+        const float v = channel_volumes[c];
+        if (v < min_v) min_v = v;
+        if (v > max_v) max_v = v;
+    }
+    (void)max_v;
+    return min_v;
+}
+
+fvad_vad_result VadMachine::run(uint64_t index, const float* channel_volumes, bool has_ratio, float ratio)
+{
+    const float mv = min_volume(channel_volumes);
+    const double st = short_term.push(mv);                       // :166
+    const double cr = ch_ratio.push(has_ratio ? ratio : 0);      // :167
+    const bool met = decide(st, cr, nullptr);
+    if (!met) long_term.push(mv);                                // :176-178
+    return finish_step(index, met, has_ratio, ratio);
+}
+
+// ------------------------------------------------------------------ many streams in lock-step
+// The long-term average is an 8437-term dependent f64 chain per frame per stream
+// (RollingAverage.zig:45-56) -- latency-bound when done one stream at a time.  Here up to LANES
+// streams advance together and the chain is evaluated for all of them at once from a
+// structure-of-arrays copy of their rings: data[i][lane].  Every lane still adds its own terms in
+// index order, so each stream's result is bit-identical to VadMachine::run.
+namespace {
+constexpr int LANES = 8;
+
+struct Group {
+    std::vector<VadMachine*> m;            // <= LANES machines with identical ring length
+    std::vector<double> soa;               // [len][LANES]
+    size_t len = 0;
+};
+
+void group_resum(Group& g, const bool* pushed, double* out)
+{
+    // all lanes have written_count == len once initialised with a value (the reference default);
+    // lanes that are still filling fall back to the scalar path in the caller.
+    double acc[LANES] = {0};
+    const double scalar = 1.0 / (double)g.len;
+    const double* d = g.soa.data();
+    for (size_t i = 0; i < g.len; ++i) {
+#pragma omp simd
+        for (int l = 0; l < LANES; ++l) acc[l] += d[i * LANES + l] * scalar;
+    }
+    for (int l = 0; l < LANES; ++l) if (pushed[l]) out[l] = acc[l];
+}
+} // namespace
+
+void run_many(VadMachine* const* vads, size_t n_streams, const float* const* band,
+              const float* const* ratio, const size_t* n_frames, size_t n_channels,
+              const uint64_t* first_index, size_t fft_size, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    // partition streams into groups of <= LANES machines with equal, already full long-term rings
+    std::vector<Group> groups;
+    std::vector<std::vector<size_t>> group_sid;
+    std::vector<size_t> scalar_streams;
+    {
+        std::vector<bool> used(n_streams, false);
+        for (size_t i = 0; i < n_streams; ++i) {
+            if (used[i]) continue;
+            used[i] = true;
+            const RollingAverage& a = vads[i]->long_term;
+            if (a.written_count != a.len) { scalar_streams.push_back(i); continue; }
+            std::vector<size_t> idx{i};
+            for (size_t j = i + 1; j < n_streams && idx.size() < (size_t)LANES; ++j) {
+                const RollingAverage& b = vads[j]->long_term;
+                if (!used[j] && b.len == a.len && b.written_count == b.len) { idx.push_back(j); used[j] = true; }
+            }
+            if (idx.size() < 2) { scalar_streams.push_back(i); continue; }
+            Group g;
+            g.len = a.len;
+            g.soa.assign(g.len * LANES, 0.0);
+            for (size_t l = 0; l < idx.size(); ++l) {
+                g.m.push_back(vads[idx[l]]);
+                for (size_t k = 0; k < g.len; ++k) g.soa[k * LANES + l] = vads[idx[l]]->long_term.data[k];
+            }
+            groups.push_back(std::move(g));
+            group_sid.push_back(idx);
+        }
+    }
+
+    auto run_group = [&](size_t gi) {
+        Group& g = groups[gi];
+        const size_t L = g.m.size();
+        size_t sid[LANES]; size_t nf[LANES]; size_t max_f = 0;
+        for (size_t l = 0; l < L; ++l) { sid[l] = group_sid[gi][l]; nf[l] = n_frames[sid[l]]; max_f = std::max(max_f, nf[l]); }
+        for (size_t k = 0; k < max_f; ++k) {
+            bool pushed[LANES] = {false};
+            bool met[LANES] = {false};
+            float mv[LANES] = {0};
+            bool any = false;
+            for (size_t l = 0; l < L; ++l) {
+                if (k >= nf[l]) continue;
+                VadMachine* m = g.m[l];
+                const size_t s = sid[l];
+                mv[l] = m->min_volume(band[s] + k * n_channels);
+                const float r = ratio[s][k];
+                const bool has_ratio = !std::isnan(r);
+                const double st = m->short_term.push(mv[l]);
+                const double cr = m->ch_ratio.push(has_ratio ? r : 0);
+                met[l] = m->decide(st, cr, nullptr);
+                if (!met[l]) {
+                    // RollingAverage.push without the re-sum (done for the whole group below)
+                    RollingAverage& ra = m->long_term;
+                    ra.data[ra.write_idx] = (double)mv[l];
+                    g.soa[ra.write_idx * LANES + l] = (double)mv[l];
+                    ra.write_idx = (ra.write_idx + 1) % ra.len;
+                    pushed[l] = true;
+                    any = true;
+                }
+            }
+            if (any) {
+                double out[LANES];
+                group_resum(g, pushed, out);
+                for (size_t l = 0; l < L; ++l) if (pushed[l]) { g.m[l]->long_term.last_avg = out[l]; g.m[l]->long_term.has_last_avg = true; }
+            }
+            for (size_t l = 0; l < L; ++l) {
+                if (k >= nf[l]) continue;
+                const size_t s = sid[l];
+                const float r = ratio[s][k];
+                const bool has_ratio = !std::isnan(r);
+                g.m[l]->finish_step(first_index[s] + (uint64_t)k * fft_size, met[l], has_ratio, r);
+            }
+        }
+    };
+    auto run_scalar = [&](size_t s) {
+        VadMachine* m = vads[s];
+        for (size_t k = 0; k < n_frames[s]; ++k) {
+            const float r = ratio[s][k];
+            const bool has_ratio = !std::isnan(r);
+            m->run(first_index[s] + (uint64_t)k * fft_size, band[s] + k * n_channels, has_ratio, r);
+        }
+    };
+
+    // work items: groups then scalar streams, spread over threads
+    const size_t n_items = groups.size() + scalar_streams.size();
+    if (n_threads == 1 || n_items <= 1) {
+        for (size_t gi = 0; gi < groups.size(); ++gi) run_group(gi);
+        for (size_t s : scalar_streams) run_scalar(s);
+        return;
+    }
+    std::vector<std::thread> th;
+    std::atomic<size_t> next{0};
+    const int nt = (int)std::min<size_t>((size_t)n_threads, n_items);
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&]() {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= n_items) break;
+                if (i < groups.size()) run_group(i);
+                else run_scalar(scalar_streams[i - groups.size()]);
+            }
+        });
+    for (auto& t : th) t.join();
+}
+
+} // namespace fvad
+
+// ------------------------------------------------------------------ C ABI
+struct fvad_vad { fvad::VadMachine m; fvad_vad(const fvad_vad_config& c, size_t sr, size_t nc, size_t fs) : m(c, sr, nc, fs) {} };
+struct fvad_rolling_average { fvad::RollingAverage ra; fvad_rolling_average(size_t n, bool h, double v) : ra(n, h, v) {} };
+
+extern "C" {
+
+void fvad_vad_config_default(fvad_vad_config* c)
+{
+    c->speech_min_freq = 500; c->speech_max_freq = 2000;
+    c->long_term_speech_avg_sec = 180; c->has_initial_long_term_avg = 1; c->initial_long_term_avg = 0.005;
+    c->short_term_speech_avg_sec = 0.2f; c->speech_threshold_factor = 10;
+    c->channel_vol_ratio_avg_sec = 0.5f; c->channel_vol_ratio_threshold = 0.5f;
+    c->min_consecutive_sec_to_open = 0.2f; c->max_speech_gap_sec = 2; c->min_vad_duration_sec = 0.7f;
+}
+
+int fvad_vad_create(const fvad_vad_config* cfg, size_t sample_rate, size_t n_channels, size_t fft_size, fvad_vad** out)
+{
+    if (!cfg || !out || n_channels == 0 || fft_size == 0 || sample_rate == 0) return FVAD_ERR_INVALID_ARGUMENT;
+    // a zero-length channel_vol_ratio ring would divide by zero in the reference (RollingAverage.zig:36)
+    if ((size_t)(((float)sample_rate / (float)fft_size) * cfg->channel_vol_ratio_avg_sec) == 0) return FVAD_ERR_INVALID_ARGUMENT;
+    *out = new (std::nothrow) fvad_vad(*cfg, sample_rate, n_channels, fft_size);
+    return *out ? FVAD_OK : FVAD_ERR_ALLOC_FAILED;
+}
+void fvad_vad_destroy(fvad_vad* v) { delete v; }
+
+int fvad_vad_run(fvad_vad* v, uint64_t index, const float* channel_volumes, int has_ratio, float volume_ratio, fvad_vad_result* out)
+{
+    if (!v || !channel_volumes) return FVAD_ERR_INVALID_ARGUMENT;
+    const fvad_vad_result r = v->m.run(index, channel_volumes, has_ratio != 0, volume_ratio);
+    if (out) *out = r;
+    return FVAD_OK;
+}
+size_t fvad_vad_segment_count(const fvad_vad* v) { return v ? v->m.segments.size() : 0; }
+int fvad_vad_segments(const fvad_vad* v, fvad_speech_segment* out, size_t cap, size_t* n)
+{
+    if (!v || !n) return FVAD_ERR_INVALID_ARGUMENT;
+    *n = v->m.segments.size();
+    if (cap < *n) return FVAD_ERR_BUFFER_TOO_SMALL;
+    if (*n) memcpy(out, v->m.segments.data(), *n * sizeof(fvad_speech_segment));
+    return FVAD_OK;
+}
+int fvad_vad_audit_get(const fvad_vad* v, fvad_vad_audit* out)
+{
+    if (!v || !out) return FVAD_ERR_INVALID_ARGUMENT;
+    *out = v->m.audit;
+    return FVAD_OK;
+}
+
+int fvad_vad_run_many(fvad_vad* const* vads, size_t n_streams, const float* const* band, const float* const* ratio,
+                      const size_t* n_frames, size_t n_channels, const uint64_t* first_index, size_t fft_size, int n_threads)
+{
+    if (!vads || !band || !ratio || !n_frames || !first_index) return FVAD_ERR_INVALID_ARGUMENT;
+    std::vector<fvad::VadMachine*> ms(n_streams);
+    for (size_t i = 0; i < n_streams; ++i) {
+        if (!vads[i] || vads[i]->m.n_channels != n_channels) return FVAD_ERR_CHANNEL_COUNT_MISMATCH;
+        ms[i] = &vads[i]->m;
+    }
+    fvad::run_many(ms.data(), n_streams, band, ratio, n_frames, n_channels, first_index, fft_size, n_threads);
+    return FVAD_OK;
+}
+
+int fvad_ra_create(size_t count, int has_initial, double initial_val, fvad_rolling_average** out)
+{
+    if (!out || count == 0) return FVAD_ERR_INVALID_ARGUMENT;
+    *out = new (std::nothrow) fvad_rolling_average(count, has_initial != 0, initial_val);
+    return *out ? FVAD_OK : FVAD_ERR_ALLOC_FAILED;
+}
+void fvad_ra_destroy(fvad_rolling_average* ra) { delete ra; }
+double fvad_ra_push(fvad_rolling_average* ra, float sample) { return ra->ra.push(sample); }
+int fvad_ra_last_avg(const fvad_rolling_average* ra, double* out)
+{
+    if (ra->ra.has_last_avg && out) *out = ra->ra.last_avg;
+    return ra->ra.has_last_avg ? 1 : 0;
+}
+
+} // extern "C"

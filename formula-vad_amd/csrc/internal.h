@@ -1,0 +1,134 @@
+// internal.h -- shared host-side declarations of libfvad_hip.so (not part of the ABI)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/fvad.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------ host tables / windows
+namespace fvad {
+
+void hann_window_periodic(float* result, size_t n);   // window_fn.zig:22-28,51-68
+void hann_window_symmetric(float* result, size_t n);  // window_fn.zig:30-41
+float window_norm_factor(const float* w, size_t n);   // window_fn.zig:8-16
+void nsnet2_window(float* w320);                      // NSNet2.zig:384-396
+// exp(-2 pi i j / n) for j < n, evaluated in double, rounded once (kissfft's kf_cexp)
+void make_twiddles(int n, std::vector<float>& out);
+// exp(-i pi ((k+1)/ncfft + 1/2)) for k < ncfft/2 (kissfft's super_twiddles)
+void make_super_twiddles(int ncfft, std::vector<float>& out);
+
+// ------------------------------------------------------------------ weights
+struct HostWeights {
+    int n_bins = 0, n_fc1 = 0, n_hidden = 0, n_fc2 = 0, n_fc3 = 0;
+    std::vector<float> fc1_w, fc1_b, gru1_w, gru1_r, gru1_b, gru2_w, gru2_r, gru2_b, fc2_w, fc2_b,
+        fc3_w, fc3_b, fc4_w, fc4_b;
+    void view(fvad_nsnet2_weights* out) const;
+    bool from_view(const fvad_nsnet2_weights* in, std::string& err);
+    bool check_dims(std::string& err) const;
+};
+void synth_weights(uint64_t seed, HostWeights& w);
+int read_onnx_nsnet2(const char* path, HostWeights& w, std::string& err);
+
+// fragment-major packing for the MFMA kernels (see kernels_nn.hip)
+void pack_panel(const float* W, int N, int K, int n_blocks, int NT, int S, std::vector<float>& out);
+void pack_gru_r(const float* R, int H, std::vector<float>& out);
+
+// ------------------------------------------------------------------ device model
+struct DevBuf {
+    float* p = nullptr;
+    size_t n = 0; // floats
+};
+
+struct DeviceModel {
+    DevBuf fc1_w, fc1_b, gi1_w, gi1_b, r1, br1, gi2_w, gi2_b, r2, br2, fc2_w, fc2_b, fc3_w, fc3_b,
+        fc4_w, fc4_b;
+    bool loaded = false;
+};
+
+struct Workspace {
+    long cap_chunks = 0; // padded chunk capacity (multiple of 128)
+    int T = 0;
+    ChunkDesc* descs = nullptr;
+    ChunkDesc* h_descs = nullptr; // pinned
+    float *feat = nullptr, *spec = nullptr, *rms = nullptr, *a1 = nullptr, *gi = nullptr,
+          *h1 = nullptr, *h2 = nullptr, *f2 = nullptr, *f3 = nullptr, *gains = nullptr;
+    // generic scratch (engine_run staging, denoised audio, band sums)
+    float* in = nullptr;  size_t in_cap = 0;
+    float* den = nullptr; size_t den_cap = 0;
+    float* band = nullptr; size_t band_cap = 0;
+    float* bins = nullptr; size_t bins_cap = 0;
+    LaneCarry* carries = nullptr; size_t carries_cap = 0; // scratch carries (2 per lane)
+};
+
+struct KernelTime {
+    std::string name;
+    hipEvent_t e0, e1;
+};
+
+} // namespace fvad
+
+struct fvad_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mutable std::string err;
+    // constant tables
+    float* d_tables = nullptr;
+    FftTables tb{};
+    std::vector<float> h_win320, h_win1024;
+    // model
+    fvad::HostWeights hw;
+    fvad::DeviceModel dm;
+    fvad::Workspace ws;
+    // timing
+    bool timing = false;
+    std::vector<fvad::KernelTime> times;
+    std::vector<std::string> time_names;
+    std::vector<float> time_ms;
+    // cached descriptor table of the last enqueue_device call
+    const float* last_pcm = nullptr;
+    float* last_den = nullptr;
+    size_t last_lanes = 0, last_stride = 0, last_samples = 0;
+};
+
+struct fvad_lane_state {
+    fvad_ctx* ctx = nullptr;
+    LaneCarry* carry[2] = {nullptr, nullptr}; // device, double-buffered
+    int cur = 0;
+    float* den_rem = nullptr; // device, 1024 floats: denoised samples not yet FFT'd
+    size_t n_rem = 0;
+    uint64_t samples_consumed = 0; // raw samples consumed so far (multiple of 24000)
+    uint64_t next_frame_index = 0; // absolute index of the next FFT frame's first sample
+};
+
+namespace fvad {
+int set_err(const fvad_ctx* ctx, int code, const std::string& msg);
+int hip_fail(const fvad_ctx* ctx, hipError_t e, const char* what);
+#define FVAD_HIP(ctx, call)                                         \
+    do {                                                            \
+        hipError_t _e = (call);                                     \
+        if (_e != hipSuccess) return fvad::hip_fail(ctx, _e, #call); \
+    } while (0)
+
+int upload_model(fvad_ctx* ctx);
+int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T);
+// NSNet2 on ws.feat -> ws.gains for n_chunks sequences of T rows; gains rows skip..T-1 only
+int run_nn(fvad_ctx* ctx, long n_chunks_pad, int T, int skip);
+
+struct LaneJob {
+    const float* d_in;   // device, n_chunks * 24000 samples (480 samples of history are read
+                         // from the lane's carry, never from before d_in)
+    float* d_den;        // device, n_chunks * 24000
+    size_t n_chunks;
+    LaneCarry* carry[2];
+    int cur;             // index of the carry holding the current state
+    float* d_rms;        // device, n_chunks
+};
+int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks);
+void time_begin(fvad_ctx* ctx, const char* name);
+void time_end(fvad_ctx* ctx);
+} // namespace fvad

@@ -1,0 +1,74 @@
+// kernels.h -- launch wrappers of the gfx950 kernels (internal; the public ABI is include/fvad.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+enum { FVAD_ACT_NONE = 0, FVAD_ACT_RELU = 1, FVAD_ACT_SIGMOID = 2 };
+
+// ------------------------------------------------------------------ geometry (NSNet2.zig:12-16)
+constexpr int kNFft = 320;
+constexpr int kNHop = 160;
+constexpr int kFramesPerChunk = 50;
+constexpr int kWarmupRows = 4;                 // artifact_mitigation_window
+constexpr int kRowsPerChunk = kFramesPerChunk + kWarmupRows; // 54
+constexpr int kNBins = 161;
+constexpr int kFeatStride = 176;               // 161 padded to 11 x 16 (zero-filled tail)
+constexpr int kDown = 3;                       // 48 kHz -> 16 kHz
+constexpr int kChunk48 = kFramesPerChunk * kNHop * kDown; // 24000
+constexpr int kVadFft = 1024;
+constexpr int kVadBins = 513;
+
+// cross-call carry of one lane (all device floats); mirrors NSNet2.zig:27-33 state
+struct LaneCarry {
+    float in_tail[kNHop * kDown];          // last 480 raw 48 kHz samples (-> audio_input[0..160])
+    float feat_tail[kWarmupRows * kNBins]; // features rows 50..53 of the previous chunk
+    float ola_tail[kNHop];                 // audio_output[8000..8160)
+    float last_sample;                     // resample carry
+    float pad[3];
+};
+
+// one 0.5 s chunk of one lane inside a launch
+struct ChunkDesc {
+    const float* in;    // 24000 samples of this chunk (device)
+    float* den;         // 24000 denoised samples out (device)
+    const LaneCarry* carry_in; // read by the lane's first chunk of a launch (never null)
+    LaneCarry* carry_out;      // written by the lane's last chunk of a launch (!= carry_in)
+    uint32_t first;     // first chunk of its lane in this launch -> history comes from carry_in
+    uint32_t last;      // last chunk of its lane in this launch -> writes carry_out
+};
+
+// constant tables (device), built on the host in double like kissfft does and rounded once
+struct FftTables {
+    const float* win320;     // sqrt-Hann, NSNet2.zig:384-396
+    const float* win320n;    // win320 * (1/320)  (NSNet2.zig:323,335)
+    const float* tw160;      // [160][2] exp(-2 pi i j / 160)
+    const float* st320;      // [80][2]  exp(-i pi ((k+1)/160 + 1/2))  real-FFT un-mixing
+    const float* win1024;    // periodic Hann, window_fn.zig:22-28
+    const float* tw512;      // [512][2]
+    const float* st1024;     // [256][2]
+    float norm1024;          // windowNormFactor / 1024, BufferedFFT.zig:99
+};
+
+int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
+                           int ldc, long rows, int nt, int n_blocks, int S_steps, int act,
+                           int map_T, int map_skip, hipStream_t stream);
+int fvad_launch_gru_rec(const float* gi, const float* Rfrag, const float* bR, float* hout,
+                        long n_seq_pad, int T, int waves, hipStream_t stream);
+
+// K1: per chunk: RMS, decimate, STFT-320, log-power features (+ warm-up rows)
+void fvad_launch_stft(const ChunkDesc* descs, int n_chunks, FftTables tb, float* feat,
+                      float* spec, float* rms, hipStream_t stream);
+// K3: per chunk: gain, inverse STFT, overlap-add, x3 upsample
+void fvad_launch_istft(const ChunkDesc* descs, int n_chunks, FftTables tb, const float* spec,
+                       const float* gains, int gains_rows_per_chunk, int gains_row0,
+                       hipStream_t stream);
+// K4: 1024-point periodic-Hann rFFT magnitude + band sum over [min_bin, max_bin]
+void fvad_launch_vadfft(const float* den, long n_frames, FftTables tb, int min_bin, int max_bin,
+                        float* band_sum, float* bins_or_null, hipStream_t stream);
+// batched FFT.fft for B3 / BASELINE config 2: n_fft in {320, 1024}
+void fvad_launch_rfft_batch(const float* frames, long n_frames, int n_fft, const float* window,
+                            FftTables tb, float* bins_or_null, float* mag_or_null,
+                            hipStream_t stream);
+void fvad_launch_irfft_batch(const float* bins, long n_frames, FftTables tb, float* out,
+                             hipStream_t stream);

@@ -1,0 +1,741 @@
+// kernels_fft.hip -- the spectral front end on gfx950.
+//
+//   K1 stft_kernel    chunk RMS (BufferedVolumeAnalyzer.zig:48-69, audio_utils.zig:14-24),
+//                     /3 decimation (resample.zig:9-29), sqrt-Hann 320-point real FFT
+//                     (NSNet2.zig:239-264 -> FFT.zig:85-113), log-power features (NSNet2.zig:266-287)
+//   K3 istft_kernel   gain (NSNet2.zig:289-310), inverse real FFT + window + overlap-add
+//                     (NSNet2.zig:312-339), x3 linear upsample (resample.zig:32-79)
+//   K4 vadfft_kernel  periodic-Hann 1024-point real FFT, |X| * norm, band sum
+//                     (BufferedFFT.zig:162-202)
+//   rfft/irfft batch  FFT.fft / FFT.invFft for many frames (BASELINE config 2)
+//
+// All FFTs share one wavefront-level scheme.  A real transform of length 2N is one complex
+// transform of length N = R * L over z[n] = x[2n] + i x[2n+1] plus the same un-mixing pass
+// kissfft uses ("super twiddles").  The complex transform keeps R points per lane in registers
+// and spreads L points over lanes (N = 160: R = 5, L = 32, two frames per 64-lane wavefront;
+// N = 512: R = 8, L = 64):
+//     X[k1 + R k2] = sum_p W_L^{p k2} ( W_N^{p k1} sum_j z[p + L j] W_R^{j k1} )
+// i.e. an R-point DFT in registers, one twiddle multiply, then R independent L-point
+// decimation-in-frequency FFTs whose butterflies are lane exchanges (__shfl_xor).  Twiddles are
+// read once per wavefront from tables the host evaluated in double (as kissfft does) and kept in
+// registers; window coefficients likewise.  f32 throughout; fp contraction is off for this file
+// so products and sums round exactly where the reference's do.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct cpx { float r, i; };
+
+__device__ __forceinline__ cpx cmul(cpx a, cpx b) { return {a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r}; }
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return {a.r + b.r, a.i + b.i}; }
+__device__ __forceinline__ cpx csub(cpx a, cpx b) { return {a.r - b.r, a.i - b.i}; }
+__device__ __forceinline__ cpx cconj(cpx a) { return {a.r, -a.i}; }
+template <bool INV> __device__ __forceinline__ cpx mul_mi(cpx a) // a * (-i) forward, a * (+i) inverse
+{
+    return INV ? cpx{-a.i, a.r} : cpx{a.i, -a.r};
+}
+__device__ __forceinline__ cpx ld_tw(const float* t, int idx) { return {t[2 * idx], t[2 * idx + 1]}; }
+
+// ---- R-point DFT in registers (exponent sign: -, or + when INV)
+template <bool INV> __device__ __forceinline__ void dft5(cpx (&v)[5])
+{
+    // W5^1 = (c1, -+s1), W5^2 = (c2, -+s2); constants rounded from double
+    const float c1 = 0.30901699437494742f, s1 = 0.95105651629515357f;
+    const float c2 = -0.80901699437494742f, s2 = 0.58778525229247313f;
+    const float ya_i = INV ? s1 : -s1, yb_i = INV ? s2 : -s2;
+    const cpx z0 = v[0];
+    const cpx s7 = cadd(v[1], v[4]), s10 = csub(v[1], v[4]);
+    const cpx s8 = cadd(v[2], v[3]), s9 = csub(v[2], v[3]);
+    v[0] = {z0.r + (s7.r + s8.r), z0.i + (s7.i + s8.i)};
+    const cpx s5 = {z0.r + s7.r * c1 + s8.r * c2, z0.i + s7.i * c1 + s8.i * c2};
+    const cpx s6 = {s10.i * ya_i + s9.i * yb_i, -(s10.r * ya_i) - s9.r * yb_i};
+    v[1] = csub(s5, s6);
+    v[4] = cadd(s5, s6);
+    const cpx s11 = {z0.r + s7.r * c2 + s8.r * c1, z0.i + s7.i * c2 + s8.i * c1};
+    const cpx s12 = {-(s10.i * yb_i) + s9.i * ya_i, s10.r * yb_i - s9.r * ya_i};
+    v[2] = cadd(s11, s12);
+    v[3] = csub(s11, s12);
+}
+
+template <bool INV> __device__ __forceinline__ void dft4(cpx& c0, cpx& c1, cpx& c2, cpx& c3)
+{
+    const cpx e0 = cadd(c0, c2), e1 = csub(c0, c2);
+    const cpx o0 = cadd(c1, c3), o1 = mul_mi<INV>(csub(c1, c3));
+    c0 = cadd(e0, o0);
+    c2 = csub(e0, o0);
+    c1 = cadd(e1, o1);
+    c3 = csub(e1, o1);
+}
+
+template <bool INV> __device__ __forceinline__ void dft8(cpx (&v)[8])
+{
+    const float h = 0.70710678118654752f;
+    cpx a0 = cadd(v[0], v[4]), a1 = cadd(v[1], v[5]), a2 = cadd(v[2], v[6]), a3 = cadd(v[3], v[7]);
+    cpx b0 = csub(v[0], v[4]), b1 = csub(v[1], v[5]), b2 = csub(v[2], v[6]), b3 = csub(v[3], v[7]);
+    // b_j *= W8^j
+    const cpx w1 = INV ? cpx{h, h} : cpx{h, -h};
+    const cpx w3 = INV ? cpx{-h, h} : cpx{-h, -h};
+    b1 = cmul(b1, w1);
+    b2 = mul_mi<INV>(b2);
+    b3 = cmul(b3, w3);
+    dft4<INV>(a0, a1, a2, a3); // Y[0], Y[2], Y[4], Y[6]
+    dft4<INV>(b0, b1, b2, b3); // Y[1], Y[3], Y[5], Y[7]
+    v[0] = a0; v[2] = a1; v[4] = a2; v[6] = a3;
+    v[1] = b0; v[3] = b1; v[5] = b2; v[7] = b3;
+}
+
+template <int R, bool INV> __device__ __forceinline__ void reg_dft(cpx (&v)[R])
+{
+    if constexpr (R == 5) dft5<INV>(v);
+    else dft8<INV>(v);
+}
+
+// Per-lane twiddle set of one wavefront FFT, loaded once and reused for every frame.
+template <int R, int L> struct LaneTw {
+    static constexpr int LOG_L = (L == 64) ? 6 : 5;
+    cpx lane[R - 1];   // W_N^{p k1}, k1 = 1..R-1
+    cpx stage[LOG_L];  // DIF stage twiddle of this lane (1 for the lower half of a butterfly)
+};
+
+template <int R, int L, bool INV>
+__device__ __forceinline__ void lane_tw_load(LaneTw<R, L>& tw, const float* table /*[R*L][2] fwd*/, int p)
+{
+    constexpr int N = R * L;
+#pragma unroll
+    for (int k1 = 1; k1 < R; ++k1) {
+        cpx t = ld_tw(table, p * k1);
+        tw.lane[k1 - 1] = INV ? cconj(t) : t;
+    }
+    int s = 0;
+#pragma unroll
+    for (int h = L / 2; h >= 1; h >>= 1, ++s) {
+        cpx t = {1.0f, 0.0f};
+        if (p & h) {
+            t = ld_tw(table, (p & (h - 1)) * (N / (2 * h)));
+            if (INV) t = cconj(t);
+        }
+        tw.stage[s] = t;
+    }
+}
+
+// v[j] = z[p + L j] in, v[k1] = Z[k1 + R * bitrev_L(p)] out.
+template <int R, int L, bool INV>
+__device__ __forceinline__ void wave_fft(cpx (&v)[R], const LaneTw<R, L>& tw, int p)
+{
+    reg_dft<R, INV>(v);
+#pragma unroll
+    for (int k1 = 1; k1 < R; ++k1) v[k1] = cmul(v[k1], tw.lane[k1 - 1]);
+    int s = 0;
+#pragma unroll
+    for (int h = L / 2; h >= 1; h >>= 1, ++s) {
+        const bool upper = (p & h) != 0;
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) {
+            const cpx mine = v[k1];
+            cpx other;
+            other.r = __shfl_xor(mine.r, h, 64);
+            other.i = __shfl_xor(mine.i, h, 64);
+            // lower lane: a + b ; upper lane: (a_low - a_high) * w = (other - mine) * w
+            const cpx t = upper ? csub(other, mine) : cadd(mine, other);
+            v[k1] = cmul(t, tw.stage[s]);
+        }
+    }
+}
+
+template <int L> __device__ __forceinline__ int bitrev_lane(int p)
+{
+    return (int)(__brev((unsigned)p) >> (L == 64 ? 26 : 27));
+}
+
+// kissfft's real-FFT un-mixing for one k in [1, ncfft/2]: writes X[k] and X[ncfft-k]
+__device__ __forceinline__ void unmix_fwd(cpx zk, cpx znk, cpx st, cpx& xk, cpx& xnk)
+{
+    const cpx fpnk = cconj(znk);
+    const cpx f1k = cadd(zk, fpnk);
+    const cpx f2k = csub(zk, fpnk);
+    const cpx tw = cmul(f2k, st);
+    xk = {(f1k.r + tw.r) * 0.5f, (f1k.i + tw.i) * 0.5f};
+    xnk = {(f1k.r - tw.r) * 0.5f, (tw.i - f1k.i) * 0.5f};
+}
+// and the inverse pre-mixing: T[k], T[ncfft-k] from Y[k], Y[ncfft-k]; st is the INVERSE twiddle
+__device__ __forceinline__ void premix_inv(cpx fk, cpx fnk, cpx st_inv, cpx& tk, cpx& tnk)
+{
+    const cpx fnkc = cconj(fnk);
+    const cpx fek = cadd(fk, fnkc);
+    const cpx tmp = csub(fk, fnkc);
+    const cpx fok = cmul(tmp, st_inv);
+    tk = cadd(fek, fok);
+    tnk = cconj(csub(fek, fok));
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ============================================================================ K1
+constexpr int K1_THREADS = 256;
+constexpr int K1_DEC = (kRowsPerChunk + 1) * kNHop; // 8800 decimated samples: frames -4..49
+
+__global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __restrict__ descs,
+                                                          FftTables tb, float* __restrict__ feat,
+                                                          float* __restrict__ spec,
+                                                          float* __restrict__ rms_out)
+{
+    __shared__ __attribute__((aligned(16))) float dec[K1_DEC];
+    __shared__ __attribute__((aligned(16))) float zb[4][2][2 * 160];
+    __shared__ float s_win[kNFft];
+    __shared__ float s_st[2 * 80];
+    __shared__ float s_red[4];
+
+    const int g = blockIdx.x;
+    const ChunkDesc d = descs[g];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    for (int i = tid; i < kNFft; i += K1_THREADS) s_win[i] = tb.win320[i];
+    for (int i = tid; i < 160; i += K1_THREADS) s_st[i] = tb.st320[i];
+
+    // ---- load + decimate + sum of squares
+    float ss = 0.0f;
+    {
+        const int hist = d.first ? 0 : (kWarmupRows + 1) * kNHop * kDown; // 2400 raw samples
+        const float* src = d.in - hist;
+        const int n4 = (hist + kChunk48) / 4;
+        const int dec0 = d.first ? (kWarmupRows + 1) * kNHop : 0;          // 800
+        const f32x4* src4 = reinterpret_cast<const f32x4*>(src);
+        for (int i4 = tid; i4 < n4; i4 += K1_THREADS) {
+            const f32x4 v = src4[i4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned s = 4u * i4 + e;
+                const unsigned s3 = s / 3u;
+                if (s3 * 3u == s) dec[dec0 + s3] = v[e];
+                if ((int)s >= hist) ss += v[e] * v[e];
+            }
+        }
+        if (d.first) {
+            // audio_input[0..160) of the reference = decimated tail of the previous call
+            const float* tail = d.carry_in->in_tail;
+            for (int j = tid; j < kNHop; j += K1_THREADS) dec[dec0 - kNHop + j] = tail[kDown * j];
+        }
+        if (d.last) {
+            for (int j = tid; j < kNHop * kDown; j += K1_THREADS)
+                d.carry_out->in_tail[j] = d.in[kChunk48 - kNHop * kDown + j];
+        }
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) s_red[wave] = ss;
+    __syncthreads();
+    if (tid == 0) {
+        const float sum = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        rms_out[g] = sqrtf(sum / (float)kChunk48);
+    }
+
+    // ---- warm-up feature rows of the first chunk of a call come from the carry (zeros at t=0:
+    // NSNet2.zig:77-79)
+    float* feat_g = feat + (size_t)g * kRowsPerChunk * kFeatStride;
+    if (d.first) {
+        const float* ft = d.carry_in->feat_tail;
+        for (int i = tid; i < kWarmupRows * kNBins; i += K1_THREADS) {
+            const int r = i / kNBins, k = i - r * kNBins;
+            feat_g[r * kFeatStride + k] = ft[i];
+        }
+    }
+
+    // ---- per-lane constants
+    const int half = lane >> 5;
+    const int p = lane & 31;
+    LaneTw<5, 32> tw;
+    lane_tw_load<5, 32, false>(tw, tb.tw160, p);
+    float wre[5], wim[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        wre[j] = s_win[2 * (p + 32 * j)];
+        wim[j] = s_win[2 * (p + 32 * j) + 1];
+    }
+    const int k2 = bitrev_lane<32>(p);
+    const float p_min = 1.0f / 1e12f; // std.math.pow(f32, 10, -12), NSNet2.zig:275
+    float* spec_g = spec + (size_t)g * kFramesPerChunk * kNBins * 2;
+    const int fl_begin = d.first ? kWarmupRows : 0;
+
+    constexpr int N_PAIRS = kRowsPerChunk / 2; // 27
+    for (int it = 0; it < (N_PAIRS + 3) / 4; ++it) {
+        const int pi = it * 4 + wave;
+        const int fl = 2 * pi + half;
+        const bool active = (pi < N_PAIRS) && (fl >= fl_begin);
+        if (active) {
+            cpx v[5];
+            const float* x = dec + kNHop * fl;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int n = 2 * (p + 32 * j);
+                v[j] = {x[n] * wre[j], x[n + 1] * wim[j]}; // loadSamplesFwd, FFT.zig:183-199
+            }
+            wave_fft<5, 32, false>(v, tw, p);
+            float* z = zb[wave][half];
+#pragma unroll
+            for (int k1 = 0; k1 < 5; ++k1) {
+                const int k = k1 + 5 * k2;
+                z[2 * k] = v[k1].r;
+                z[2 * k + 1] = v[k1].i;
+            }
+        }
+        __syncthreads();
+        // un-mix: 2 frames x 81 k's per wavefront
+        for (int item = lane; item < 2 * 81; item += 64) {
+            const int hh = item / 81;
+            const int k = item - hh * 81;
+            const int fl2 = 2 * pi + hh;
+            if (pi < N_PAIRS && fl2 >= fl_begin) {
+                const float* z = zb[wave][hh];
+                cpx xk, xnk;
+                int kn;
+                if (k == 0) {
+                    const cpx tdc = {z[0], z[1]};
+                    xk = {tdc.r + tdc.i, 0.0f};
+                    xnk = {tdc.r - tdc.i, 0.0f};
+                    kn = 160;
+                } else {
+                    kn = 160 - k;
+                    unmix_fwd({z[2 * k], z[2 * k + 1]}, {z[2 * kn], z[2 * kn + 1]},
+                              {s_st[2 * (k - 1)], s_st[2 * (k - 1) + 1]}, xk, xnk);
+                }
+                float* frow = feat_g + fl2 * kFeatStride;
+                const float fk = log10f(fmaxf(xk.r * xk.r + xk.i * xk.i, p_min));
+                const float fnk = log10f(fmaxf(xnk.r * xnk.r + xnk.i * xnk.i, p_min));
+                if (k != 80) frow[k] = fk; // k == 80: X[160-k] is written last in the reference
+                frow[kn] = fnk;
+                if (fl2 >= kWarmupRows) {
+                    float* srow = spec_g + (size_t)(fl2 - kWarmupRows) * kNBins * 2;
+                    if (k != 80) { srow[2 * k] = xk.r; srow[2 * k + 1] = xk.i; }
+                    srow[2 * kn] = xnk.r; srow[2 * kn + 1] = xnk.i;
+                }
+                if (d.last && fl2 >= kFramesPerChunk) {
+                    float* ft = d.carry_out->feat_tail + (fl2 - kFramesPerChunk) * kNBins;
+                    if (k != 80) ft[k] = fk;
+                    ft[kn] = fnk;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void fvad_launch_stft(const ChunkDesc* descs, int n_chunks, FftTables tb, float* feat, float* spec,
+                      float* rms, hipStream_t stream)
+{
+    hipLaunchKernelGGL(stft_kernel, dim3(n_chunks), dim3(K1_THREADS), 0, stream, descs, tb, feat,
+                       spec, rms);
+}
+
+// ============================================================================ K3
+constexpr int K3_FR = kFramesPerChunk + 2; // frames -2..49
+
+__global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict__ descs, FftTables tb,
+                                                    const float* __restrict__ spec,
+                                                    const float* __restrict__ gains,
+                                                    int g_rows, int g_row0)
+{
+    __shared__ __attribute__((aligned(16))) float oa[K3_FR][kNHop]; // first halves y_f[0..160)
+    __shared__ __attribute__((aligned(16))) float ob[K3_FR][kNHop]; // second halves y_f[160..320)
+    __shared__ __attribute__((aligned(16))) float zb[4][2][2 * 160];
+    __shared__ float s_wn[kNFft];
+    __shared__ float s_st[2 * 80];
+    __shared__ float s_dm1;
+
+    const int g = blockIdx.x;
+    const ChunkDesc d = descs[g];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int p = lane & 31;
+
+    for (int i = tid; i < kNFft; i += 256) s_wn[i] = tb.win320n[i];
+    for (int i = tid; i < 160; i += 256) s_st[i] = tb.st320[i];
+    __syncthreads();
+
+    LaneTw<5, 32> tw;
+    lane_tw_load<5, 32, true>(tw, tb.tw160, p);
+    const int k2 = bitrev_lane<32>(p);
+
+    // frames fr = -2..49; fr < 0 belong to the previous chunk of the same lane (g - 1)
+    const int fr_begin = d.first ? 0 : -2;
+    constexpr int N_PAIRS = K3_FR / 2; // 26
+    for (int it = 0; it < (N_PAIRS + 3) / 4; ++it) {
+        const int pi = it * 4 + wave;
+        // pre-mix gain * X into the length-160 complex sequence
+        for (int item = lane; item < 2 * 81; item += 64) {
+            const int hh = item / 81;
+            const int k = item - hh * 81;
+            const int fr = 2 * pi + hh - 2;
+            if (pi < N_PAIRS && fr >= fr_begin) {
+                const int gg = fr < 0 ? g - 1 : g;
+                const int f = fr < 0 ? fr + kFramesPerChunk : fr;
+                const float* srow = spec + ((size_t)gg * kFramesPerChunk + f) * kNBins * 2;
+                const float* grow = gains + ((size_t)gg * g_rows + g_row0 + f) * kFeatStride;
+                const int kn = 160 - k;
+                float gk = grow[k], gnk = grow[kn];
+                gk = gk < -80.0f ? -80.0f : (gk > 1.0f ? 1.0f : gk);   // NSNet2.zig:295-305
+                gnk = gnk < -80.0f ? -80.0f : (gnk > 1.0f ? 1.0f : gnk);
+                const cpx yk = {srow[2 * k] * gk, srow[2 * k + 1] * gk};
+                const cpx ynk = {srow[2 * kn] * gnk, srow[2 * kn + 1] * gnk};
+                float* z = zb[wave][hh];
+                if (k == 0) {
+                    z[0] = yk.r + ynk.r;
+                    z[1] = yk.r - ynk.r;
+                } else {
+                    cpx tk, tnk;
+                    const cpx st_inv = {s_st[2 * (k - 1)], -s_st[2 * (k - 1) + 1]};
+                    premix_inv(yk, ynk, st_inv, tk, tnk);
+                    z[2 * k] = tk.r; z[2 * k + 1] = tk.i;
+                    z[2 * kn] = tnk.r; z[2 * kn + 1] = tnk.i; // k == 80: second write wins
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int fr = 2 * pi + half - 2;
+            if (pi < N_PAIRS && fr >= fr_begin) {
+                const float* z = zb[wave][half];
+                cpx v[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int n = p + 32 * j;
+                    v[j] = {z[2 * n], z[2 * n + 1]};
+                }
+                wave_fft<5, 32, true>(v, tw, p);
+#pragma unroll
+                for (int k1 = 0; k1 < 5; ++k1) {
+                    const int n = 2 * (k1 + 5 * k2);
+                    // inv_fft_buffer[i] *= window[i] * (1/320), NSNet2.zig:335
+                    const float y0 = v[k1].r * s_wn[n];
+                    const float y1 = v[k1].i * s_wn[n + 1];
+                    if (n < kNHop) { oa[fr + 2][n] = y0; oa[fr + 2][n + 1] = y1; }
+                    else { ob[fr + 2][n - kNHop] = y0; ob[fr + 2][n - kNHop + 1] = y1; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // previous-chunk state of the first chunk of a call comes from the carry
+    if (d.first) {
+        for (int j = tid; j < kNHop; j += 256) ob[1][j] = d.carry_in->ola_tail[j];
+        if (tid == 0) s_dm1 = d.carry_in->last_sample;
+    } else if (tid == 0) {
+        s_dm1 = ob[0][kNHop - 1] + oa[1][kNHop - 1]; // decimated output sample 8000c - 1
+    }
+    __syncthreads();
+
+    // overlap-add (NSNet2.zig:336): d[160 f + j] = y_{f-1}[160 + j] + y_f[j], in place into oa
+    for (int i = tid; i < kFramesPerChunk * kNHop; i += 256) {
+        const int f = i / kNHop, j = i - f * kNHop;
+        oa[f + 2][j] = ob[f + 1][j] + oa[f + 2][j];
+    }
+    __syncthreads();
+    if (d.last) {
+        for (int j = tid; j < kNHop; j += 256) d.carry_out->ola_tail[j] = ob[kFramesPerChunk + 1][j];
+        if (tid == 0) d.carry_out->last_sample = oa[kFramesPerChunk + 1][kNHop - 1];
+    }
+
+    // x3 upsample (resample.zig:32-79): out[3m+2] = d[m]; out[3m+j] = lerp(d[m-1], d[m], (j+1)/3)
+    const float* dd = &oa[2][0];
+    const float frac1 = 1.0f / 3.0f, frac2 = 2.0f / 3.0f;
+    float* out = d.den;
+    const float dm1 = s_dm1;
+    for (int s = tid; s < kChunk48; s += 256) {
+        const int mm = s / 3;
+        const int r = s - 3 * mm;
+        const float cur = dd[mm];
+        float o;
+        if (r == 2) {
+            o = cur;
+        } else {
+            const float prev = mm > 0 ? dd[mm - 1] : dm1;
+            o = __builtin_fmaf(cur - prev, r == 0 ? frac1 : frac2, prev); // std.math.lerp = mulAdd
+        }
+        out[s] = o;
+    }
+}
+
+void fvad_launch_istft(const ChunkDesc* descs, int n_chunks, FftTables tb, const float* spec,
+                       const float* gains, int gains_rows_per_chunk, int gains_row0,
+                       hipStream_t stream)
+{
+    hipLaunchKernelGGL(istft_kernel, dim3(n_chunks), dim3(256), 0, stream, descs, tb, spec, gains,
+                       gains_rows_per_chunk, gains_row0);
+}
+
+// ============================================================================ K4 / rfft-1024
+// One wavefront per 1024-sample frame.  mode: band sum only, or full 513 magnitudes / bins too.
+__device__ __forceinline__ void rfft1024_wave(const float* __restrict__ x, const float* __restrict__ win,
+                                              const FftTables& tb, float* zl /*LDS [1024]*/, int lane)
+{
+    LaneTw<8, 64> tw;
+    lane_tw_load<8, 64, false>(tw, tb.tw512, lane);
+    cpx v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = 2 * (lane + 64 * j);
+        const float2 xv = *reinterpret_cast<const float2*>(x + n);
+        const float2 wv = *reinterpret_cast<const float2*>(win + n);
+        v[j] = {xv.x * wv.x, xv.y * wv.y};
+    }
+    wave_fft<8, 64, false>(v, tw, lane);
+    const int k2 = bitrev_lane<64>(lane);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+        const int k = k1 + 8 * k2;
+        zl[2 * k] = v[k1].r;
+        zl[2 * k + 1] = v[k1].i;
+    }
+}
+
+// X[k], 0 <= k <= 512, from the complex transform in LDS
+__device__ __forceinline__ cpx rfft1024_bin(const float* zl, const float* st, int k)
+{
+    if (k == 0) return {zl[0] + zl[1], 0.0f};
+    if (k == 512) return {zl[0] - zl[1], 0.0f};
+    const int kk = k <= 256 ? k : 512 - k;
+    cpx xk, xnk;
+    unmix_fwd({zl[2 * kk], zl[2 * kk + 1]}, {zl[2 * (512 - kk)], zl[2 * (512 - kk) + 1]},
+              {st[2 * (kk - 1)], st[2 * (kk - 1) + 1]}, xk, xnk);
+    return (k < 256) ? xk : xnk; // k == 256: the X[ncfft-k] form is written last in kissfft
+}
+
+__global__ __launch_bounds__(256) void vadfft_kernel(const float* __restrict__ den, long n_frames,
+                                                     FftTables tb, int min_bin, int max_bin,
+                                                     float* __restrict__ band_sum,
+                                                     float* __restrict__ bins_out)
+{
+    __shared__ __attribute__((aligned(16))) float zl[4][1024];
+    __shared__ float mag[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long frame = (long)blockIdx.x * 4 + wave;
+    const bool active = frame < n_frames;
+    if (active) rfft1024_wave(den + frame * kVadFft, tb.win1024, tb, zl[wave], lane);
+    __syncthreads();
+    const float norm = tb.norm1024;
+    if (active && bins_out) {
+        for (int k = lane; k < kVadBins; k += 64) {
+            const cpx xk = rfft1024_bin(zl[wave], tb.st1024, k);
+            bins_out[frame * kVadBins + k] = sqrtf(xk.r * xk.r + xk.i * xk.i) * norm; // FFT.zig:16-18
+        }
+    }
+    const int nb = max_bin - min_bin + 1;
+    // band bins (<= 64 of them per pass), then the reference's index-order sum in one lane
+    float acc = 0.0f;
+    for (int base = 0; base < nb; base += 64) {
+        const int k = min_bin + base + lane;
+        if (active && base + lane < nb) {
+            const cpx xk = rfft1024_bin(zl[wave], tb.st1024, k);
+            mag[wave][lane] = sqrtf(xk.r * xk.r + xk.i * xk.i) * norm;
+        }
+        __syncthreads();
+        if (active && lane == 0) {
+            const int cnt = nb - base < 64 ? nb - base : 64;
+            for (int i = 0; i < cnt; ++i) acc += mag[wave][i]; // BufferedFFT.zig:192-199
+        }
+        __syncthreads();
+    }
+    if (active && lane == 0) band_sum[frame] = acc;
+}
+
+void fvad_launch_vadfft(const float* den, long n_frames, FftTables tb, int min_bin, int max_bin,
+                        float* band_sum, float* bins_or_null, hipStream_t stream)
+{
+    if (n_frames <= 0) return;
+    hipLaunchKernelGGL(vadfft_kernel, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0, stream, den,
+                       n_frames, tb, min_bin, max_bin, band_sum, bins_or_null);
+}
+
+// ============================================================================ batched FFT.fft
+__global__ __launch_bounds__(256) void rfft1024_batch_kernel(const float* __restrict__ frames,
+                                                             long n_frames,
+                                                             const float* __restrict__ window,
+                                                             FftTables tb, float* __restrict__ bins,
+                                                             float* __restrict__ mag)
+{
+    __shared__ __attribute__((aligned(16))) float zl[4][1024];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long frame = (long)blockIdx.x * 4 + wave;
+    const bool active = frame < n_frames;
+    if (active) rfft1024_wave(frames + frame * kVadFft, window, tb, zl[wave], lane);
+    __syncthreads();
+    if (!active) return;
+    for (int k = lane; k < kVadBins; k += 64) {
+        const cpx xk = rfft1024_bin(zl[wave], tb.st1024, k);
+        if (bins) { bins[(frame * kVadBins + k) * 2] = xk.r; bins[(frame * kVadBins + k) * 2 + 1] = xk.i; }
+        if (mag) mag[frame * kVadBins + k] = sqrtf(xk.r * xk.r + xk.i * xk.i);
+    }
+}
+
+// 320-point: two frames per wavefront, 8 frames per workgroup, frames straight from global
+__global__ __launch_bounds__(256) void rfft320_batch_kernel(const float* __restrict__ frames,
+                                                            long n_frames,
+                                                            const float* __restrict__ window,
+                                                            FftTables tb, float* __restrict__ bins,
+                                                            float* __restrict__ mag)
+{
+    __shared__ __attribute__((aligned(16))) float zb[4][2][2 * 160];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5;
+    const int p = lane & 31;
+    LaneTw<5, 32> tw;
+    lane_tw_load<5, 32, false>(tw, tb.tw160, p);
+    const int k2 = bitrev_lane<32>(p);
+    float wre[5], wim[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        wre[j] = window[2 * (p + 32 * j)];
+        wim[j] = window[2 * (p + 32 * j) + 1];
+    }
+    // grid-stride over groups of 8 frames
+    for (long base = (long)blockIdx.x * 8; base < n_frames; base += (long)gridDim.x * 8) {
+        const long frame = base + 2 * wave + half;
+        if (frame < n_frames) {
+            const float* x = frames + frame * kNFft;
+            cpx v[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int n = 2 * (p + 32 * j);
+                const float2 xv = *reinterpret_cast<const float2*>(x + n);
+                v[j] = {xv.x * wre[j], xv.y * wim[j]};
+            }
+            wave_fft<5, 32, false>(v, tw, p);
+            float* z = zb[wave][half];
+#pragma unroll
+            for (int k1 = 0; k1 < 5; ++k1) {
+                const int k = k1 + 5 * k2;
+                z[2 * k] = v[k1].r;
+                z[2 * k + 1] = v[k1].i;
+            }
+        }
+        __syncthreads();
+        for (int item = lane; item < 2 * 81; item += 64) {
+            const int hh = item / 81;
+            const int k = item - hh * 81;
+            const long fr = base + 2 * wave + hh;
+            if (fr < n_frames) {
+                const float* z = zb[wave][hh];
+                cpx xk, xnk;
+                int kn;
+                if (k == 0) {
+                    xk = {z[0] + z[1], 0.0f};
+                    xnk = {z[0] - z[1], 0.0f};
+                    kn = 160;
+                } else {
+                    kn = 160 - k;
+                    unmix_fwd({z[2 * k], z[2 * k + 1]}, {z[2 * kn], z[2 * kn + 1]},
+                              {tb.st320[2 * (k - 1)], tb.st320[2 * (k - 1) + 1]}, xk, xnk);
+                }
+                if (bins) {
+                    float* b = bins + fr * kNBins * 2;
+                    if (k != 80) { b[2 * k] = xk.r; b[2 * k + 1] = xk.i; }
+                    b[2 * kn] = xnk.r; b[2 * kn + 1] = xnk.i;
+                }
+                if (mag) {
+                    float* mrow = mag + fr * kNBins;
+                    if (k != 80) mrow[k] = sqrtf(xk.r * xk.r + xk.i * xk.i);
+                    mrow[kn] = sqrtf(xnk.r * xnk.r + xnk.i * xnk.i);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void fvad_launch_rfft_batch(const float* frames, long n_frames, int n_fft, const float* window,
+                            FftTables tb, float* bins_or_null, float* mag_or_null,
+                            hipStream_t stream)
+{
+    if (n_frames <= 0) return;
+    if (n_fft == kVadFft) {
+        hipLaunchKernelGGL(rfft1024_batch_kernel, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0,
+                           stream, frames, n_frames, window, tb, bins_or_null, mag_or_null);
+    } else {
+        long groups = (n_frames + 7) / 8;
+        if (groups > 4096) groups = 4096;
+        hipLaunchKernelGGL(rfft320_batch_kernel, dim3((unsigned)groups), dim3(256), 0, stream, frames,
+                           n_frames, window, tb, bins_or_null, mag_or_null);
+    }
+}
+
+// FFT.invFft for many 320-point frames: bins [n][161][2] -> out [n][320], unscaled
+__global__ __launch_bounds__(256) void irfft320_batch_kernel(const float* __restrict__ bins,
+                                                             long n_frames, FftTables tb,
+                                                             float* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float zb[4][2][2 * 160];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5;
+    const int p = lane & 31;
+    LaneTw<5, 32> tw;
+    lane_tw_load<5, 32, true>(tw, tb.tw160, p);
+    const int k2 = bitrev_lane<32>(p);
+    for (long base = (long)blockIdx.x * 8; base < n_frames; base += (long)gridDim.x * 8) {
+        for (int item = lane; item < 2 * 81; item += 64) {
+            const int hh = item / 81;
+            const int k = item - hh * 81;
+            const long fr = base + 2 * wave + hh;
+            if (fr < n_frames) {
+                const float* b = bins + fr * kNBins * 2;
+                const int kn = 160 - k;
+                const cpx yk = {b[2 * k], b[2 * k + 1]};
+                const cpx ynk = {b[2 * kn], b[2 * kn + 1]};
+                float* z = zb[wave][hh];
+                if (k == 0) {
+                    z[0] = yk.r + ynk.r;
+                    z[1] = yk.r - ynk.r;
+                } else {
+                    cpx tk, tnk;
+                    premix_inv(yk, ynk, {tb.st320[2 * (k - 1)], -tb.st320[2 * (k - 1) + 1]}, tk, tnk);
+                    z[2 * k] = tk.r; z[2 * k + 1] = tk.i;
+                    z[2 * kn] = tnk.r; z[2 * kn + 1] = tnk.i;
+                }
+            }
+        }
+        __syncthreads();
+        const long frame = base + 2 * wave + half;
+        if (frame < n_frames) {
+            const float* z = zb[wave][half];
+            cpx v[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int n = p + 32 * j;
+                v[j] = {z[2 * n], z[2 * n + 1]};
+            }
+            wave_fft<5, 32, true>(v, tw, p);
+            float* o = out + frame * kNFft;
+#pragma unroll
+            for (int k1 = 0; k1 < 5; ++k1) {
+                const int n = 2 * (k1 + 5 * k2);
+                *reinterpret_cast<float2*>(o + n) = make_float2(v[k1].r, v[k1].i);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void fvad_launch_irfft_batch(const float* bins, long n_frames, FftTables tb, float* out,
+                             hipStream_t stream)
+{
+    if (n_frames <= 0) return;
+    long groups = (n_frames + 7) / 8;
+    if (groups > 4096) groups = 4096;
+    hipLaunchKernelGGL(irfft320_batch_kernel, dim3((unsigned)groups), dim3(256), 0, stream, bins,
+                       n_frames, tb, out);
+}

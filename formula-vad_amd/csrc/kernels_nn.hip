@@ -1,0 +1,328 @@
+// kernels_nn.hip -- NSNet2 on gfx950 fp32 MFMA (v_mfma_f32_16x16x4_f32).
+//
+// Replaces onnx_instance.run() (reference src/NSNet2.zig:220) for a batch of independent
+// 54-row sequences.  The GRU hidden state is zero at row 0 of every sequence (the reference's
+// ORT session has no state tensors, NSNet2.zig:57-58,71-112), so sequences -- one per 0.5 s chunk
+// of every stream -- are a pure batch axis; only the 54 steps inside a sequence are serial.
+//
+// Operand convention shared by both kernels ("row panel"): one wavefront owns 16 activation rows
+// for the whole kernel.  Lane l = (m = l & 15, q = l >> 4).  For a 16-deep "super-step" S of the
+// reduction dimension the lane holds the float4  Act[row m][16 S + 4 q .. + 3];  element r of it is
+// the B operand of the r-th of four MFMAs.  Weights are pre-arranged on the host into "fragment
+// blocks" of 64 lanes x 4 floats:  block(tile T, super-step S)[lane][r] = W[16 T + (lane & 15)]
+// [16 S + 4 (lane >> 4) + r]  -- element r is the A operand of the r-th MFMA.  With weights as A
+// and activations as B the result tile D[unit][row] lands as: lane (m, q) holds units
+// 16 T + 4 q + {0..3} of row m in its 4 accumulator registers -- i.e. exactly the float4 the next
+// layer (or the next GRU step) needs as its activation operand for super-step T.  No transposes,
+// no LDS traffic for activations; LDS only stages weight fragment blocks, which are shared by the
+// waves of a workgroup and read back with one conflict-free ds_read_b128 per lane per 4 MFMAs.
+//
+// Each output element is a k-ordered chain of f32 fmas (the MFMA is exact f32 fma, guide:
+// MI355X_MICROARCH.md "Matrix cores"), bias added after the chain like MatMul+Add in the graph.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------ panel GEMM
+// C[row][n0 + ...] = act(A[row][0..16 S_steps) . W^T + bias), one workgroup = WAVES*16 rows x
+// one block of NT*16 output units.  grid = (rows / (16 WAVES), n_blocks).
+// Wfrag: [n_blocks][S_steps][NT][64][4] floats.
+template <int NT, int ACT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void panel_gemm_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ Wfrag,
+    const float* __restrict__ bias, float* __restrict__ C, int ldc, int S_steps, int row_map_T,
+    int row_map_skip)
+{
+    __shared__ __attribute__((aligned(16))) float slab[2][NT * 256];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int m = lane & 15;
+    const int q = lane >> 4;
+    const int nblk = blockIdx.y;
+
+    // Row mapping: when row_map_T > 0 the kernel's compact row index i addresses only rows
+    // skip..T-1 of every T-row sequence of A (used to run fc2..fc4 on rows 4..53 only).
+    long row = (long)(blockIdx.x * WAVES + wave) * 16 + m;
+    long a_row = row;
+    if (row_map_T > 0) {
+        const int per = row_map_T - row_map_skip;
+        a_row = (row / per) * row_map_T + row_map_skip + (row % per);
+    }
+    const float* a_ptr = A + a_row * (long)lda + 4 * q;
+    const float* w_src = Wfrag + (size_t)nblk * S_steps * (NT * 256);
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int SLAB_F4 = NT * 64;               // float4s per slab
+    constexpr int PER_T = (SLAB_F4 + WAVES * 64 - 1) / (WAVES * 64);
+
+    // prologue: slab 0 -> LDS
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(w_src);
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int idx = tid + i * WAVES * 64;
+            if (idx < SLAB_F4) reinterpret_cast<f32x4*>(slab[0])[idx] = src[idx];
+        }
+    }
+    f32x4 a_cur = *reinterpret_cast<const f32x4*>(a_ptr);
+    __syncthreads();
+
+    for (int S = 0; S < S_steps; ++S) {
+        const int cur = S & 1;
+        f32x4 stage[PER_T];
+        f32x4 a_next = a_cur;
+        const bool more = (S + 1 < S_steps);
+        if (more) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(w_src + (size_t)(S + 1) * (NT * 256));
+#pragma unroll
+            for (int i = 0; i < PER_T; ++i) {
+                const int idx = tid + i * WAVES * 64;
+                if (idx < SLAB_F4) stage[i] = src[idx];
+            }
+            a_next = *reinterpret_cast<const f32x4*>(a_ptr + 16 * (S + 1));
+        }
+        const f32x4* wl = reinterpret_cast<const f32x4*>(slab[cur]) + lane;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 w4 = wl[t * 64];
+            acc[t] = MFMA16(w4.x, a_cur.x, acc[t]);
+            acc[t] = MFMA16(w4.y, a_cur.y, acc[t]);
+            acc[t] = MFMA16(w4.z, a_cur.z, acc[t]);
+            acc[t] = MFMA16(w4.w, a_cur.w, acc[t]);
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < PER_T; ++i) {
+                const int idx = tid + i * WAVES * 64;
+                if (idx < SLAB_F4) reinterpret_cast<f32x4*>(slab[cur ^ 1])[idx] = stage[i];
+            }
+        }
+        a_cur = a_next;
+        __syncthreads();
+    }
+
+    float* c_ptr = C + row * (long)ldc + nblk * (NT * 16) + 4 * q;
+    const float* b_ptr = bias + nblk * (NT * 16) + 4 * q;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(b_ptr + 16 * t);
+        f32x4 v = acc[t] + b4;
+        if (ACT == FVAD_ACT_RELU) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        } else if (ACT == FVAD_ACT_SIGMOID) {
+            v.x = act_sigmoid(v.x); v.y = act_sigmoid(v.y); v.z = act_sigmoid(v.z); v.w = act_sigmoid(v.w);
+        }
+        *reinterpret_cast<f32x4*>(c_ptr + 16 * t) = v;
+    }
+}
+
+template <int NT, int ACT>
+static void launch_panel(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
+                         int ldc, long rows, int n_blocks, int S_steps, int map_T, int map_skip,
+                         hipStream_t stream)
+{
+    constexpr int WAVES = 4;
+    dim3 grid((unsigned)(rows / (16 * WAVES)), (unsigned)n_blocks);
+    hipLaunchKernelGGL((panel_gemm_kernel<NT, ACT, WAVES>), grid, dim3(WAVES * 64), 0, stream, A,
+                       lda, Wfrag, bias, C, ldc, S_steps, map_T, map_skip);
+}
+
+// rows must be a multiple of 64; NT selects the per-block width (16*NT units).
+int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
+                           int ldc, long rows, int nt, int n_blocks, int S_steps, int act,
+                           int map_T, int map_skip, hipStream_t stream)
+{
+#define CASE(NT_, ACT_)                                                                          \
+    if (nt == NT_ && act == ACT_) {                                                              \
+        launch_panel<NT_, ACT_>(A, lda, Wfrag, bias, C, ldc, rows, n_blocks, S_steps, map_T,     \
+                                map_skip, stream);                                               \
+        return 0;                                                                                \
+    }
+    CASE(25, FVAD_ACT_NONE)
+    CASE(19, FVAD_ACT_RELU)
+    CASE(11, FVAD_ACT_SIGMOID)
+#undef CASE
+    return -1;
+}
+
+// ------------------------------------------------------------------ GRU recurrence
+// h_t = GRU(gi_t, h_{t-1}) for T steps, 16 sequences per wavefront.
+//   gi   [n_seq_pad * T][3H]   = x_t W^T + Wb   (from panel_gemm), gate order z,r,h
+//   Rfrag[H/16 J][5 s5][3 g][5 Sin][64][4]      recurrent weights, fragment blocks
+//   bR   [3H]
+//   hout [n_seq_pad * T][H]
+// Specialised for H = 400 (25 unit tiles, 25 super-steps = 5 slabs of 5).
+//
+// h_{t-1} stays in registers as the 25 activation float4s (100 VGPRs).  Each workgroup streams
+// the whole R (1.92 MB, L2-resident) through LDS once per step in 125 slabs of 15 KB
+// (3 gates x 5 super-steps of one unit tile), double-buffered; the waves of the workgroup share
+// every slab.  New h values are written straight to hout in the layout the lane itself re-reads
+// as next step's operand, so the only cross-lane traffic in the recurrence is the MFMA itself.
+constexpr int GRU_H = 400;
+constexpr int GRU_J = GRU_H / 16;     // 25 unit tiles
+constexpr int GRU_S5 = 5;             // slabs per tile
+constexpr int GRU_SIN = 5;            // super-steps per slab
+constexpr int GRU_SLAB = 3 * GRU_SIN * 256; // floats per slab (15 KB)
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gru_rec_kernel(const float* __restrict__ gi,
+                                                             const float* __restrict__ Rfrag,
+                                                             const float* __restrict__ bR,
+                                                             float* hout, int T)
+{
+    __shared__ __attribute__((aligned(16))) float slab[2][GRU_SLAB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int m = lane & 15;
+    const int q = lane >> 4;
+    const long seq = (long)(blockIdx.x * WAVES + wave) * 16 + m;
+
+    const float* gi_seq = gi + seq * T * (3 * GRU_H) + 4 * q;
+    float* h_seq = hout + seq * T * GRU_H + 4 * q;
+    const float* bR_q = bR + 4 * q;
+
+    constexpr int SLAB_F4 = GRU_SLAB / 4; // 960 float4
+    constexpr int PER_T = (SLAB_F4 + WAVES * 64 - 1) / (WAVES * 64);
+
+    // ---- t = 0: h_{-1} = 0, so R h + Rb = Rb
+    for (int J = 0; J < GRU_J; ++J) {
+        const f32x4 giz = *reinterpret_cast<const f32x4*>(gi_seq + 16 * J);
+        const f32x4 gir = *reinterpret_cast<const f32x4*>(gi_seq + GRU_H + 16 * J);
+        const f32x4 gin = *reinterpret_cast<const f32x4*>(gi_seq + 2 * GRU_H + 16 * J);
+        const f32x4 bz = *reinterpret_cast<const f32x4*>(bR_q + 16 * J);
+        const f32x4 br = *reinterpret_cast<const f32x4*>(bR_q + GRU_H + 16 * J);
+        const f32x4 bn = *reinterpret_cast<const f32x4*>(bR_q + 2 * GRU_H + 16 * J);
+        f32x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float z = act_sigmoid(giz[r] + bz[r]);
+            const float rr = act_sigmoid(gir[r] + br[r]);
+            const float n = tanhf(gin[r] + rr * bn[r]);
+            h[r] = (1.0f - z) * n + z * 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(h_seq + 16 * J) = h;
+    }
+
+    // ---- t >= 1
+    // prologue: slab 0 -> LDS buffer 0
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(Rfrag);
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int idx = tid + i * WAVES * 64;
+            if (idx < SLAB_F4) reinterpret_cast<f32x4*>(slab[0])[idx] = src[idx];
+        }
+    }
+    __syncthreads();
+    int buf = 0;
+
+    for (int t = 1; t < T; ++t) {
+        const float* gi_t = gi_seq + (long)t * (3 * GRU_H);
+        const float* h_prev = h_seq + (long)(t - 1) * GRU_H;
+        float* h_out = h_seq + (long)t * GRU_H;
+
+        // this lane's own h_{t-1}, as the activation operand of all 25 super-steps
+        f32x4 hreg[GRU_J];
+#pragma unroll
+        for (int S = 0; S < GRU_J; ++S) hreg[S] = *reinterpret_cast<const f32x4*>(h_prev + 16 * S);
+
+        for (int J = 0; J < GRU_J; ++J) {
+            // epilogue operands, issued early so they land during the MFMA phase
+            const f32x4 giz = *reinterpret_cast<const f32x4*>(gi_t + 16 * J);
+            const f32x4 gir = *reinterpret_cast<const f32x4*>(gi_t + GRU_H + 16 * J);
+            const f32x4 gin = *reinterpret_cast<const f32x4*>(gi_t + 2 * GRU_H + 16 * J);
+            const f32x4 hp = *reinterpret_cast<const f32x4*>(h_prev + 16 * J);
+            const f32x4 bz = *reinterpret_cast<const f32x4*>(bR_q + 16 * J);
+            const f32x4 br = *reinterpret_cast<const f32x4*>(bR_q + GRU_H + 16 * J);
+            const f32x4 bn = *reinterpret_cast<const f32x4*>(bR_q + 2 * GRU_H + 16 * J);
+
+            f32x4 az = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 ar = az, an = az;
+
+#pragma unroll
+            for (int s5 = 0; s5 < GRU_S5; ++s5) {
+                // next slab in the (periodic) sequence
+                int nslab = J * GRU_S5 + s5 + 1;
+                if (nslab == GRU_J * GRU_S5) nslab = 0;
+                const f32x4* src = reinterpret_cast<const f32x4*>(Rfrag + (size_t)nslab * GRU_SLAB);
+                f32x4 stage[PER_T];
+#pragma unroll
+                for (int i = 0; i < PER_T; ++i) {
+                    const int idx = tid + i * WAVES * 64;
+                    if (idx < SLAB_F4) stage[i] = src[idx];
+                }
+                const f32x4* wl = reinterpret_cast<const f32x4*>(slab[buf]) + lane;
+#pragma unroll
+                for (int si = 0; si < GRU_SIN; ++si) {
+                    const f32x4 hv = hreg[s5 * GRU_SIN + si];
+                    const f32x4 wz = wl[(0 * GRU_SIN + si) * 64];
+                    const f32x4 wr = wl[(1 * GRU_SIN + si) * 64];
+                    const f32x4 wn = wl[(2 * GRU_SIN + si) * 64];
+                    az = MFMA16(wz.x, hv.x, az);
+                    ar = MFMA16(wr.x, hv.x, ar);
+                    an = MFMA16(wn.x, hv.x, an);
+                    az = MFMA16(wz.y, hv.y, az);
+                    ar = MFMA16(wr.y, hv.y, ar);
+                    an = MFMA16(wn.y, hv.y, an);
+                    az = MFMA16(wz.z, hv.z, az);
+                    ar = MFMA16(wr.z, hv.z, ar);
+                    an = MFMA16(wn.z, hv.z, an);
+                    az = MFMA16(wz.w, hv.w, az);
+                    ar = MFMA16(wr.w, hv.w, ar);
+                    an = MFMA16(wn.w, hv.w, an);
+                }
+#pragma unroll
+                for (int i = 0; i < PER_T; ++i) {
+                    const int idx = tid + i * WAVES * 64;
+                    if (idx < SLAB_F4) reinterpret_cast<f32x4*>(slab[buf ^ 1])[idx] = stage[i];
+                }
+                buf ^= 1;
+                __syncthreads();
+            }
+
+            f32x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = act_sigmoid(giz[r] + (az[r] + bz[r]));
+                const float rr = act_sigmoid(gir[r] + (ar[r] + br[r]));
+                const float n = tanhf(gin[r] + rr * (an[r] + bn[r]));
+                h[r] = (1.0f - z) * n + z * hp[r];
+            }
+            *reinterpret_cast<f32x4*>(h_out + 16 * J) = h;
+        }
+    }
+}
+
+// n_seq_pad must be a multiple of 16*waves (waves = 4 or 8)
+int fvad_launch_gru_rec(const float* gi, const float* Rfrag, const float* bR, float* hout,
+                        long n_seq_pad, int T, int waves, hipStream_t stream)
+{
+    if (waves == 8) {
+        hipLaunchKernelGGL((gru_rec_kernel<8>), dim3((unsigned)(n_seq_pad / 128)), dim3(512), 0,
+                           stream, gi, Rfrag, bR, hout, T);
+    } else if (waves == 4) {
+        hipLaunchKernelGGL((gru_rec_kernel<4>), dim3((unsigned)(n_seq_pad / 64)), dim3(256), 0,
+                           stream, gi, Rfrag, bR, hout, T);
+    } else if (waves == 1) {
+        hipLaunchKernelGGL((gru_rec_kernel<1>), dim3((unsigned)(n_seq_pad / 16)), dim3(64), 0,
+                           stream, gi, Rfrag, bR, hout, T);
+    } else {
+        return -1;
+    }
+    return 0;
+}

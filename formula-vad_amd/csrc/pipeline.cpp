@@ -1,0 +1,444 @@
+// pipeline.cpp -- host-side mirrors of the reference's three seams above the batched engine:
+//   B3  fvad_fft       <-> src/FFT.zig            (init / fft / invFft / bin helpers)
+//   B2  fvad_nsnet2    <-> src/NSNet2.zig         (init / denoise / getChunkSize)
+//   B1  fvad_pipeline  <-> src/AudioPipeline.zig  (init / pushSamples / vad_segments)
+// Same names, argument meaning and error behaviour; the arithmetic runs in the HIP kernels, the
+// sequential VAD state machine (src/AudioPipeline/VADMachine.zig) on the host (host_vad.cpp).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "host_vad.h"
+#include "internal.h"
+
+using namespace fvad;
+
+// ------------------------------------------------------------------ B3: FFT
+struct fvad_fft {
+    fvad_ctx* ctx;
+    size_t n_fft, sample_rate;
+    bool inverse;
+    float* d_in = nullptr;   // n_fft
+    float* d_win = nullptr;  // n_fft
+    float* d_out = nullptr;  // (n_fft/2+1)*2
+    std::vector<float> h_in;
+};
+
+extern "C" {
+
+int fvad_fft_create(fvad_ctx* ctx, size_t n_fft, size_t sample_rate, int mode_inverse, fvad_fft** out)
+{
+    if (!ctx || !out) return FVAD_ERR_INVALID_ARGUMENT;
+    if (n_fft == 0 || n_fft % 2 != 0) return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "n_fft must be even and non-zero"); // FFT.zig:41-43
+    if (!(n_fft == 320 || (n_fft == 1024 && !mode_inverse)))
+        return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "gfx950 kernels exist for the sizes the pipeline uses: 320 (fwd/inv) and 1024 (fwd)");
+    hipSetDevice(ctx->device);
+    auto* f = new (std::nothrow) fvad_fft();
+    if (!f) return FVAD_ERR_ALLOC_FAILED;
+    f->ctx = ctx; f->n_fft = n_fft; f->sample_rate = sample_rate; f->inverse = mode_inverse != 0;
+    f->h_in.resize(n_fft);
+    if (hipMalloc((void**)&f->d_in, n_fft * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&f->d_win, n_fft * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&f->d_out, (n_fft / 2 + 1) * 2 * sizeof(float)) != hipSuccess) {
+        fvad_fft_destroy(f);
+        return set_err(ctx, FVAD_ERR_ALLOC_FAILED, "hipMalloc failed"); // KissFFTAllocFailed, FFT.zig:58-60
+    }
+    *out = f;
+    return FVAD_OK;
+}
+
+void fvad_fft_destroy(fvad_fft* f)
+{
+    if (!f) return;
+    if (f->d_in) hipFree(f->d_in);
+    if (f->d_win) hipFree(f->d_win);
+    if (f->d_out) hipFree(f->d_out);
+    delete f;
+}
+
+size_t fvad_fft_bin_count(const fvad_fft* f) { return f->n_fft / 2 + 1; }                      // FFT.zig:137-139
+float fvad_fft_bin_width(const fvad_fft* f) { return (float)f->sample_rate / (float)f->n_fft; } // :142-147
+float fvad_fft_nyquist_freq(const fvad_fft* f) { return (float)f->sample_rate / 2; }            // :150-153
+
+int fvad_fft_freq_to_bin(const fvad_fft* f, float freq, size_t* bin) // FFT.zig:156-167
+{
+    if (!f || !bin) return FVAD_ERR_INVALID_ARGUMENT;
+    if (freq > fvad_fft_nyquist_freq(f)) return FVAD_ERR_OUT_OF_RANGE;
+    if (freq < 0) return FVAD_ERR_NEGATIVE_FREQUENCY;
+    *bin = (size_t)roundf(freq / fvad_fft_bin_width(f)); // @round: half away from zero
+    return FVAD_OK;
+}
+
+int fvad_fft_bin_to_freq(const fvad_fft* f, size_t bin, float* freq) // FFT.zig:170-180
+{
+    if (!f || !freq) return FVAD_ERR_INVALID_ARGUMENT;
+    if (bin > fvad_fft_bin_count(f) - 1) return FVAD_ERR_OUT_OF_RANGE;
+    *freq = (float)bin * fvad_fft_bin_width(f);
+    return FVAD_OK;
+}
+
+int fvad_fft_forward(fvad_fft* f, const float* first, size_t n_first, const float* second, size_t n_second,
+                     const float* window, size_t n_window, fvad_complex* bins, size_t n_bins)
+{
+    if (!f) return FVAD_ERR_INVALID_ARGUMENT;
+    fvad_ctx* ctx = f->ctx;
+    // the reference's checks, in its order (FFT.zig:91-102)
+    if (n_first + n_second != f->n_fft) return set_err(ctx, FVAD_ERR_INVALID_SAMPLES_LENGTH, "samples.len != n_fft");
+    if (n_window != f->n_fft) return set_err(ctx, FVAD_ERR_INVALID_WINDOW_LENGTH, "window.len != n_fft");
+    if (n_bins != fvad_fft_bin_count(f)) return set_err(ctx, FVAD_ERR_INVALID_RESULT_LENGTH, "bins.len != binCount()");
+    if (f->inverse) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "forward transform on an inverse-mode FFT");
+    if ((n_first && !first) || (n_second && !second) || !window || !bins) return FVAD_ERR_INVALID_ARGUMENT;
+    hipSetDevice(ctx->device);
+    if (n_first) memcpy(f->h_in.data(), first, n_first * sizeof(float));
+    if (n_second) memcpy(f->h_in.data() + n_first, second, n_second * sizeof(float));
+    hipStream_t st = ctx->stream;
+    FVAD_HIP(ctx, hipMemcpyAsync(f->d_in, f->h_in.data(), f->n_fft * sizeof(float), hipMemcpyHostToDevice, st));
+    FVAD_HIP(ctx, hipMemcpyAsync(f->d_win, window, f->n_fft * sizeof(float), hipMemcpyHostToDevice, st));
+    fvad_launch_rfft_batch(f->d_in, 1, (int)f->n_fft, f->d_win, ctx->tb, f->d_out, nullptr, st);
+    FVAD_HIP(ctx, hipMemcpyAsync(bins, f->d_out, n_bins * sizeof(fvad_complex), hipMemcpyDeviceToHost, st));
+    FVAD_HIP(ctx, hipStreamSynchronize(st));
+    return FVAD_OK;
+}
+
+int fvad_fft_inverse(fvad_fft* f, const fvad_complex* bins, size_t n_bins, float* result, size_t n_result)
+{
+    if (!f) return FVAD_ERR_INVALID_ARGUMENT;
+    fvad_ctx* ctx = f->ctx;
+    if (n_bins != fvad_fft_bin_count(f)) return set_err(ctx, FVAD_ERR_INVALID_BINS_LENGTH, "bins.len != binCount()");   // FFT.zig:120-122
+    if (n_result != f->n_fft) return set_err(ctx, FVAD_ERR_INVALID_RESULT_LENGTH, "result.len != n_fft");                // :124-126
+    if (!f->inverse) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "inverse transform on a forward-mode FFT");
+    if (!bins || !result) return FVAD_ERR_INVALID_ARGUMENT;
+    hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    FVAD_HIP(ctx, hipMemcpyAsync(f->d_out, bins, n_bins * sizeof(fvad_complex), hipMemcpyHostToDevice, st));
+    fvad_launch_irfft_batch(f->d_out, 1, ctx->tb, f->d_in, st);
+    FVAD_HIP(ctx, hipMemcpyAsync(result, f->d_in, f->n_fft * sizeof(float), hipMemcpyDeviceToHost, st));
+    FVAD_HIP(ctx, hipStreamSynchronize(st));
+    return FVAD_OK;
+}
+
+int fvad_fft_forward_batch(fvad_fft* f, const float* frames, size_t n_frames, const float* window,
+                           fvad_complex* bins, float* magnitudes, int on_device)
+{
+    if (!f || !frames || !window) return FVAD_ERR_INVALID_ARGUMENT;
+    fvad_ctx* ctx = f->ctx;
+    if (f->inverse) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "forward transform on an inverse-mode FFT");
+    if (n_frames == 0) return FVAD_OK;
+    hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    const size_t nb = fvad_fft_bin_count(f);
+    if (on_device) {
+        fvad_launch_rfft_batch(frames, (long)n_frames, (int)f->n_fft, window, ctx->tb, (float*)bins, magnitudes, st);
+        FVAD_HIP(ctx, hipGetLastError());
+        return FVAD_OK;
+    }
+    float *d_fr = nullptr, *d_bins = nullptr, *d_mag = nullptr;
+    int rc = FVAD_OK;
+    auto cleanup = [&]() { if (d_fr) hipFree(d_fr); if (d_bins) hipFree(d_bins); if (d_mag) hipFree(d_mag); };
+    if (hipMalloc((void**)&d_fr, n_frames * f->n_fft * sizeof(float)) != hipSuccess ||
+        (bins && hipMalloc((void**)&d_bins, n_frames * nb * 2 * sizeof(float)) != hipSuccess) ||
+        (magnitudes && hipMalloc((void**)&d_mag, n_frames * nb * sizeof(float)) != hipSuccess)) {
+        cleanup();
+        return set_err(ctx, FVAD_ERR_ALLOC_FAILED, "hipMalloc failed");
+    }
+    hipMemcpyAsync(d_fr, frames, n_frames * f->n_fft * sizeof(float), hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(f->d_win, window, f->n_fft * sizeof(float), hipMemcpyHostToDevice, st);
+    fvad_launch_rfft_batch(d_fr, (long)n_frames, (int)f->n_fft, f->d_win, ctx->tb, d_bins, d_mag, st);
+    if (bins) hipMemcpyAsync(bins, d_bins, n_frames * nb * 2 * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (magnitudes) hipMemcpyAsync(magnitudes, d_mag, n_frames * nb * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) rc = set_err(ctx, FVAD_ERR_HIP, "batched FFT failed");
+    cleanup();
+    return rc;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------ B2: NSNet2
+struct fvad_nsnet2 {
+    fvad_ctx* ctx;
+    size_t sample_rate;
+    fvad_lane_state* state = nullptr;
+    std::vector<float> staged;
+    std::vector<float> band, rms;
+};
+
+extern "C" {
+
+size_t fvad_nsnet2_chunk_size(size_t in_sample_rate)
+{
+    // chunk_size * calcDownsampleRate(in_sample_rate, 16000)  (NSNet2.zig:157-159, resample.zig:4-7)
+    if (in_sample_rate == 0 || in_sample_rate % 16000 != 0) return 0;
+    return (size_t)(kFramesPerChunk * kNHop) * (in_sample_rate / 16000);
+}
+
+int fvad_nsnet2_create(fvad_ctx* ctx, size_t sample_rate, fvad_nsnet2** out)
+{
+    if (!ctx || !out) return FVAD_ERR_INVALID_ARGUMENT;
+    // the pipeline only ever runs at 48 kHz (VADPipeline.zig:55-58); the decimating kernels are
+    // built for that ratio
+    if (sample_rate != 48000) return set_err(ctx, FVAD_ERR_INVALID_SAMPLE_RATE, "only 48000 Hz input is supported");
+    if (!ctx->dm.loaded) return set_err(ctx, FVAD_ERR_NO_MODEL, "load the NSNet2 model into the context first");
+    auto* d = new (std::nothrow) fvad_nsnet2();
+    if (!d) return FVAD_ERR_ALLOC_FAILED;
+    d->ctx = ctx; d->sample_rate = sample_rate;
+    const int rc = fvad_lane_state_create(ctx, &d->state);
+    if (rc) { delete d; return rc; }
+    d->staged.resize(kChunk48);
+    d->band.resize(64);
+    d->rms.resize(4);
+    *out = d;
+    return FVAD_OK;
+}
+
+void fvad_nsnet2_destroy(fvad_nsnet2* d)
+{
+    if (!d) return;
+    fvad_lane_state_destroy(d->state);
+    delete d;
+}
+
+int fvad_nsnet2_denoise(fvad_nsnet2* d, const float* first, size_t n_first, const float* second, size_t n_second,
+                        float* denoised_result, size_t n_result)
+{
+    if (!d) return FVAD_ERR_INVALID_ARGUMENT;
+    fvad_ctx* ctx = d->ctx;
+    const size_t chunk = fvad_nsnet2_chunk_size(d->sample_rate);
+    if (n_first + n_second != chunk) return set_err(ctx, FVAD_ERR_INVALID_INPUT_LENGTH, "samples.len != chunk size"); // NSNet2.zig:166-169
+    if (n_result != chunk) return set_err(ctx, FVAD_ERR_INVALID_RESULT_LENGTH, "denoised_result.len != chunk size");   // resample.zig:38-40 (@panic there)
+    if ((n_first && !first) || (n_second && !second) || !denoised_result) return FVAD_ERR_INVALID_ARGUMENT;
+    if (n_first) memcpy(d->staged.data(), first, n_first * sizeof(float));
+    if (n_second) memcpy(d->staged.data() + n_first, second, n_second * sizeof(float));
+    fvad_lane lane;
+    memset(&lane, 0, sizeof lane);
+    lane.pcm = d->staged.data();
+    lane.n_samples = chunk;
+    lane.state = d->state;
+    lane.denoised = denoised_result;
+    lane.band_sum = d->band.data();
+    lane.band_sum_capacity = d->band.size();
+    lane.chunk_rms = d->rms.data();
+    lane.chunk_rms_capacity = d->rms.size();
+    return fvad_engine_run(ctx, &lane, 1, nullptr);
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------ B1: AudioPipeline
+struct fvad_pipeline {
+    fvad_ctx* ctx;
+    fvad_pipeline_config cfg;
+    fvad_callbacks cb{};
+    bool has_cb = false;
+    size_t chunk_size;
+    std::vector<std::vector<float>> pending;  // per channel: pushed, not yet processed
+    uint64_t total_write_count = 0;           // AudioPipeline.totalWriteCount
+    uint64_t pipeline_read_count = 0;         // VADPipeline.pipeline_read_count
+    std::vector<fvad_lane_state*> states;     // per channel (one NSNet2 per channel, BufferedDenoiser.zig:38-41)
+    std::unique_ptr<VadMachine> vad;
+    std::vector<std::unique_ptr<VadMachine>> alt;
+    long min_bin = 0, max_bin = 0;
+    // metadata carried between the stages (VADMetadata.zig)
+    std::vector<float> chunk_ratio;           // per chunk: volume_ratio after the denoiser stage
+    uint64_t frames_done = 0;                 // FFT frames handed to the state machine so far
+    // traces
+    std::vector<float> trace_band, trace_ratio;
+    // scratch
+    std::vector<std::vector<float>> band, rms;
+};
+
+// BufferedFFT.write's metadata for frame k (BufferedFFT.zig:137-140,153): weighted mean of the
+// chunk ratios over the chunks whose samples the 1024-sample window covers, accumulated in f32 in
+// chunk order exactly like VADMetadata.push / toResult.
+static MetaResult frame_metadata(const std::vector<float>& chunk_ratio, uint64_t frame, size_t fft_size, size_t chunk_size)
+{
+    Metadata m;
+    const uint64_t from = frame * fft_size, to = from + fft_size;
+    for (uint64_t c = from / chunk_size; c * chunk_size < to; ++c) {
+        const uint64_t lo = std::max<uint64_t>(from, c * chunk_size);
+        const uint64_t hi = std::min<uint64_t>(to, (c + 1) * chunk_size);
+        MetaResult r;
+        r.has_ratio = true;
+        r.volume_ratio = chunk_ratio[(size_t)c];
+        m.push(r, (float)(hi - lo)); // weight = n_written, an integer -> @floatFromInt
+    }
+    return m.to_result();
+}
+
+extern "C" {
+
+void fvad_pipeline_config_default(fvad_pipeline_config* c)
+{
+    memset(c, 0, sizeof *c);
+    c->sample_rate = 48000;
+    c->n_channels = 1;
+    c->buffer_length = 0;
+    c->skip_processing = 0;
+    c->fft_size = 1024; // VADPipeline.zig:21
+    fvad_vad_config_default(&c->vad_machine_config);
+}
+
+int fvad_pipeline_create(fvad_ctx* ctx, const fvad_pipeline_config* cfg, const fvad_callbacks* callbacks, fvad_pipeline** out)
+{
+    if (!ctx || !cfg || !out) return FVAD_ERR_INVALID_ARGUMENT;
+    if (cfg->sample_rate != 48000) return set_err(ctx, FVAD_ERR_INVALID_SAMPLE_RATE, "VADPipeline needs 48000 Hz"); // VADPipeline.zig:55-58
+    if (cfg->fft_size == 0 || cfg->fft_size % 2 != 0) return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "fft_size must be even"); // FFT.zig:41-43
+    if (cfg->fft_size != 1024) return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "the VAD-side kernel is built for fft_size = 1024 (the reference default)");
+    if (cfg->n_channels == 0) return FVAD_ERR_INVALID_ARGUMENT;
+    if (!ctx->dm.loaded) return set_err(ctx, FVAD_ERR_NO_MODEL, "load the NSNet2 model into the context first");
+    auto p = std::unique_ptr<fvad_pipeline>(new (std::nothrow) fvad_pipeline());
+    if (!p) return FVAD_ERR_ALLOC_FAILED;
+    p->ctx = ctx;
+    p->cfg = *cfg;
+    if (callbacks) { p->cb = *callbacks; p->has_cb = true; }
+    p->chunk_size = fvad_nsnet2_chunk_size(cfg->sample_rate);
+    p->pending.resize(cfg->n_channels);
+    p->band.resize(cfg->n_channels);
+    p->rms.resize(cfg->n_channels);
+    // band edges: FFT.freqToBin on the 1024-point / 48 kHz transform (BufferedFFT.zig:192-193)
+    const float bin_width = (float)cfg->sample_rate / (float)cfg->fft_size;
+    const float nyq = (float)cfg->sample_rate / 2;
+    const float fmin = cfg->vad_machine_config.speech_min_freq, fmax = cfg->vad_machine_config.speech_max_freq;
+    if (fmin > nyq || fmax > nyq) return set_err(ctx, FVAD_ERR_OUT_OF_RANGE, "speech band above Nyquist");
+    if (fmin < 0 || fmax < 0) return set_err(ctx, FVAD_ERR_NEGATIVE_FREQUENCY, "negative speech band edge");
+    p->min_bin = (long)roundf(fmin / bin_width);
+    p->max_bin = (long)roundf(fmax / bin_width);
+    if (p->max_bin < p->min_bin) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "speech_max_freq < speech_min_freq");
+    for (size_t c = 0; c < cfg->n_channels; ++c) {
+        fvad_lane_state* s = nullptr;
+        const int rc = fvad_lane_state_create(ctx, &s);
+        if (rc) { for (auto* t : p->states) fvad_lane_state_destroy(t); return rc; }
+        p->states.push_back(s);
+    }
+    p->vad.reset(new VadMachine(cfg->vad_machine_config, cfg->sample_rate, cfg->n_channels, cfg->fft_size));
+    for (size_t i = 0; i < cfg->n_alt_vad_machine_configs; ++i)
+        p->alt.emplace_back(new VadMachine(cfg->alt_vad_machine_configs[i], cfg->sample_rate, cfg->n_channels, cfg->fft_size));
+    p->cfg.alt_vad_machine_configs = nullptr; // not retained
+    *out = p.release();
+    return FVAD_OK;
+}
+
+void fvad_pipeline_destroy(fvad_pipeline* p)
+{
+    if (!p) return;
+    for (auto* s : p->states) fvad_lane_state_destroy(s);
+    delete p;
+}
+
+uint64_t fvad_pipeline_total_write_count(const fvad_pipeline* p) { return p ? p->total_write_count : 0; }
+
+int fvad_pipeline_push_samples(fvad_pipeline* p, const float* const* channel_pcm, size_t n_samples, uint64_t* first_sample_index)
+{
+    if (!p || (n_samples && !channel_pcm)) return FVAD_ERR_INVALID_ARGUMENT;
+    fvad_ctx* ctx = p->ctx;
+    const size_t C = p->cfg.n_channels;
+    if (first_sample_index) *first_sample_index = p->total_write_count; // AudioPipeline.zig:119
+    for (size_t c = 0; c < C; ++c) {
+        if (n_samples && !channel_pcm[c]) return set_err(ctx, FVAD_ERR_CHANNEL_COUNT_MISMATCH, "missing channel");
+        p->pending[c].insert(p->pending[c].end(), channel_pcm[c], channel_pcm[c] + n_samples);
+    }
+    p->total_write_count += n_samples;
+    if (p->cfg.skip_processing) { // AudioPipeline.zig:212: samples are written but never read
+        for (auto& v : p->pending) v.clear();
+        return FVAD_OK;
+    }
+    // VADPipeline.collectInputStep (VADPipeline.zig:144-166): every complete chunk, in order -- here
+    // all of them in one batched engine call
+    const size_t n_chunks = (size_t)((p->total_write_count - p->pipeline_read_count) / p->chunk_size);
+    if (n_chunks == 0) return FVAD_OK;
+    std::vector<fvad_lane> lanes(C);
+    const size_t max_frames = (n_chunks * p->chunk_size + p->cfg.fft_size) / p->cfg.fft_size + 1;
+    for (size_t c = 0; c < C; ++c) {
+        p->band[c].resize(max_frames);
+        p->rms[c].resize(n_chunks);
+        fvad_lane& L = lanes[c];
+        memset(&L, 0, sizeof L);
+        L.pcm = p->pending[c].data();
+        L.n_samples = n_chunks * p->chunk_size;
+        L.state = p->states[c];
+        L.band_sum = p->band[c].data();
+        L.band_sum_capacity = max_frames;
+        L.chunk_rms = p->rms[c].data();
+        L.chunk_rms_capacity = n_chunks;
+    }
+    fvad_engine_opts opts;
+    fvad_engine_opts_default(&opts);
+    opts.min_bin = (int32_t)p->min_bin;
+    opts.max_bin = (int32_t)p->max_bin;
+    const int rc = fvad_engine_run(ctx, lanes.data(), C, &opts);
+    if (rc) return rc;
+    p->pipeline_read_count += (uint64_t)n_chunks * p->chunk_size;
+    for (auto& v : p->pending) v.erase(v.begin(), v.begin() + (long)(n_chunks * p->chunk_size));
+
+    // per-chunk metadata: BufferedVolumeAnalyzer.write then BufferedDenoiser.write each push the
+    // ratio with weight 24000 and divide it out again (BufferedVolumeAnalyzer.zig:33-45,
+    // BufferedDenoiser.zig:83-86,115)
+    std::vector<float> ch(C);
+    for (size_t k = 0; k < n_chunks; ++k) {
+        for (size_t c = 0; c < C; ++c) ch[c] = p->rms[c][k];
+        const MetaResult va = analyse_volume(ch.data(), C);
+        Metadata m1; m1.push(va, (float)p->chunk_size);
+        const MetaResult r1 = m1.to_result();
+        Metadata m2; m2.push(r1, (float)p->chunk_size);
+        p->chunk_ratio.push_back(m2.to_result().volume_ratio);
+    }
+    // the state machine, frame by frame (VADPipeline.stateMachineStep, VADPipeline.zig:209-237)
+    const size_t n_frames = lanes[0].n_fft_frames;
+    const uint64_t first_index = lanes[0].first_frame_index;
+    std::vector<float> vols(C);
+    for (size_t k = 0; k < n_frames; ++k) {
+        for (size_t c = 0; c < C; ++c) vols[c] = p->band[c][k];
+        const MetaResult md = frame_metadata(p->chunk_ratio, p->frames_done + k, p->cfg.fft_size, p->chunk_size);
+        const uint64_t index = first_index + (uint64_t)k * p->cfg.fft_size;
+        p->vad->run(index, vols.data(), md.has_ratio, md.volume_ratio);
+        for (auto& a : p->alt) a->run(index, vols.data(), md.has_ratio, md.volume_ratio);
+        p->trace_band.insert(p->trace_band.end(), vols.begin(), vols.end());
+        p->trace_ratio.push_back(md.has_ratio ? md.volume_ratio : NAN);
+    }
+    p->frames_done += n_frames;
+    return FVAD_OK;
+}
+
+size_t fvad_pipeline_segment_count(const fvad_pipeline* p) { return p ? p->vad->segments.size() : 0; }
+
+static int copy_segments(const std::vector<fvad_speech_segment>& v, fvad_speech_segment* out, size_t cap, size_t* n)
+{
+    if (!n) return FVAD_ERR_INVALID_ARGUMENT;
+    *n = v.size();
+    if (cap < v.size()) return FVAD_ERR_BUFFER_TOO_SMALL;
+    if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(fvad_speech_segment));
+    return FVAD_OK;
+}
+
+int fvad_pipeline_segments(const fvad_pipeline* p, fvad_speech_segment* out, size_t cap, size_t* n)
+{
+    if (!p) return FVAD_ERR_INVALID_ARGUMENT;
+    return copy_segments(p->vad->segments, out, cap, n);
+}
+
+int fvad_pipeline_alt_segments(const fvad_pipeline* p, size_t alt_index, fvad_speech_segment* out, size_t cap, size_t* n)
+{
+    if (!p || alt_index >= p->alt.size()) return FVAD_ERR_INVALID_ARGUMENT;
+    return copy_segments(p->alt[alt_index]->segments, out, cap, n);
+}
+
+int fvad_pipeline_audit(const fvad_pipeline* p, fvad_vad_audit* out)
+{
+    if (!p || !out) return FVAD_ERR_INVALID_ARGUMENT;
+    *out = p->vad->audit;
+    return FVAD_OK;
+}
+
+size_t fvad_pipeline_n_fft_frames(const fvad_pipeline* p) { return p ? (size_t)p->frames_done : 0; }
+
+int fvad_pipeline_trace(const fvad_pipeline* p, float* band_volumes, float* vol_ratio, size_t cap_frames)
+{
+    if (!p) return FVAD_ERR_INVALID_ARGUMENT;
+    if (cap_frames < p->frames_done) return FVAD_ERR_BUFFER_TOO_SMALL;
+    if (band_volumes && !p->trace_band.empty()) memcpy(band_volumes, p->trace_band.data(), p->trace_band.size() * sizeof(float));
+    if (vol_ratio && !p->trace_ratio.empty()) memcpy(vol_ratio, p->trace_ratio.data(), p->trace_ratio.size() * sizeof(float));
+    return FVAD_OK;
+}
+
+} // extern "C"

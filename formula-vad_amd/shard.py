@@ -1,0 +1,47 @@
+"""Multi-GPU sharding of independent streams.
+
+Streams never interact (one pipeline per file in the reference, src/simulator.zig:225-231), so
+whole streams are dealt round-robin to ranks and no audio crosses GPUs.  The only exchange is the
+final gather of the per-stream Evaluator statistics (13 f32 each, statistics.zig:8-37) to rank 0,
+where statistics.aggregate runs in PLAN order to keep the reference's f32 summation order
+(statistics.zig:124-129).  On GPUs the gather is one torch.distributed all_gather over RCCL
+(backend "nccl"); on CPU (tests) the same code runs over gloo."""
+import numpy as np
+
+N_STAT = 11  # floats in SingleStats as laid out in include/fvad.h (f_score_beta included)
+
+
+def streams_for_rank(n_streams, rank, world):
+    """Round-robin: stream i -> rank i % world (21 streams over 8 GPUs -> 3,3,3,3,3,2,2,2)"""
+    return [i for i in range(n_streams) if i % world == rank]
+
+
+def gather_stats(local_ids, local_stats, n_streams, dist=None, device=None):
+    """local_stats: [len(local_ids)][N_STAT] float32.  Returns [n_streams][N_STAT] in plan order on
+    every rank (all_gather of a fixed-size block per rank; payload <= world*max_per_rank*44 B)."""
+    import torch
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    max_per_rank = (n_streams + world - 1) // world
+    block = torch.zeros((max_per_rank, N_STAT + 1), dtype=torch.float32)
+    block[:, 0] = -1.0
+    for j, (sid, st) in enumerate(zip(local_ids, local_stats)):
+        block[j, 0] = float(sid)
+        block[j, 1:] = torch.from_numpy(np.asarray(st, dtype=np.float32))
+    if world == 1:
+        blocks = [block]
+    else:
+        if device is not None:
+            block = block.to(device)
+        blocks = [torch.empty_like(block) for _ in range(world)]
+        dist.all_gather(blocks, block)
+        blocks = [b.cpu() for b in blocks]
+    out = np.zeros((n_streams, N_STAT), np.float32)
+    seen = np.zeros(n_streams, bool)
+    for b in blocks:
+        for row in b.numpy():
+            sid = int(row[0])
+            if sid >= 0:
+                out[sid] = row[1:]
+                seen[sid] = True
+    assert seen.all(), "a stream's statistics never arrived"
+    return out

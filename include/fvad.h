@@ -1,0 +1,359 @@
+/*
+ * fvad.h -- C ABI of libfvad_hip.so: the MI355X (gfx950) implementation of Formula-VAD's
+ * per-frame spectral front end + NSNet2 denoiser + VAD decision path.
+ *
+ * The reference (recursiveGecko/Formula-VAD) is Zig; its hot path sits behind three nested Zig
+ * seams: B1 AudioPipeline (src/AudioPipeline.zig), B2 NSNet2
+ * (src/NSNet2.zig), B3 FFT (src/FFT.zig), which bottom out in two C-ABI dependencies, kissfft
+ * and ONNX Runtime.  Every entry point below names the reference interface it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the Zig `extern` block a
+ * maintainer adds (bindings/fvad.zig).
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns an int
+ * status (0 = FVAD_OK, negative = the reference's Zig error of the same name) unless it is a
+ * pure query; nothing throws or aborts across this boundary.  The caller owns every sample
+ * buffer and the callee never keeps a pointer past the call (same contract as the ring-buffer
+ * slices the reference hands around, src/structures/MultiRingBuffer.zig:159-161).  Objects are
+ * thread-confined like the reference's (one AudioPipeline per OS thread,
+ * src/simulator.zig:225-231): one fvad_ctx = one HIP device + one HIP stream.
+ *
+ * Audio is channel-planar f32 (`[][]f32`, src/AudioPipeline.zig:118); `Complex` is
+ * {f32 r; f32 i} (src/FFT.zig:12-14, == kiss_fft_cpx); sample indices are u64
+ * (src/AudioPipeline/Segment.zig:22).
+ *
+ * The functions that need the GPU fail with FVAD_ERR_NO_DEVICE when no gfx950 device is
+ * present; there is no CPU fallback.  The VAD state machine / Evaluator entry points are host
+ * code by design (src/AudioPipeline/VADMachine.zig is sequential per stream) and work without
+ * a device.
+ */
+#ifndef FVAD_H
+#define FVAD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FVAD_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ status codes */
+enum {
+    FVAD_OK = 0,
+    FVAD_ERR_INVALID_FFT_SIZE = -1,       /* error.InvalidFFTSize        FFT.zig:42 */
+    FVAD_ERR_INVALID_SAMPLES_LENGTH = -2, /* error.InvalidSamplesLength  FFT.zig:92 */
+    FVAD_ERR_INVALID_WINDOW_LENGTH = -3,  /* error.InvalidWindowLength   FFT.zig:96 */
+    FVAD_ERR_INVALID_RESULT_LENGTH = -4,  /* error.InvalidResultLength   FFT.zig:101,125 */
+    FVAD_ERR_INVALID_BINS_LENGTH = -5,    /* error.InvalidBinsLength     FFT.zig:121 */
+    FVAD_ERR_OUT_OF_RANGE = -6,           /* error.OutOfRange            FFT.zig:158,174 */
+    FVAD_ERR_NEGATIVE_FREQUENCY = -7,     /* error.NegativeFrequency     FFT.zig:162 */
+    FVAD_ERR_INVALID_INPUT_LENGTH = -8,   /* error.InvalidInputLength    NSNet2.zig:168 */
+    FVAD_ERR_INVALID_SAMPLE_RATE = -9,    /* error.InvalidSampleRate     VADPipeline.zig:57 */
+    FVAD_ERR_CHANNEL_COUNT_MISMATCH = -10,/* error.ChannelCountMismatch  SegmentWriter.zig:70 */
+    FVAD_ERR_ALLOC_FAILED = -11,          /* error.KissFFTAllocFailed / OutOfMemory FFT.zig:59 */
+    /* errors with no reference counterpart */
+    FVAD_ERR_INVALID_ARGUMENT = -100,
+    FVAD_ERR_NO_DEVICE = -101,            /* no gfx950 device / HIP runtime unavailable */
+    FVAD_ERR_HIP = -102,                  /* a HIP call failed; text in fvad_last_error */
+    FVAD_ERR_NO_MODEL = -103,             /* NSNet2 weights not loaded */
+    FVAD_ERR_MODEL_FORMAT = -104,         /* ONNX file unreadable / not the NSNet2 graph */
+    FVAD_ERR_IO = -105,
+    FVAD_ERR_BUFFER_TOO_SMALL = -106
+};
+
+const char *fvad_status_name(int status);
+int fvad_abi_version(void);
+
+/* ------------------------------------------------------------------ context */
+typedef struct fvad_ctx fvad_ctx;
+
+/* Binds HIP device `device` (hipSetDevice) and creates the context's stream and constant
+ * tables (windows, twiddles).  Replaces the allocator argument every reference init takes. */
+int fvad_ctx_create(int device, fvad_ctx **out);
+void fvad_ctx_destroy(fvad_ctx *ctx);
+/* Text of the last failure on this context ("" if none).  Valid until the next call. */
+const char *fvad_last_error(const fvad_ctx *ctx);
+/* Blocks until all work queued on the context's stream has finished. */
+int fvad_ctx_synchronize(fvad_ctx *ctx);
+/* The context's hipStream_t as an opaque pointer, so a caller can time it with HIP events. */
+void *fvad_ctx_stream(fvad_ctx *ctx);
+
+/* ------------------------------------------------------------------ NSNet2 model
+ * Replaces onnx.OnnxInstance.init(allocator, .{ .model_path = ... }) (NSNet2.zig:53-61): the
+ * model is loaded once per context and shared by every denoiser/pipeline made from it. */
+
+/* Host-side weights in the ONNX operator layout: all matrices [out][in] row-major; GRU tensors
+ * W [3H][in], R [3H][H], B [6H] = {Wb_z,Wb_r,Wb_h,Rb_z,Rb_r,Rb_h}, gate order z,r,h,
+ * linear_before_reset = 1. */
+typedef struct {
+    int32_t n_bins;   /* 161 */
+    int32_t n_fc1;    /* 400 */
+    int32_t n_hidden; /* 400 */
+    int32_t n_fc2;    /* 600 */
+    int32_t n_fc3;    /* 600 */
+    const float *fc1_w, *fc1_b;
+    const float *gru1_w, *gru1_r, *gru1_b;
+    const float *gru2_w, *gru2_r, *gru2_b;
+    const float *fc2_w, *fc2_b;
+    const float *fc3_w, *fc3_b;
+    const float *fc4_w, *fc4_b;
+} fvad_nsnet2_weights;
+
+/* Reads nsnet2-20ms-baseline.onnx (the file NSNet2.zig:56 names) with a built-in protobuf
+ * reader; dimensions are taken from the file. */
+int fvad_load_nsnet2_onnx(fvad_ctx *ctx, const char *onnx_path);
+/* Takes weights from host memory (copied). */
+int fvad_load_nsnet2_weights(fvad_ctx *ctx, const fvad_nsnet2_weights *w);
+/* Seeded synthetic weights of the NSNet2-baseline architecture (for benchmarks and tests: the
+ * real model file is not redistributable here). */
+int fvad_load_nsnet2_synth(fvad_ctx *ctx, uint64_t seed);
+/* Borrow the host copy of the loaded weights (valid until the next load / ctx destroy). */
+int fvad_get_nsnet2_weights(const fvad_ctx *ctx, fvad_nsnet2_weights *out);
+/* Host-only helpers (no device needed): */
+int fvad_onnx_read_nsnet2(const char *onnx_path, fvad_nsnet2_weights *out, void **owner);
+int fvad_synth_nsnet2(uint64_t seed, fvad_nsnet2_weights *out, void **owner);
+void fvad_weights_free(void *owner);
+
+/* ------------------------------------------------------------------ B3: FFT  (src/FFT.zig)
+ * Replaces FFT.init/fft/invFft/deinit and, underneath, kiss_fftr_alloc / kiss_fftr /
+ * kiss_fftri / kiss_fftr_free (FFT.zig:52-57,108-112,129-133,79). */
+typedef struct { float r, i; } fvad_complex; /* FFT.zig:12-14 */
+typedef struct fvad_fft fvad_fft;
+
+/* FFT.init(allocator, n_fft, sample_rate, mode_inverse)  FFT.zig:35-76.  GPU sizes: 320, 1024. */
+int fvad_fft_create(fvad_ctx *ctx, size_t n_fft, size_t sample_rate, int mode_inverse,
+                    fvad_fft **out);
+void fvad_fft_destroy(fvad_fft *fft);                                   /* FFT.deinit :78-83 */
+/* FFT.fft(samples: SplitSlice, window, bins)  FFT.zig:85-113.  Host pointers. */
+int fvad_fft_forward(fvad_fft *fft, const float *first, size_t n_first, const float *second,
+                     size_t n_second, const float *window, size_t n_window, fvad_complex *bins,
+                     size_t n_bins);
+/* FFT.invFft(bins, result)  FFT.zig:115-134: unscaled inverse (== n_fft * x). */
+int fvad_fft_inverse(fvad_fft *fft, const fvad_complex *bins, size_t n_bins, float *result,
+                     size_t n_result);
+size_t fvad_fft_bin_count(const fvad_fft *fft);                         /* FFT.zig:137-139 */
+float fvad_fft_bin_width(const fvad_fft *fft);                          /* :142-147 */
+float fvad_fft_nyquist_freq(const fvad_fft *fft);                       /* :150-153 */
+int fvad_fft_freq_to_bin(const fvad_fft *fft, float freq, size_t *bin); /* :156-167 */
+int fvad_fft_bin_to_freq(const fvad_fft *fft, size_t bin, float *freq); /* :170-180 */
+/* The batched form the GPU wants (BASELINE config 2): n_frames contiguous frames of n_fft
+ * samples -> bins [n_frames][n_fft/2+1] and/or magnitudes [n_frames][n_fft/2+1]; either output
+ * may be NULL.  `on_device` != 0: all pointers are device pointers and the call only enqueues. */
+int fvad_fft_forward_batch(fvad_fft *fft, const float *frames, size_t n_frames,
+                           const float *window, fvad_complex *bins, float *magnitudes,
+                           int on_device);
+
+/* window_fn.zig:22-41, 8-16 and NSNet2.zig:384-396 (host; same f32 arithmetic as the reference) */
+void fvad_hann_window_periodic(float *result, size_t n);
+void fvad_hann_window_symmetric(float *result, size_t n);
+float fvad_window_norm_factor(const float *window, size_t n);
+void fvad_nsnet2_window(float *window320);
+
+/* ------------------------------------------------------------------ B2: NSNet2 (src/NSNet2.zig) */
+typedef struct fvad_nsnet2 fvad_nsnet2;
+/* NSNet2.init(allocator, sample_rate, model_path)  NSNet2.zig:35-142.  The model comes from the
+ * context.  One object per channel, like BufferedDenoiser.zig:38-41. */
+int fvad_nsnet2_create(fvad_ctx *ctx, size_t sample_rate, fvad_nsnet2 **out);
+void fvad_nsnet2_destroy(fvad_nsnet2 *d);                               /* NSNet2.zig:144-155 */
+size_t fvad_nsnet2_chunk_size(size_t in_sample_rate);                   /* NSNet2.zig:157-159 */
+/* NSNet2.denoise(samples: SplitSlice, denoised_result)  NSNet2.zig:161-237.  Host pointers;
+ * carries the same cross-chunk state (input hop, overlap-add tail, 4 feature rows,
+ * last_sample: NSNet2.zig:27-33). */
+int fvad_nsnet2_denoise(fvad_nsnet2 *d, const float *first, size_t n_first, const float *second,
+                        size_t n_second, float *denoised_result, size_t n_result);
+
+/* ------------------------------------------------------------------ batched engine
+ * What simulator.zig would call with preload_audio = true: whole streams in, per-stream VAD
+ * inputs out.  A "lane" is one channel of one stream.  For every lane the engine runs, for all
+ * complete 24000-sample chunks at once: chunk RMS (BufferedVolumeAnalyzer.zig:48-69), decimate +
+ * sqrt-Hann STFT-320 + log-power features (NSNet2.zig:205-219), NSNet2 (NSNet2.zig:220), gain +
+ * inverse STFT overlap-add + x3 upsample (NSNet2.zig:221-236), then the 1024-point periodic-Hann
+ * rFFT magnitude and 500-2000 Hz band sum of the denoised audio (BufferedFFT.zig:162-202). */
+typedef struct fvad_lane_state fvad_lane_state; /* cross-call carry of one lane (device) */
+int fvad_lane_state_create(fvad_ctx *ctx, fvad_lane_state **out);
+void fvad_lane_state_reset(fvad_lane_state *s);
+void fvad_lane_state_destroy(fvad_lane_state *s);
+
+typedef struct {
+    const float *pcm;        /* n_samples f32 @48 kHz (host or device, see on_device) */
+    size_t n_samples;        /* only floor(n/24000) chunks are consumed */
+    fvad_lane_state *state;  /* NULL = fresh stream (zero history), state not kept */
+    float *denoised;         /* out, optional: n_chunks*24000 f32 (same memory space as pcm) */
+    float *band_sum;         /* out: one f32 per completed 1024-sample frame */
+    size_t band_sum_capacity;
+    float *chunk_rms;        /* out: one f32 per chunk */
+    size_t chunk_rms_capacity;
+    float *fft_bins;         /* out, optional (parity/debug): [n_fft_frames][513] magnitudes */
+    /* filled by the call: */
+    size_t n_chunks;         /* chunks consumed */
+    size_t n_fft_frames;     /* band sums written */
+    uint64_t first_frame_index; /* absolute sample index of the first FFT frame's window */
+} fvad_lane;
+
+typedef struct {
+    int32_t on_device;       /* pcm/denoised are device pointers; outputs band_sum/chunk_rms/
+                                fft_bins are always host pointers */
+    int32_t min_bin;         /* band edges, inclusive; default 11..43 = freqToBin(500/2000) */
+    int32_t max_bin;
+    int32_t max_chunks_per_launch; /* 0 = default (16384) */
+} fvad_engine_opts;
+void fvad_engine_opts_default(fvad_engine_opts *o);
+
+int fvad_engine_run(fvad_ctx *ctx, fvad_lane *lanes, size_t n_lanes, const fvad_engine_opts *opts);
+
+/* Benchmark form: everything device-resident, nothing copied back; outputs stay in the
+ * context's workspace.  Returns after enqueueing.  `d_pcm` holds n_lanes lanes of n_samples. */
+int fvad_engine_enqueue_device(fvad_ctx *ctx, const float *d_pcm, size_t n_lanes,
+                               size_t lane_stride, size_t n_samples, float *d_denoised,
+                               float *d_band_sum, float *d_chunk_rms,
+                               const fvad_engine_opts *opts);
+/* NSNet2 graph only: features [n_seq][T][161] -> gains [n_seq][T][161] (host pointers).
+ * Replaces onnx_instance.run() (NSNet2.zig:220) for n_seq independent sequences. */
+int fvad_nsnet2_forward(fvad_ctx *ctx, const float *features, size_t n_seq, size_t T,
+                        float *gains);
+/* Per-kernel device time of the last fvad_engine_* call (HIP events on the context's stream):
+ * names[i]/ms[i] for i < *n.  Enabled by fvad_ctx_enable_timing(ctx, 1). */
+int fvad_ctx_enable_timing(fvad_ctx *ctx, int on);
+int fvad_ctx_kernel_times(fvad_ctx *ctx, const char **names, float *ms, size_t cap, size_t *n);
+
+/* ------------------------------------------------------------------ VAD state machine (host)
+ * src/AudioPipeline/VADMachine.zig + src/structures/RollingAverage.zig, exact f64 order. */
+typedef struct {
+    float speech_min_freq;             /* 500   VADMachine.zig:32 */
+    float speech_max_freq;             /* 2000  :33 */
+    float long_term_speech_avg_sec;    /* 180   :35 */
+    int32_t has_initial_long_term_avg; /* 1     :36 (?f64) */
+    double initial_long_term_avg;      /* 0.005 */
+    float short_term_speech_avg_sec;   /* 0.2   :38 */
+    float speech_threshold_factor;     /* 10    :41 */
+    float channel_vol_ratio_avg_sec;   /* 0.5   :43 */
+    float channel_vol_ratio_threshold; /* 0.5   :44 */
+    float min_consecutive_sec_to_open; /* 0.2   :46 */
+    float max_speech_gap_sec;          /* 2     :48 */
+    float min_vad_duration_sec;        /* 0.7   :50 */
+} fvad_vad_config;
+void fvad_vad_config_default(fvad_vad_config *c);
+
+typedef struct {
+    uint64_t sample_from, sample_to;
+    float avg_channel_vol_ratio, vad_met_sec;
+} fvad_speech_segment; /* VADPipeline.SpeechSegment, VADPipeline.zig:28-33 */
+
+enum { FVAD_REC_NONE = 0, FVAD_REC_STARTED = 1, FVAD_REC_COMPLETED = 2, FVAD_REC_ABORTED = 3 };
+typedef struct { int32_t recording_state; uint64_t sample_number; } fvad_vad_result; /* :18-28 */
+
+/* smallest decision margins seen so far (the "margin audit" of SURVEY.md section 7): how close
+ * any frame came to flipping `short_term > threshold` or `ratio > 0.5` */
+typedef struct {
+    double min_rel_threshold_margin; /* min |short_term - threshold| / threshold */
+    double min_abs_ratio_margin;     /* min |channel_vol_ratio - ratio_threshold| */
+    uint64_t n_frames;
+} fvad_vad_audit;
+
+typedef struct fvad_vad fvad_vad;
+int fvad_vad_create(const fvad_vad_config *cfg, size_t sample_rate, size_t n_channels,
+                    size_t fft_size, fvad_vad **out);                  /* VADMachine.init :75-128 */
+void fvad_vad_destroy(fvad_vad *v);
+/* VADMachine.run(fft_result)  VADMachine.zig:138-239 with the band volumes already summed. */
+int fvad_vad_run(fvad_vad *v, uint64_t index, const float *channel_volumes, int has_ratio,
+                 float volume_ratio, fvad_vad_result *out);
+size_t fvad_vad_segment_count(const fvad_vad *v);
+int fvad_vad_segments(const fvad_vad *v, fvad_speech_segment *out, size_t cap, size_t *n);
+int fvad_vad_audit_get(const fvad_vad *v, fvad_vad_audit *out);
+/* Many independent streams at once, bit-identical to fvad_vad_run per stream: streams are
+ * advanced in lock-step with the f64 re-summation vectorised ACROSS streams (same index order
+ * within each).  band[s] points at [n_frames[s]][n_channels] f32, ratio[s] at [n_frames[s]].
+ * first_index[s] + 1024*k is frame k's index. */
+int fvad_vad_run_many(fvad_vad *const *vads, size_t n_streams, const float *const *band,
+                      const float *const *ratio, const size_t *n_frames, size_t n_channels,
+                      const uint64_t *first_index, size_t fft_size, int n_threads);
+
+/* RollingAverage.zig:11-56 exposed for parity tests */
+typedef struct fvad_rolling_average fvad_rolling_average;
+int fvad_ra_create(size_t count, int has_initial, double initial_val, fvad_rolling_average **out);
+void fvad_ra_destroy(fvad_rolling_average *ra);
+double fvad_ra_push(fvad_rolling_average *ra, float sample);
+int fvad_ra_last_avg(const fvad_rolling_average *ra, double *out);
+
+/* ------------------------------------------------------------------ B1: AudioPipeline
+ * (src/AudioPipeline.zig) -- what simulator.zig / main.zig hold. */
+typedef struct fvad_audio_buffer {           /* audio_utils/AudioBuffer.zig (recording payload) */
+    const float *const *channel_pcm;
+    size_t n_channels, length, sample_rate;
+    uint64_t global_start_frame_number;
+} fvad_audio_buffer;
+typedef void (*fvad_recording_cb)(void *ctx, const fvad_audio_buffer *recording);
+typedef struct {                              /* AudioPipeline.Callbacks, AudioPipeline.zig:14-18 */
+    void *ctx;
+    fvad_recording_cb on_original_recording;
+    fvad_recording_cb on_denoised_recording;
+} fvad_callbacks;
+
+typedef struct {
+    size_t sample_rate;                       /* AudioPipeline.Config, AudioPipeline.zig:20-26 */
+    size_t n_channels;
+    size_t buffer_length;                     /* 0 = sample_rate * 10 (:46) */
+    int32_t skip_processing;
+    size_t fft_size;                          /* VADPipeline.Config.fft_size = 1024 (:21) */
+    fvad_vad_config vad_machine_config;       /* :22 */
+    const fvad_vad_config *alt_vad_machine_configs; /* :24 */
+    size_t n_alt_vad_machine_configs;
+} fvad_pipeline_config;
+void fvad_pipeline_config_default(fvad_pipeline_config *c);
+
+typedef struct fvad_pipeline fvad_pipeline;
+/* AudioPipeline.init(allocator, config, callbacks)  AudioPipeline.zig:40-102 */
+int fvad_pipeline_create(fvad_ctx *ctx, const fvad_pipeline_config *cfg,
+                         const fvad_callbacks *callbacks, fvad_pipeline **out);
+void fvad_pipeline_destroy(fvad_pipeline *p);                          /* deinit :104-112 */
+/* pushSamples(channel_pcm) -> index of the first pushed sample  AudioPipeline.zig:118-143 */
+int fvad_pipeline_push_samples(fvad_pipeline *p, const float *const *channel_pcm,
+                               size_t n_samples, uint64_t *first_sample_index);
+uint64_t fvad_pipeline_total_write_count(const fvad_pipeline *p);      /* :114-116 */
+/* pipeline.vad.vad_machine.vad_segments  (SimulationInstance.zig:221) */
+size_t fvad_pipeline_segment_count(const fvad_pipeline *p);
+int fvad_pipeline_segments(const fvad_pipeline *p, fvad_speech_segment *out, size_t cap,
+                           size_t *n);
+int fvad_pipeline_alt_segments(const fvad_pipeline *p, size_t alt_index,
+                               fvad_speech_segment *out, size_t cap, size_t *n);
+int fvad_pipeline_audit(const fvad_pipeline *p, fvad_vad_audit *out);
+/* traces for parity tests: per-FFT-frame band sums [n][n_channels] and volume ratios [n] */
+size_t fvad_pipeline_n_fft_frames(const fvad_pipeline *p);
+int fvad_pipeline_trace(const fvad_pipeline *p, float *band_volumes, float *vol_ratio,
+                        size_t cap_frames);
+
+/* ------------------------------------------------------------------ Evaluator (host)
+ * src/Evaluator.zig:90-156 + src/Evaluator/statistics.zig */
+typedef struct {
+    float total_positives_sec, true_positives_sec, false_positives_sec, false_negatives_sec;
+    float true_positive_rate, false_negative_rate, false_discovery_rate, precision;
+    float fm_index, f_score, f_score_beta;
+} fvad_single_stats;                          /* statistics.SingleStats :8-37 */
+typedef struct { float overall, min, max, avg; } fvad_agg_stat;          /* :39-44 */
+typedef struct {
+    float total_positives_sec, true_positives_sec, false_positives_sec, false_negatives_sec;
+    fvad_agg_stat true_positive_rate, false_negative_rate, false_discovery_rate, precision;
+    float fm_index, f_score, f_score_beta;
+} fvad_aggregate_stats;                       /* statistics.AggregateStats :46-75 */
+typedef struct {
+    float ignore_shorter_than_sec, extrude_start, extrude_end, fill_gaps;
+} fvad_stat_config;                           /* statistics.StatConfig :77-83 */
+typedef struct { float from_sec, to_sec; } fvad_segment_sec;
+
+/* SimulationInstance.storeResult's sample->second conversion (SimulationInstance.zig:237-238) */
+fvad_segment_sec fvad_segment_to_sec(const fvad_speech_segment *s, size_t sample_rate);
+/* Evaluator.initAndRun + statistics.fromEvaluator */
+int fvad_stats_from_segments(const fvad_segment_sec *vad, size_t n_vad,
+                             const fvad_segment_sec *ref, size_t n_ref,
+                             const fvad_stat_config *cfg, fvad_single_stats *out);
+/* statistics.aggregate(stats)  statistics.zig:116-172 -- in slice order */
+int fvad_stats_aggregate(const fvad_single_stats *stats, size_t n, fvad_aggregate_stats *out);
+/* formats.parseAudacitySegments / serialize  (Evaluator/formats.zig:7-56) */
+int fvad_parse_audacity(const char *txt, size_t len, fvad_segment_sec *out, size_t cap,
+                        size_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FVAD_H */

@@ -1,0 +1,419 @@
+"""ctypes loader for the CPU oracle (oracle/liborc.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under formula-vad_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+
+
+def _cpu_has_avx2_fma():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    flags = set(line.split(":", 1)[1].split())
+                    return "avx2" in flags and "fma" in flags
+    except OSError:
+        pass
+    return False
+
+
+def build(native=False):
+    """(Re)build liborc.so with the committed Makefile; returns the path."""
+    target = "liborc_native.so" if native else "liborc.so"
+    env = dict(os.environ)
+    if not native and not _cpu_has_avx2_fma():
+        env["ORC_GENERIC"] = "1"
+        subprocess.run(["make", "-C", ORACLE_DIR, "clean"], check=True, env=env,
+                       stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", ORACLE_DIR, target], check=True, env=env,
+                   stdout=subprocess.DEVNULL)
+    return os.path.join(ORACLE_DIR, target)
+
+
+class Cpx(C.Structure):
+    _fields_ = [("r", C.c_float), ("i", C.c_float)]
+
+
+class Weights(C.Structure):
+    _fields_ = [("n_bins", C.c_int32), ("n_fc1", C.c_int32), ("n_hidden", C.c_int32),
+                ("n_fc2", C.c_int32), ("n_fc3", C.c_int32)] + [
+        (n, c_float_p) for n in (
+            "fc1_w", "fc1_b", "gru1_w", "gru1_r", "gru1_b", "gru2_w", "gru2_r", "gru2_b",
+            "fc2_w", "fc2_b", "fc3_w", "fc3_b", "fc4_w", "fc4_b")]
+
+
+class VadConfig(C.Structure):
+    _fields_ = [("speech_min_freq", C.c_float), ("speech_max_freq", C.c_float),
+                ("long_term_speech_avg_sec", C.c_float),
+                ("has_initial_long_term_avg", C.c_int32),
+                ("initial_long_term_avg", C.c_double),
+                ("short_term_speech_avg_sec", C.c_float),
+                ("speech_threshold_factor", C.c_float),
+                ("channel_vol_ratio_avg_sec", C.c_float),
+                ("channel_vol_ratio_threshold", C.c_float),
+                ("min_consecutive_sec_to_open", C.c_float),
+                ("max_speech_gap_sec", C.c_float),
+                ("min_vad_duration_sec", C.c_float)]
+
+
+class SpeechSegment(C.Structure):
+    _fields_ = [("sample_from", C.c_uint64), ("sample_to", C.c_uint64),
+                ("avg_channel_vol_ratio", C.c_float), ("vad_met_sec", C.c_float)]
+
+
+class VadResult(C.Structure):
+    _fields_ = [("recording_state", C.c_int32), ("sample_number", C.c_uint64)]
+
+
+class VadTrace(C.Structure):
+    _fields_ = [("index", C.c_uint64), ("min_volume", C.c_float), ("short_term", C.c_double),
+                ("channel_vol_ratio", C.c_double), ("threshold", C.c_double),
+                ("threshold_met", C.c_int32), ("state_after", C.c_int32)]
+
+
+class PipelineConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_int32), ("n_channels", C.c_int32), ("fft_size", C.c_int32),
+                ("keep_denoised", C.c_int32), ("vad", VadConfig)]
+
+
+class MetaResult(C.Structure):
+    _fields_ = [("has_ratio", C.c_int), ("has_min", C.c_int), ("has_max", C.c_int),
+                ("volume_ratio", C.c_float), ("volume_min", C.c_float), ("volume_max", C.c_float)]
+
+
+class Meta(C.Structure):
+    _fields_ = [("has_ratio", C.c_int), ("has_min", C.c_int), ("has_max", C.c_int),
+                ("ratio_sum", C.c_float), ("ratio_weight", C.c_float),
+                ("volume_min", C.c_float), ("volume_max", C.c_float)]
+
+
+class SingleStats(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "total_positives_sec", "true_positives_sec", "false_positives_sec", "false_negatives_sec",
+        "true_positive_rate", "false_negative_rate", "false_discovery_rate", "precision",
+        "fm_index", "f_score", "f_score_beta")]
+
+
+class AggStat(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("overall", "min", "max", "avg")]
+
+
+class AggregateStats(C.Structure):
+    _fields_ = [("total_positives_sec", C.c_float), ("true_positives_sec", C.c_float),
+                ("false_positives_sec", C.c_float), ("false_negatives_sec", C.c_float),
+                ("true_positive_rate", AggStat), ("false_negative_rate", AggStat),
+                ("false_discovery_rate", AggStat), ("precision", AggStat),
+                ("fm_index", C.c_float), ("f_score", C.c_float), ("f_score_beta", C.c_float)]
+
+
+class StatConfig(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("ignore_shorter_than_sec", "extrude_start",
+                                         "extrude_end", "fill_gaps")]
+
+
+class SegSec(C.Structure):
+    _fields_ = [("from_sec", C.c_float), ("to_sec", C.c_float)]
+
+
+_lib = None
+
+
+def lib(native=False):
+    global _lib
+    if _lib is not None and not native:
+        return _lib
+    path = build(native=native)
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    sz = C.c_size_t
+    sig = {
+        "orc_fftr_alloc": (vp, [C.c_int, C.c_int]),
+        "orc_fftr_free": (None, [vp]),
+        "orc_fftr_forward": (None, [vp, c_float_p, C.POINTER(Cpx)]),
+        "orc_fftr_inverse": (None, [vp, C.POINTER(Cpx), c_float_p]),
+        "orc_fft_fft": (C.c_int, [vp, c_float_p, sz, c_float_p, sz, c_float_p, sz,
+                                  C.POINTER(Cpx), sz]),
+        "orc_fft_bin_count": (C.c_int, [C.c_int]),
+        "orc_fft_freq_to_bin": (C.c_long, [C.c_int, C.c_int, C.c_float]),
+        "orc_hann_window_symmetric": (None, [c_float_p, sz]),
+        "orc_hann_window_periodic": (None, [c_float_p, sz]),
+        "orc_window_norm_factor": (C.c_float, [c_float_p, sz]),
+        "orc_nsnet2_create_window": (None, [c_float_p]),
+        "orc_downsample": (None, [c_float_p, sz, c_float_p, sz, c_float_p, sz, sz]),
+        "orc_upsample": (C.c_float, [c_float_p, sz, c_float_p, sz, C.c_float, sz]),
+        "orc_rms_volume": (C.c_float, [c_float_p, sz, c_float_p, sz]),
+        "orc_nsnet2_forward": (None, [C.POINTER(Weights), c_float_p, C.c_int, c_float_p]),
+        "orc_nsnet2_create": (vp, [C.c_int, C.POINTER(Weights)]),
+        "orc_nsnet2_destroy": (None, [vp]),
+        "orc_nsnet2_chunk_size": (sz, [C.c_int]),
+        "orc_nsnet2_denoise": (C.c_int, [vp, c_float_p, sz, c_float_p, sz, c_float_p, sz]),
+        "orc_nsnet2_features": (c_float_p, [vp]),
+        "orc_nsnet2_gains": (c_float_p, [vp]),
+        "orc_nsnet2_specgram": (C.POINTER(Cpx), [vp]),
+        "orc_nsnet2_audio_output": (c_float_p, [vp]),
+        "orc_nsnet2_spec_features": (None, [c_float_p, C.POINTER(Cpx), c_float_p]),
+        "orc_ra_create": (vp, [sz, C.c_int, C.c_double]),
+        "orc_ra_destroy": (None, [vp]),
+        "orc_ra_push": (C.c_double, [vp, C.c_float]),
+        "orc_ra_last_avg": (C.c_int, [vp, c_double_p]),
+        "orc_meta_reset": (None, [C.POINTER(Meta)]),
+        "orc_meta_push": (None, [C.POINTER(Meta), C.POINTER(MetaResult), C.c_float]),
+        "orc_meta_to_result": (MetaResult, [C.POINTER(Meta)]),
+        "orc_vad_config_default": (None, [C.POINTER(VadConfig)]),
+        "orc_vad_create": (vp, [C.POINTER(VadConfig), C.c_int, C.c_int, C.c_int]),
+        "orc_vad_destroy": (None, [vp]),
+        "orc_vad_run": (VadResult, [vp, C.c_uint64, c_float_p, C.c_int, C.c_float]),
+        "orc_vad_n_segments": (sz, [vp]),
+        "orc_vad_segments": (C.POINTER(SpeechSegment), [vp]),
+        "orc_vad_n_trace": (sz, [vp]),
+        "orc_vad_traces": (C.POINTER(VadTrace), [vp]),
+        "orc_pipeline_config_default": (None, [C.POINTER(PipelineConfig)]),
+        "orc_pipeline_create": (vp, [C.POINTER(PipelineConfig), C.POINTER(Weights),
+                                     C.POINTER(C.c_int)]),
+        "orc_pipeline_destroy": (None, [vp]),
+        "orc_pipeline_push_samples": (C.c_uint64, [vp, C.POINTER(c_float_p), sz]),
+        "orc_pipeline_n_segments": (sz, [vp]),
+        "orc_pipeline_segments": (C.POINTER(SpeechSegment), [vp]),
+        "orc_pipeline_n_fft_frames": (sz, [vp]),
+        "orc_pipeline_band_volumes": (c_float_p, [vp]),
+        "orc_pipeline_frame_vol_ratio": (c_float_p, [vp]),
+        "orc_pipeline_vad_traces": (C.POINTER(VadTrace), [vp]),
+        "orc_pipeline_chunk_rms": (c_float_p, [vp]),
+        "orc_pipeline_n_chunks": (sz, [vp]),
+        "orc_pipeline_denoised": (c_float_p, [vp, C.c_int]),
+        "orc_pipeline_n_denoised": (sz, [vp]),
+        "orc_pipeline_fft_bins": (c_float_p, [vp, sz, C.c_int]),
+        "orc_buffered_fft_frame": (None, [c_float_p, C.c_int, c_float_p]),
+        "orc_band_sum": (C.c_float, [c_float_p, C.c_long, C.c_long]),
+        "orc_sw_create": (vp, [sz]),
+        "orc_sw_destroy": (None, [vp]),
+        "orc_sw_write": (sz, [vp, c_float_p, sz, c_float_p, sz, sz]),
+        "orc_sw_is_full": (C.c_int, [vp]),
+        "orc_sw_reset": (None, [vp, C.c_uint64]),
+        "orc_sw_data": (c_float_p, [vp]),
+        "orc_sw_write_index": (sz, [vp]),
+        "orc_sw_index": (C.c_uint64, [vp]),
+        "orc_stats_from_segments": (SingleStats, [C.POINTER(SegSec), sz, C.POINTER(SegSec), sz,
+                                                  C.POINTER(StatConfig)]),
+        "orc_stats_aggregate": (AggregateStats, [C.POINTER(SingleStats), sz]),
+        "orc_calc_false_positive_sec": (C.c_float, [SegSec, C.POINTER(SegSec), sz,
+                                                    C.POINTER(StatConfig)]),
+        "orc_segment_to_sec": (SegSec, [C.POINTER(SpeechSegment), C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    if not native:
+        _lib = L
+    return L
+
+
+def fptr(a):
+    """float32 C-contiguous ndarray -> float*; None -> NULL"""
+    if a is None:
+        return None
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_float_p)
+
+
+# ------------------------------------------------------------------ numpy-level helpers
+
+
+def rfft(x, inverse_cfg=False):
+    """kiss_fftr restatement on a float32 vector -> complex64[n/2+1]"""
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n = x.shape[0]
+    cfg = L.orc_fftr_alloc(n, 0)
+    out = np.zeros((n // 2 + 1, 2), dtype=np.float32)
+    L.orc_fftr_forward(cfg, fptr(x), out.ctypes.data_as(C.POINTER(Cpx)))
+    L.orc_fftr_free(cfg)
+    return out.view(np.complex64)[:, 0]
+
+
+def irfft_unscaled(X, n):
+    """kiss_fftri restatement: complex64[n/2+1] -> float32[n] (== n * irfft)"""
+    L = lib()
+    Xc = np.ascontiguousarray(np.asarray(X, dtype=np.complex64)).view(np.float32).reshape(-1, 2)
+    cfg = L.orc_fftr_alloc(n, 1)
+    out = np.zeros(n, dtype=np.float32)
+    L.orc_fftr_inverse(cfg, Xc.ctypes.data_as(C.POINTER(Cpx)), fptr(out))
+    L.orc_fftr_free(cfg)
+    return out
+
+
+def hann_symmetric(n):
+    w = np.zeros(n, dtype=np.float32)
+    lib().orc_hann_window_symmetric(fptr(w), n)
+    return w
+
+
+def hann_periodic(n):
+    w = np.zeros(n, dtype=np.float32)
+    lib().orc_hann_window_periodic(fptr(w), n)
+    return w
+
+
+def nsnet2_window():
+    w = np.zeros(320, dtype=np.float32)
+    lib().orc_nsnet2_create_window(fptr(w))
+    return w
+
+
+WEIGHT_SHAPES = lambda nb, f1, h, f2, f3: {  # noqa: E731
+    "fc1_w": (f1, nb), "fc1_b": (f1,),
+    "gru1_w": (3 * h, f1), "gru1_r": (3 * h, h), "gru1_b": (6 * h,),
+    "gru2_w": (3 * h, h), "gru2_r": (3 * h, h), "gru2_b": (6 * h,),
+    "fc2_w": (f2, h), "fc2_b": (f2,), "fc3_w": (f3, f2), "fc3_b": (f3,),
+    "fc4_w": (nb, f3), "fc4_b": (nb,)}
+
+
+def make_weights_struct(wd):
+    """dict name->float32 array (ONNX layout, see oracle/orc.h) -> (Weights, keepalive)"""
+    w = Weights()
+    w.n_bins = wd["fc1_w"].shape[1]
+    w.n_fc1 = wd["fc1_w"].shape[0]
+    w.n_hidden = wd["gru1_r"].shape[1]
+    w.n_fc2 = wd["fc2_w"].shape[0]
+    w.n_fc3 = wd["fc3_w"].shape[0]
+    keep = {}
+    for k in WEIGHT_SHAPES(1, 1, 1, 1, 1):
+        a = np.ascontiguousarray(wd[k], dtype=np.float32)
+        keep[k] = a
+        setattr(w, k, fptr(a))
+    return w, keep
+
+
+def nsnet2_forward(wd, features):
+    w, keep = make_weights_struct(wd)
+    f = np.ascontiguousarray(features, dtype=np.float32)
+    g = np.zeros_like(f)
+    lib().orc_nsnet2_forward(C.byref(w), fptr(f), f.shape[0], fptr(g))
+    return g
+
+
+class Denoiser:
+    """orc_nsnet2 object (NSNet2.zig) for one channel"""
+
+    def __init__(self, wd, sample_rate=48000):
+        self.w, self.keep = make_weights_struct(wd)
+        self.h = lib().orc_nsnet2_create(sample_rate, C.byref(self.w))
+        self.chunk = lib().orc_nsnet2_chunk_size(sample_rate)
+
+    def denoise(self, x, split=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.zeros(self.chunk, dtype=np.float32)
+        if split is None:
+            rc = lib().orc_nsnet2_denoise(self.h, fptr(x), x.shape[0], None, 0, fptr(out),
+                                          out.shape[0])
+        else:
+            a = np.ascontiguousarray(x[:split])
+            b = np.ascontiguousarray(x[split:])
+            rc = lib().orc_nsnet2_denoise(self.h, fptr(a), a.shape[0], fptr(b), b.shape[0],
+                                          fptr(out), out.shape[0])
+        return rc, out
+
+    def features(self):
+        return np.ctypeslib.as_array(lib().orc_nsnet2_features(self.h), (54, 161)).copy()
+
+    def gains(self):
+        return np.ctypeslib.as_array(lib().orc_nsnet2_gains(self.h), (54, 161)).copy()
+
+    def specgram(self):
+        p = C.cast(lib().orc_nsnet2_specgram(self.h), c_float_p)
+        return np.ctypeslib.as_array(p, (50, 161, 2)).copy().view(np.complex64)[..., 0]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_nsnet2_destroy(self.h)
+            self.h = None
+
+
+class Pipeline:
+    """orc_pipeline (AudioPipeline + VADPipeline streaming order)"""
+
+    def __init__(self, wd, n_channels=1, keep_denoised=False, sample_rate=48000, fft_size=1024,
+                 vad_overrides=None):
+        L = lib()
+        self.cfg = PipelineConfig()
+        L.orc_pipeline_config_default(C.byref(self.cfg))
+        self.cfg.n_channels = n_channels
+        self.cfg.sample_rate = sample_rate
+        self.cfg.fft_size = fft_size
+        self.cfg.keep_denoised = 1 if keep_denoised else 0
+        for k, v in (vad_overrides or {}).items():
+            setattr(self.cfg.vad, k, v)
+        self.w, self.keep = make_weights_struct(wd)
+        err = C.c_int(0)
+        self.h = L.orc_pipeline_create(C.byref(self.cfg), C.byref(self.w), C.byref(err))
+        self.err = err.value
+        self.n_channels = n_channels
+
+    def push(self, pcm):
+        """pcm: [n_channels][n] float32"""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        assert pcm.shape[0] == self.n_channels
+        ptrs = (c_float_p * self.n_channels)(*[fptr(pcm[c]) for c in range(self.n_channels)])
+        return lib().orc_pipeline_push_samples(self.h, ptrs, pcm.shape[1])
+
+    def segments(self):
+        n = lib().orc_pipeline_n_segments(self.h)
+        p = lib().orc_pipeline_segments(self.h)
+        return [(p[i].sample_from, p[i].sample_to, p[i].avg_channel_vol_ratio, p[i].vad_met_sec)
+                for i in range(n)]
+
+    def band_volumes(self):
+        n = lib().orc_pipeline_n_fft_frames(self.h)
+        if n == 0:
+            return np.zeros((0, self.n_channels), np.float32)
+        return np.ctypeslib.as_array(lib().orc_pipeline_band_volumes(self.h),
+                                     (n, self.n_channels)).copy()
+
+    def frame_vol_ratio(self):
+        n = lib().orc_pipeline_n_fft_frames(self.h)
+        if n == 0:
+            return np.zeros((0,), np.float32)
+        return np.ctypeslib.as_array(lib().orc_pipeline_frame_vol_ratio(self.h), (n,)).copy()
+
+    def chunk_rms(self):
+        n = lib().orc_pipeline_n_chunks(self.h)
+        if n == 0:
+            return np.zeros((0, self.n_channels), np.float32)
+        return np.ctypeslib.as_array(lib().orc_pipeline_chunk_rms(self.h),
+                                     (n, self.n_channels)).copy()
+
+    def denoised(self):
+        n = lib().orc_pipeline_n_denoised(self.h)
+        out = np.zeros((self.n_channels, n), np.float32)
+        for c in range(self.n_channels):
+            if n:
+                out[c] = np.ctypeslib.as_array(lib().orc_pipeline_denoised(self.h, c), (n,))
+        return out
+
+    def fft_bins(self, frame, channel=0):
+        nb = self.cfg.fft_size // 2 + 1
+        return np.ctypeslib.as_array(lib().orc_pipeline_fft_bins(self.h, frame, channel),
+                                     (nb,)).copy()
+
+    def vad_traces(self):
+        n = lib().orc_pipeline_n_fft_frames(self.h)
+        p = lib().orc_pipeline_vad_traces(self.h)
+        return [(p[i].index, p[i].min_volume, p[i].short_term, p[i].channel_vol_ratio,
+                 p[i].threshold, p[i].threshold_met, p[i].state_after) for i in range(n)]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_pipeline_destroy(self.h)
+            self.h = None

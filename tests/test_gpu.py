@@ -1,0 +1,381 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every comparison goes through the C ABI of
+libfvad_hip.so (formula-vad_amd/binding.py) against the CPU oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star: "FFT/NSNet2 floats within 1e-4 rel", "bit-exact frame
+indices / VAD segment boundaries"):
+  * complex FFT bins: |gpu - ref| <= 1e-4 |ref| where |ref| >= 1e-3 * max|frame|, and
+    <= 2e-6 * max|frame| elsewhere (a relative bound is meaningless on bins that are pure
+    f32 round-off of the transform);
+  * log-power features: abs <= 1e-4 where the bin power is > 1e-10;
+  * NSNet2 gains, denoised audio, band sums, RMS: <= 1e-4 relative (floor noted per test);
+  * indices, frame counts, segment boundaries, error codes: exact.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def assert_bins_close(gpu, ref, what=""):
+    gpu = np.asarray(gpu)
+    ref = np.asarray(ref)
+    mx = np.abs(ref).max(axis=-1, keepdims=True)
+    err = np.abs(gpu - ref)
+    big = np.abs(ref) >= 1e-3 * mx
+    rel = np.where(big, err / np.maximum(np.abs(ref), 1e-30), 0.0)
+    assert rel.max() <= 1e-4, f"{what}: rel {rel.max():.3e}"
+    small = np.where(~big, err / np.maximum(mx, 1e-30), 0.0)
+    assert small.max() <= 2e-6, f"{what}: small-bin abs/max {small.max():.3e}"
+
+
+def assert_rel(gpu, ref, tol=1e-4, floor=0.0, what=""):
+    gpu = np.asarray(gpu, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert gpu.shape == ref.shape, (gpu.shape, ref.shape)
+    err = np.abs(gpu - ref) / np.maximum(np.abs(ref), floor)
+    assert np.all(np.isfinite(gpu)), what
+    assert err.max() <= tol, f"{what}: max rel err {err.max():.3e} (tol {tol})"
+
+
+# ------------------------------------------------------------------ B3: FFT (src/FFT.zig)
+def test_fft_single_frame_matches_oracle(fv, gpu_ctx):
+    rng = np.random.default_rng(1)
+    for n, win in ((320, orc.nsnet2_window()), (1024, orc.hann_periodic(1024))):
+        f = fv.FFT(gpu_ctx, n, 48000)
+        assert f.bin_count() == n // 2 + 1
+        cases = [rng.uniform(-1, 1, n), np.eye(1, n, 3)[0], np.ones(n), np.zeros(n)]
+        for k in (1, 11, 43, 80, 160):
+            cases.append(np.cos(2 * np.pi * k * np.arange(n) / n))
+        for x in cases:
+            x = x.astype(np.float32)
+            X = f.fft(x, win)
+            ref = orc.rfft(x * win)  # loadSamplesFwd: sample * window in f32 (FFT.zig:183-199)
+            if np.abs(ref).max() == 0:
+                assert np.all(X == 0)
+            else:
+                assert_bins_close(X, ref, f"fft{n}")
+        # SplitSlice halves
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        assert np.array_equal(f.fft(x[:77], win, second=x[77:]), f.fft(x, win))
+        f.close()
+
+
+def test_fft_errors_match_reference(fv, gpu_ctx):
+    f = fv.FFT(gpu_ctx, 320, 16000)
+    w = np.ones(320, np.float32)
+    x = np.zeros(320, np.float32)
+    for args, code in (((x[:319], w), -2), ((x, w[:300]), -3)):
+        with pytest.raises(fv.FvadError) as e:
+            f.fft(*args)
+        assert e.value.status == code
+    with pytest.raises(fv.FvadError) as e:
+        f.fft(x, w, n_bins=160)
+    assert e.value.status == -4                      # InvalidResultLength
+    assert f.freq_to_bin(500.0) == 10 and f.freq_to_bin(8000.0) == 160
+    with pytest.raises(fv.FvadError) as e:
+        f.freq_to_bin(8000.5)
+    assert e.value.status == -6                      # OutOfRange
+    with pytest.raises(fv.FvadError) as e:
+        f.freq_to_bin(-1.0)
+    assert e.value.status == -7                      # NegativeFrequency
+    for bad in (0, 321):
+        with pytest.raises(fv.FvadError) as e:
+            fv.FFT(gpu_ctx, bad, 16000)
+        assert e.value.status == -1                  # InvalidFFTSize
+    f1024 = fv.FFT(gpu_ctx, 1024, 48000)
+    assert f1024.freq_to_bin(500.0) == 11 and f1024.freq_to_bin(2000.0) == 43
+
+
+def test_inverse_fft_unscaled_like_kissfft(fv, gpu_ctx):
+    rng = np.random.default_rng(2)
+    fi = fv.FFT(gpu_ctx, 320, 16000, inverse=True)
+    ff = fv.FFT(gpu_ctx, 320, 16000)
+    one = np.ones(320, np.float32)
+    for _ in range(4):
+        x = rng.uniform(-1, 1, 320).astype(np.float32)
+        X = orc.rfft(x)
+        y = fi.inv_fft(X)
+        ref = orc.irfft_unscaled(X, 320)
+        assert np.abs(y - ref).max() <= 1e-4 * np.abs(ref).max() * 1e-1
+        # round trip through the GPU forward: inverse(forward(x)) == 320 * x
+        y2 = fi.inv_fft(ff.fft(x, one)) / 320
+        assert np.abs(y2 - x).max() < 2e-6
+    with pytest.raises(fv.FvadError) as e:
+        fi.inv_fft(np.zeros(160, np.complex64))
+    assert e.value.status == -5                      # InvalidBinsLength
+    with pytest.raises(fv.FvadError) as e:
+        fi.inv_fft(np.zeros(161, np.complex64), n_result=319)
+    assert e.value.status == -4
+
+
+def test_config2_fft_isolation_1024_frames(fv, gpu_ctx):
+    # BASELINE config 2: 1024 frames x 320, U(-1,1), seed 1 -> bins + magnitudes
+    rng = np.random.default_rng(1)
+    frames = rng.uniform(-1, 1, (1024, 320)).astype(np.float32)
+    win = orc.nsnet2_window()
+    f = fv.FFT(gpu_ctx, 320, 16000)
+    bins, mag = f.fft_batch(frames, win)
+    ref = np.stack([orc.rfft(fr * win) for fr in frames])
+    assert_bins_close(bins, ref, "cfg2 bins")
+    assert_rel(mag, np.abs(ref.astype(np.complex128)), 1e-4, floor=1e-3 * np.abs(ref).max(), what="cfg2 |X|")
+    # ragged batch sizes (not a multiple of the 8 frames a workgroup takes) and the empty batch
+    for n in (1, 7, 9):
+        b2, m2 = f.fft_batch(frames[:n], win)
+        assert np.array_equal(b2, bins[:n]) and np.array_equal(m2, mag[:n])
+    b0, m0 = f.fft_batch(frames[:0], win)
+    assert b0.shape == (0, 161)
+    # 1024-point batch
+    f2 = fv.FFT(gpu_ctx, 1024, 48000)
+    fr2 = rng.uniform(-1, 1, (37, 1024)).astype(np.float32)
+    wp = orc.hann_periodic(1024)
+    b, m = f2.fft_batch(fr2, wp)
+    assert_bins_close(b, np.stack([orc.rfft(x * wp) for x in fr2]), "rfft1024 batch")
+
+
+def test_fft_linearity_at_scale(fv, gpu_ctx):
+    # size-independent property at 2^17 frames: FFT(a + b) == FFT(a) + FFT(b) within round-off,
+    # and every frame of a replicated batch is bit-identical
+    rng = np.random.default_rng(3)
+    n = 1 << 17
+    a = rng.uniform(-1, 1, (n, 320)).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, 320)).astype(np.float32)
+    win = np.ones(320, np.float32)
+    f = fv.FFT(gpu_ctx, 320, 16000)
+    A, _ = f.fft_batch(a, win, want_mag=False)
+    B, _ = f.fft_batch(b, win, want_mag=False)
+    S, _ = f.fft_batch(a + b, win, want_mag=False)
+    scale = np.abs(S).max()
+    assert np.abs(S - (A + B)).max() <= 4e-6 * scale
+    rep = np.tile(a[:1], (4096, 1))
+    R, _ = f.fft_batch(rep, win, want_mag=False)
+    assert np.all(R == R[0])
+    # Parseval per frame
+    e_t = (a.astype(np.float64) ** 2).sum(1)
+    p = np.abs(A.astype(np.complex128)) ** 2
+    e_f = (p[:, 0] + p[:, -1] + 2 * p[:, 1:-1].sum(1)) / 320
+    assert np.abs(e_f / e_t - 1).max() < 1e-5
+
+
+# ------------------------------------------------------------------ NSNet2 graph (NSNet2.zig:220)
+def test_nsnet2_forward_matches_oracle(fv, gpu_ctx, weights7):
+    rng = np.random.default_rng(4)
+    for n_seq, T in ((1, 54), (3, 54), (130, 54), (5, 7)):
+        f = rng.uniform(-11, 2, (n_seq, T, 161)).astype(np.float32)
+        f[0, :2] = 0.0  # literal-zero warm-up rows of a first chunk
+        g = gpu_ctx.nsnet2_forward(f)
+        ref = np.stack([orc.nsnet2_forward(weights7, s) for s in f])
+        assert_rel(g, ref, 1e-4, floor=1e-2, what=f"gains n_seq={n_seq} T={T}")
+        assert g.min() >= 0 and g.max() <= 1
+    # the GRU state is reset for every sequence: batch order cannot matter
+    f = rng.uniform(-11, 2, (40, 54, 161)).astype(np.float32)
+    g = gpu_ctx.nsnet2_forward(f)
+    g_rev = gpu_ctx.nsnet2_forward(f[::-1].copy())
+    assert np.array_equal(g, g_rev[::-1])
+
+
+def test_get_weights_roundtrip(fv, gpu_ctx, weights7):
+    got = gpu_ctx.weights()
+    for k in fv.WEIGHT_NAMES:
+        assert np.array_equal(got[k], weights7[k])
+
+
+# ------------------------------------------------------------------ B2: NSNet2.denoise streaming
+def test_nsnet2_denoise_streaming_matches_oracle(fv, gpu_ctx, weights7, pkg):
+    pcm, _ = pkg.synth.make_stream(2.5, seed=5)
+    x = pcm[0]
+    d_gpu = fv.NSNet2(gpu_ctx)
+    d_ref = orc.Denoiser(weights7)
+    assert d_gpu.chunk == 24000 == fv.lib().fvad_nsnet2_chunk_size(48000)
+    assert fv.lib().fvad_nsnet2_chunk_size(16000) == 8000
+    for c in range(5):
+        chunk = x[24000 * c: 24000 * (c + 1)]
+        split = None if c % 2 == 0 else 10007  # SplitSlice first/second
+        y = d_gpu.denoise(chunk, split)
+        rc, yr = d_ref.denoise(chunk, split)
+        assert rc == 0
+        assert_rel(y, yr, 1e-4, floor=1e-3 * np.abs(yr).max(), what=f"denoised chunk {c}")
+    with pytest.raises(fv.FvadError) as e:
+        d_gpu.denoise(x[:23999])
+    assert e.value.status == -8                      # InvalidInputLength (NSNet2.zig:166-169)
+    with pytest.raises(fv.FvadError) as e:
+        fv.NSNet2(gpu_ctx, 44100)
+    assert e.value.status == -9
+
+
+# ------------------------------------------------------------------ batched engine vs streaming oracle
+def _oracle_lane(weights, x):
+    p = orc.Pipeline(weights, n_channels=1, keep_denoised=True)
+    p.push(x[None])
+    nf = p.band_volumes().shape[0]
+    bins = np.stack([p.fft_bins(k) for k in range(nf)]) if nf else np.zeros((0, 513), np.float32)
+    return {"rms": p.chunk_rms()[:, 0], "den": p.denoised()[0], "band": p.band_volumes()[:, 0], "bins": bins}
+
+
+def test_engine_ragged_lanes_match_oracle(fv, gpu_ctx, weights7, pkg):
+    # ragged batch: empty lane, sub-chunk lane, 1, 2 and 5 chunks (+ trailing partial chunk)
+    lens = [0, 23999, 24000, 48000 + 777, 5 * 24000 + 12345]
+    lanes = []
+    for i, n in enumerate(lens):
+        pcm, _ = pkg.synth.make_stream(max(n, 1) / 48000.0 + 0.01, seed=100 + i)
+        lanes.append(pcm[0][:n].copy())
+    out = gpu_ctx.engine_run(lanes, want_denoised=True, want_bins=True)
+    for i, (x, o) in enumerate(zip(lanes, out)):
+        n_chunks = len(x) // 24000
+        assert o["n_chunks"] == n_chunks
+        assert o["n_fft_frames"] == (n_chunks * 24000) // 1024
+        assert o["first_frame_index"] == 0
+        if n_chunks == 0:
+            continue
+        ref = _oracle_lane(weights7, x)
+        assert_rel(o["chunk_rms"], ref["rms"], 1e-5, what=f"rms lane {i}")
+        assert_rel(o["denoised"], ref["den"], 1e-4, floor=1e-3 * np.abs(ref["den"]).max(), what=f"denoised lane {i}")
+        assert_rel(o["fft_bins"], ref["bins"], 1e-4, floor=1e-3 * ref["bins"].max(), what=f"|X| lane {i}")
+        assert_rel(o["band_sum"], ref["band"], 1e-4, what=f"band lane {i}")
+
+
+def test_engine_launch_splitting_is_invisible(fv, gpu_ctx, pkg):
+    # chunks of one lane spread over several launches (carry hand-off between launches) must give
+    # bit-identical results to a single launch
+    pcm, _ = pkg.synth.make_stream(7 * 0.5 + 0.1, seed=7)
+    lanes = [pcm[0].copy(), pcm[0][:3 * 24000].copy()]
+    one = gpu_ctx.engine_run(lanes, want_denoised=True)
+    for cap in (1, 2, 3, 128):
+        many = gpu_ctx.engine_run(lanes, want_denoised=True, max_chunks_per_launch=cap)
+        for a, b in zip(one, many):
+            assert np.array_equal(a["denoised"], b["denoised"]), cap
+            assert np.array_equal(a["band_sum"], b["band_sum"]), cap
+            assert np.array_equal(a["chunk_rms"], b["chunk_rms"]), cap
+
+
+def test_engine_streaming_state_equals_one_shot(fv, gpu_ctx, pkg):
+    # a lane fed in three calls through fvad_lane_state == the same audio in one call
+    pcm, _ = pkg.synth.make_stream(6 * 0.5 + 0.2, seed=8)
+    x = pcm[0]
+    whole = gpu_ctx.engine_run([x.copy()], want_denoised=True)[0]
+    st = gpu_ctx.lane_state()
+    parts, pos = [], 0
+    for n_chunks in (1, 3, 2):
+        seg = x[pos: pos + n_chunks * 24000].copy()
+        r = gpu_ctx.engine_run([seg], want_denoised=True, states=[st])[0]
+        assert r["first_frame_index"] == 1024 * sum(len(p["band_sum"]) for p in parts)
+        parts.append(r)
+        pos += n_chunks * 24000
+    fv.lib().fvad_lane_state_destroy(st)
+    assert np.array_equal(np.concatenate([p["denoised"] for p in parts]), whole["denoised"])
+    assert np.array_equal(np.concatenate([p["band_sum"] for p in parts]), whole["band_sum"])
+    assert np.array_equal(np.concatenate([p["chunk_rms"] for p in parts]), whole["chunk_rms"])
+
+
+def test_config3_full_pipeline_82_chunks(fv, gpu_ctx, weights7, pkg):
+    # BASELINE config 3: "batch = 4096 frames" -> 82 chunks = 4100 frames (chunks are 50 frames),
+    # synthetic weights seed 7, as 2 lanes of 41 chunks
+    lanes = []
+    for i in range(2):
+        pcm, _ = pkg.synth.make_stream(41 * 0.5, seed=30 + i)
+        lanes.append(pcm[0][: 41 * 24000].copy())
+    out = gpu_ctx.engine_run(lanes, want_denoised=True)
+    for x, o in zip(lanes, out):
+        ref = _oracle_lane(weights7, x)
+        assert o["n_chunks"] == 41 and o["n_fft_frames"] == (41 * 24000) // 1024
+        assert_rel(o["denoised"], ref["den"], 1e-4, floor=1e-3 * np.abs(ref["den"]).max(), what="cfg3 denoised")
+        assert_rel(o["band_sum"], ref["band"], 1e-4, what="cfg3 band")
+
+
+def test_engine_batch_consistency_at_scale(fv, gpu_ctx, pkg):
+    # size-independent property at 2048 chunks: identical lanes give bit-identical outputs wherever
+    # they sit in the batch, and a time-reversed batch order changes nothing
+    pcm, _ = pkg.synth.make_stream(8.0, seed=9)
+    base = pcm[0][: 16 * 24000].copy()
+    other, _ = pkg.synth.make_stream(8.0, seed=10)
+    lanes = [base if i % 3 else other[0][: 16 * 24000].copy() for i in range(128)]
+    out = gpu_ctx.engine_run(lanes, want_denoised=True)
+    ref_a = next(o for i, o in enumerate(out) if i % 3)
+    ref_b = out[0]
+    for i, o in enumerate(out):
+        r = ref_a if i % 3 else ref_b
+        assert np.array_equal(o["denoised"], r["denoised"]) and np.array_equal(o["band_sum"], r["band_sum"])
+    assert np.all(np.isfinite(ref_a["denoised"]))
+
+
+# ------------------------------------------------------------------ B1: AudioPipeline end to end
+@pytest.mark.parametrize("n_channels,seconds,seed", [(1, 90.0, 40), (2, 60.0, 41)])
+def test_pipeline_segments_bit_identical(fv, gpu_ctx, weights7, pkg, n_channels, seconds, seed):
+    pcm, labels = pkg.synth.make_stream(seconds, seed=seed, n_channels=n_channels)
+    ref = orc.Pipeline(weights7, n_channels=n_channels)
+    ref.push(pcm)
+    p = fv.AudioPipeline(gpu_ctx, n_channels=n_channels, alt_configs=[{}, {"speech_threshold_factor": 5.0}])
+    # pushSamples in uneven pieces (AudioPipeline.zig:118-143): returns the first sample's index
+    pos = 0
+    for step in (48000, 1000, 240000, 7, 10**9):
+        nxt = min(pcm.shape[1], pos + step)
+        assert p.push_samples(pcm[:, pos:nxt]) == pos
+        pos = nxt
+    band, ratio = p.trace()
+    assert band.shape == ref.band_volumes().shape
+    assert_rel(band, ref.band_volumes(), 1e-4, what="band volumes")
+    assert_rel(ratio, ref.frame_vol_ratio(), 1e-5, what="volume ratio")
+    segs, segs_ref = p.segments(), ref.segments()
+    assert len(segs_ref) >= 2, "the synthetic stream must produce speech segments"
+    # bit-exact boundaries; the two f32 by-products are sums of the same f32 terms
+    assert [(s[0], s[1]) for s in segs] == [(s[0], s[1]) for s in segs_ref]
+    for s, r in zip(segs, segs_ref):
+        assert abs(s[2] - r[2]) <= 1e-5 and s[3] == r[3]
+    assert p.segments(alt=0) == segs            # default alt config == main machine
+    thr_margin, ratio_margin, n = p.audit()
+    assert n == band.shape[0]
+    # margin audit: no frame came within the GPU/CPU float difference of flipping a decision
+    assert thr_margin > 1e-3, f"a frame sat {thr_margin:.2e} from the threshold"
+    if n_channels == 1:
+        assert np.all(ratio == 1.0)             # min/max of a single channel
+    # detected segments overlap the burst schedule
+    for a, b in labels[:3]:
+        assert any(s[0] / 48000 <= b and s[1] / 48000 >= a for s in segs)
+
+
+def test_pipeline_errors_and_skip_processing(fv, gpu_ctx):
+    with pytest.raises(fv.FvadError) as e:
+        fv.AudioPipeline(gpu_ctx, sample_rate=44100)
+    assert e.value.status == -9                      # InvalidSampleRate (VADPipeline.zig:55-58)
+    with pytest.raises(fv.FvadError) as e:
+        fv.AudioPipeline(gpu_ctx, fft_size=1023)
+    assert e.value.status == -1
+    p = fv.AudioPipeline(gpu_ctx, skip_processing=True)
+    assert p.push_samples(np.zeros((1, 50000), np.float32)) == 0
+    assert p.push_samples(np.zeros((1, 10), np.float32)) == 50000
+    assert p.segments() == [] and p.trace()[0].shape[0] == 0
+    # digital silence: features are exactly log10(1e-12), nothing is NaN, no segments
+    q = fv.AudioPipeline(gpu_ctx)
+    q.push_samples(np.zeros((1, 24000 * 4), np.float32))
+    band, _ = q.trace()
+    assert band.shape[0] == 93 and np.all(band == 0.0) and q.segments() == []
+
+
+def test_no_model_is_an_error(fv):
+    ctx = fv.Context(0)
+    with pytest.raises(fv.FvadError) as e:
+        ctx.engine_run([np.zeros(24000, np.float32)])
+    assert e.value.status == -103
+    ctx.close()
+
+
+# ------------------------------------------------------------------ committed golden vectors
+def test_golden_vectors(fv, gpu_ctx):
+    g = np.load(os.path.join(GOLD, "golden_seed7.npz"))
+    f = fv.FFT(gpu_ctx, 320, 16000)
+    assert_bins_close(f.fft(g["fft320_x"], g["win320"]), g["fft320_X"], "golden fft320")
+    f2 = fv.FFT(gpu_ctx, 1024, 48000)
+    assert_bins_close(f2.fft(g["fft1024_x"], g["win1024"]), g["fft1024_X"], "golden fft1024")
+    gains = gpu_ctx.nsnet2_forward(g["chunk_features"][None])[0]
+    assert_rel(gains, g["chunk_gains"], 1e-4, floor=1e-2, what="golden gains")
+    out = gpu_ctx.engine_run([g["stream_pcm"]], want_denoised=True)[0]
+    assert_rel(out["denoised"], g["stream_denoised"], 1e-4, floor=1e-3 * np.abs(g["stream_denoised"]).max(), what="golden denoised")
+    assert_rel(out["band_sum"], g["stream_band"], 1e-4, what="golden band")
+    assert_rel(out["chunk_rms"], g["stream_rms"], 1e-5, what="golden rms")

@@ -1,0 +1,368 @@
+"""CPU tests of the product's host side (libfvad_hip.so loads without a GPU): the C ABI exports
+every symbol include/fvad.h declares, the host logic (VAD state machine, rolling averages,
+Evaluator statistics, windows, weight generation, ONNX reader) matches the oracle, GPU entry
+points fail loudly without a device, and the N>1 sharding path runs over gloo with 2 ranks."""
+import ctypes as C
+import os
+import re
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import orc
+from conftest import ROOT
+
+
+def test_abi_exports_every_declared_symbol(fv):
+    hdr = open(os.path.join(ROOT, "include", "fvad.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fvad_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"fvad_recording_cb"}
+    L = fv.lib()
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, f"declared in fvad.h but not exported: {missing}"
+    assert declared == set(fv.SIGNATURES), (declared ^ set(fv.SIGNATURES))
+    assert L.fvad_abi_version() == 1
+    assert L.fvad_status_name(-8) == b"InvalidInputLength"
+
+
+def test_gpu_entry_points_fail_loudly_without_device(fv):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert fv.lib().fvad_ctx_create(0, C.byref(h)) == fv.FVAD_ERR_NO_DEVICE
+    with pytest.raises(fv.FvadError):
+        fv.Context(0)
+
+
+def test_windows_bit_equal_oracle(fv):
+    L = fv.lib()
+    w = np.zeros(320, np.float32)
+    L.fvad_nsnet2_window(fv.fptr(w))
+    assert np.array_equal(w, orc.nsnet2_window())
+    wp = np.zeros(1024, np.float32)
+    L.fvad_hann_window_periodic(fv.fptr(wp), 1024)
+    assert np.array_equal(wp, orc.hann_periodic(1024))
+    ws = np.zeros(77, np.float32)
+    L.fvad_hann_window_symmetric(fv.fptr(ws), 77)
+    assert np.array_equal(ws, orc.hann_symmetric(77))
+    assert L.fvad_window_norm_factor(fv.fptr(wp), 1024) == orc.lib().orc_window_norm_factor(orc.fptr(wp), 1024)
+
+
+def test_synth_weights_deterministic_and_responsive(fv, weights7):
+    again = fv.synth_weights(7)
+    other = fv.synth_weights(8)
+    for k in fv.WEIGHT_NAMES:
+        assert np.array_equal(weights7[k], again[k])
+    assert not np.array_equal(weights7["fc1_w"], other["fc1_w"])
+    assert weights7["gru1_w"].shape == (1200, 400) and weights7["fc4_w"].shape == (161, 600)
+    # the synthetic net must discriminate: gains spread over (0,1), not all ~0.5
+    rng = np.random.default_rng(0)
+    f = rng.uniform(-9, 1, (54, 161)).astype(np.float32)
+    g = orc.nsnet2_forward(weights7, f)
+    assert g.std() > 0.15 and g.min() < 0.2 and g.max() > 0.8
+
+
+def test_rolling_average_bit_exact(fv):
+    L, O = fv.lib(), orc.lib()
+    rng = np.random.default_rng(1)
+    for count, init in ((9, None), (23, None), (8437, 0.005)):
+        h = C.c_void_p()
+        assert L.fvad_ra_create(count, 0 if init is None else 1, init or 0.0, C.byref(h)) == 0
+        o = O.orc_ra_create(count, 0 if init is None else 1, init or 0.0)
+        for _ in range(40 if count > 100 else 3 * count):
+            s = C.c_float(rng.uniform(0, 0.2))
+            assert L.fvad_ra_push(h, s) == O.orc_ra_push(o, s)
+        a, b = C.c_double(), C.c_double()
+        assert L.fvad_ra_last_avg(h, C.byref(a)) == O.orc_ra_last_avg(o, C.byref(b)) == 1
+        assert a.value == b.value
+        L.fvad_ra_destroy(h)
+        O.orc_ra_destroy(o)
+
+
+def _random_band_script(rng, n, C_):
+    """band volumes that open/close the VAD several times, incl. near-threshold stretches"""
+    v = np.full((n, C_), 0.002, np.float32) + rng.uniform(0, 0.002, (n, C_)).astype(np.float32)
+    pos = 60
+    while pos < n - 200:
+        ln = int(rng.integers(3, 400))
+        lvl = rng.choice([0.03, 0.051, 0.2, 1.0])
+        v[pos:pos + ln] += np.float32(lvl) * rng.uniform(0.5, 1.0, (min(ln, n - pos), C_)).astype(np.float32)
+        pos += ln + int(rng.integers(10, 300))
+    ratio = rng.uniform(0.3, 1.0, n).astype(np.float32)
+    return v, ratio
+
+
+def _oracle_vad(band, ratio, overrides=None):
+    O = orc.lib()
+    cfg = orc.VadConfig()
+    O.orc_vad_config_default(C.byref(cfg))
+    for k, val in (overrides or {}).items():
+        setattr(cfg, k, val)
+    v = O.orc_vad_create(C.byref(cfg), 48000, band.shape[1], 1024)
+    ev = []
+    for k in range(band.shape[0]):
+        row = np.ascontiguousarray(band[k])
+        has = 0 if np.isnan(ratio[k]) else 1
+        r = O.orc_vad_run(v, 1024 * k, orc.fptr(row), has, C.c_float(0.0 if not has else ratio[k]))
+        ev.append((r.recording_state, r.sample_number))
+    n = O.orc_vad_n_segments(v)
+    p = O.orc_vad_segments(v)
+    segs = [(p[i].sample_from, p[i].sample_to, p[i].avg_channel_vol_ratio, p[i].vad_met_sec) for i in range(n)]
+    O.orc_vad_destroy(v)
+    return ev, segs
+
+
+@pytest.mark.parametrize("n_channels", [1, 2])
+def test_vad_machine_identical_to_oracle(fv, n_channels):
+    rng = np.random.default_rng(10 + n_channels)
+    band, ratio = _random_band_script(rng, 3000, n_channels)
+    ratio[5] = np.nan  # a null volume_ratio (orelse 0)
+    ev_o, segs_o = _oracle_vad(band, ratio)
+    m = fv.VadMachine(n_channels=n_channels)
+    ev = [m.run(1024 * k, band[k], None if np.isnan(ratio[k]) else float(ratio[k])) for k in range(band.shape[0])]
+    assert ev == ev_o
+    assert m.segments() == segs_o and len(segs_o) >= 3
+    thr_margin, ratio_margin, n = m.audit()
+    assert n == band.shape[0] and thr_margin >= 0 and ratio_margin >= 0
+    # non-default config: no initial long-term average, other time constants
+    ov = {"has_initial_long_term_avg": 0, "long_term_speech_avg_sec": 3.0, "max_speech_gap_sec": 0.5,
+          "min_vad_duration_sec": 0.3, "speech_threshold_factor": 4.0}
+    ev_o, segs_o = _oracle_vad(band, ratio, ov)
+    m2 = fv.VadMachine(n_channels=n_channels, overrides=ov)
+    ev = [m2.run(1024 * k, band[k], None if np.isnan(ratio[k]) else float(ratio[k])) for k in range(band.shape[0])]
+    assert ev == ev_o and m2.segments() == segs_o
+
+
+def test_vad_run_many_bit_identical_to_scalar(fv):
+    # lock-step multi-stream driver (f64 re-sum vectorised across streams) == per-stream runs
+    rng = np.random.default_rng(20)
+    n_streams = 11  # one full group of 8 + a ragged group of 3
+    bands, ratios = [], []
+    for s in range(n_streams):
+        b, r = _random_band_script(rng, 1500 + 37 * s, 1)
+        bands.append(b)
+        ratios.append(r)
+    ms = [fv.VadMachine() for _ in range(n_streams)]
+    fv.vad_run_many(ms, bands, ratios, n_threads=2)
+    for s in range(n_streams):
+        _, segs_o = _oracle_vad(bands[s], ratios[s])
+        assert ms[s].segments() == segs_o
+    # a second call continues from the carried state (rings partially replaced)
+    more = [_random_band_script(rng, 700, 1) for _ in range(n_streams)]
+    fv.vad_run_many(ms, [m[0] for m in more], [m[1] for m in more],
+                    first_index=[1024 * bands[s].shape[0] for s in range(n_streams)], n_threads=3)
+    for s in range(n_streams):
+        _, segs_o = _oracle_vad(np.concatenate([bands[s], more[s][0]]), np.concatenate([ratios[s], more[s][1]]))
+        assert ms[s].segments() == segs_o
+
+
+def test_statistics_match_oracle_and_literals(fv):
+    O = orc.lib()
+    rng = np.random.default_rng(30)
+    cfgd = {"ignore_shorter_than_sec": 0.7, "extrude_start": 5.0, "extrude_end": 10.0, "fill_gaps": 5.0}
+    ocfg = orc.StatConfig(0.7, 5.0, 10.0, 5.0)
+    singles_f, singles_o = [], []
+    for trial in range(20):
+        def segs(n):
+            t = np.sort(rng.uniform(0, 600, 2 * n)).astype(np.float32)
+            out = [(float(t[2 * i]), float(t[2 * i + 1])) for i in range(n)]
+            rng.shuffle(out)  # initAndRun sorts by start
+            return out
+        vad, ref = segs(int(rng.integers(1, 12))), segs(int(rng.integers(1, 12)))
+        s = fv.stats_from_segments(vad, ref, cfgd)
+        ov = (orc.SegSec * len(vad))(*[orc.SegSec(a, b) for a, b in vad])
+        orf = (orc.SegSec * len(ref))(*[orc.SegSec(a, b) for a, b in ref])
+        o = O.orc_stats_from_segments(ov, len(vad), orf, len(ref), C.byref(ocfg))
+        for name, _ in fv.SingleStats._fields_:
+            a, b = getattr(s, name), getattr(o, name)
+            assert a == b or (np.isnan(a) and np.isnan(b)), (trial, name, a, b)
+        singles_f.append(s)
+        singles_o.append(o)
+    agg = fv.stats_aggregate(singles_f)
+    oagg = O.orc_stats_aggregate((orc.SingleStats * 20)(*singles_o), 20)
+    for name in ("total_positives_sec", "true_positives_sec", "false_positives_sec", "false_negatives_sec",
+                 "fm_index", "f_score", "f_score_beta"):
+        assert getattr(agg, name) == getattr(oagg, name)
+    for name in ("true_positive_rate", "false_negative_rate", "false_discovery_rate", "precision"):
+        for f in ("overall", "min", "max", "avg"):
+            assert getattr(getattr(agg, name), f) == getattr(getattr(oagg, name), f)
+    # the reference's own unit cases (statistics.zig:286-360) through the public entry point:
+    # vad [1,6] vs refs [2,3],[4,5] with extrude 2/2 and fill 2 -> FP 0; vad [1,10] -> FP 3
+    lit = {"extrude_start": 2.0, "extrude_end": 2.0, "fill_gaps": 2.0}
+    assert abs(fv.stats_from_segments([(1, 6)], [(2, 3), (4, 5)], lit).false_positives_sec - 0.0) < 1e-3
+    assert abs(fv.stats_from_segments([(1, 10)], [(2, 3), (4, 5)], lit).false_positives_sec - 3.0) < 1e-3
+
+
+def test_segment_to_sec_and_audacity_parse(fv):
+    L = fv.lib()
+    s = fv.SpeechSegment(123456789, 223456789, 0.0, 0.0)
+    r = L.fvad_segment_to_sec(C.byref(s), 48000)
+    assert r.from_sec == np.float32(123456789) / np.float32(48000)  # u64 -> f32, then f32 divide
+    txt = b"1.5000\t2.2500\tspeech\r\n10.0\t12.5\n\nnot a label line\n3\t4\tx\ty\n"
+    out = (fv.SegmentSec * 8)()
+    n = C.c_size_t()
+    assert L.fvad_parse_audacity(txt, len(txt), out, 8, C.byref(n)) == 0
+    assert [(out[i].from_sec, out[i].to_sec) for i in range(n.value)] == [(1.5, 2.25), (10.0, 12.5), (3.0, 4.0)]
+    bad = b"abc\tdef\n"
+    assert L.fvad_parse_audacity(bad, len(bad), out, 8, C.byref(n)) != 0  # parseFloat error
+    from formula_vad_amd import synth
+    lab = [(1.0, 2.5), (7.25, 9.0)]
+    enc = synth.labels_to_audacity(lab).encode()
+    assert L.fvad_parse_audacity(enc, len(enc), out, 8, C.byref(n)) == 0 and n.value == 2
+
+
+# ------------------------------------------------------------------ ONNX reader
+def _varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _ld(field, payload):
+    return _varint((field << 3) | 2) + _varint(len(payload)) + payload
+
+
+def _vi(field, v):
+    return _varint((field << 3) | 0) + _varint(v)
+
+
+def _tensor(name, arr, raw=True):
+    arr = np.ascontiguousarray(arr, np.float32)
+    t = b"".join(_vi(1, d) for d in arr.shape) + _vi(2, 1)
+    if raw:
+        t += _ld(9, arr.tobytes())
+    else:
+        t += _ld(4, arr.tobytes())  # packed float_data
+    return t + _ld(8, name.encode())
+
+
+def _node(op, ins, outs, iattrs=None):
+    n = b"".join(_ld(1, i.encode()) for i in ins) + b"".join(_ld(2, o.encode()) for o in outs) + _ld(4, op.encode())
+    for k, v in (iattrs or {}).items():
+        n += _ld(5, _ld(1, k.encode()) + _vi(3, v) + _vi(20, 2))
+    return n
+
+
+def _make_onnx(wd, gemm=False):
+    """hand-encode the NSNet2-baseline graph (MatMul+Add / GRU with linear_before_reset) as protobuf"""
+    inits, nodes = [], []
+
+    def dense(i, x, y, w, b, act=None):
+        if gemm:
+            inits.append(_tensor(f"w{i}", wd[w]))            # [out][in], transB=1
+            inits.append(_tensor(f"b{i}", wd[b], raw=False))
+            nodes.append(_node("Gemm", [x, f"w{i}", f"b{i}"], [f"d{i}"], {"transB": 1}))
+        else:
+            inits.append(_tensor(f"w{i}", wd[w].T))          # MatMul B operand is [in][out]
+            inits.append(_tensor(f"b{i}", wd[b]))
+            nodes.append(_node("MatMul", [x, f"w{i}"], [f"m{i}"]))
+            nodes.append(_node("Add", [f"b{i}", f"m{i}"], [f"d{i}"]))
+        if act:
+            nodes.append(_node(act, [f"d{i}"], [y]))
+        return y if act else f"d{i}"
+
+    x = dense(1, "input", None, "fc1_w", "fc1_b")
+    nodes.append(_node("Transpose", [x], ["t0"]))
+    cur = "t0"
+    for g in (1, 2):
+        inits.append(_tensor(f"W{g}", wd[f"gru{g}_w"][None]))
+        inits.append(_tensor(f"R{g}", wd[f"gru{g}_r"][None]))
+        inits.append(_tensor(f"B{g}", wd[f"gru{g}_b"][None]))
+        nodes.append(_node("GRU", [cur, f"W{g}", f"R{g}", f"B{g}"], [f"y{g}", f"h{g}"],
+                           {"hidden_size": 400, "linear_before_reset": 1}))
+        nodes.append(_node("Squeeze", [f"y{g}"], [f"s{g}"]))
+        cur = f"s{g}"
+    nodes.append(_node("Transpose", [cur], ["t1"]))
+    x = dense(2, "t1", "r2", "fc2_w", "fc2_b", "Relu")
+    x = dense(3, x, "r3", "fc3_w", "fc3_b", "Relu")
+    dense(4, x, "output", "fc4_w", "fc4_b", "Sigmoid")
+    graph = b"".join(_ld(1, n) for n in nodes) + _ld(2, b"nsnet2") + b"".join(_ld(5, t) for t in inits)
+    return _vi(1, 7) + _ld(2, b"pytorch") + _ld(7, graph)
+
+
+@pytest.mark.parametrize("gemm", [False, True])
+def test_onnx_reader_roundtrip(fv, weights7, tmp_path, gemm):
+    path = tmp_path / "nsnet2-20ms-baseline.onnx"
+    path.write_bytes(_make_onnx(weights7, gemm))
+    got = fv.read_onnx(str(path))
+    for k in fv.WEIGHT_NAMES:
+        assert np.array_equal(got[k], weights7[k]), k
+
+
+def test_onnx_reader_errors(fv, weights7, tmp_path):
+    L = fv.lib()
+    w, owner = fv.Weights(), C.c_void_p()
+    assert L.fvad_onnx_read_nsnet2(str(tmp_path / "missing.onnx").encode(), C.byref(w), C.byref(owner)) == -105
+    p = tmp_path / "garbage.onnx"
+    p.write_bytes(b"\x00\x01\x02not a protobuf")
+    assert L.fvad_onnx_read_nsnet2(str(p).encode(), C.byref(w), C.byref(owner)) == -104
+    blob = _make_onnx(weights7)
+    p2 = tmp_path / "trunc.onnx"
+    p2.write_bytes(blob[: len(blob) // 2])
+    assert L.fvad_onnx_read_nsnet2(str(p2).encode(), C.byref(w), C.byref(owner)) == -104
+
+
+# ------------------------------------------------------------------ sharding (N > 1 path)
+def test_round_robin_partition(pkg):
+    sh = pkg.shard
+    parts = [sh.streams_for_rank(21, r, 8) for r in range(8)]
+    assert [len(p) for p in parts] == [3, 3, 3, 3, 3, 2, 2, 2]
+    assert sorted(sum(parts, [])) == list(range(21))
+
+
+_WORKER = r"""
+import os, sys, numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_package
+pkg = load_package()
+import torch.distributed as dist
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{PORT}", rank=RANK, world_size=2)
+n_streams = 5
+ids = pkg.shard.streams_for_rank(n_streams, RANK, 2)
+stats = [np.arange(11, dtype=np.float32) + 100 * i for i in ids]
+allst = pkg.shard.gather_stats(ids, stats, n_streams, dist=dist)
+assert allst.shape == (5, 11)
+for i in range(n_streams):
+    assert np.array_equal(allst[i], np.arange(11, dtype=np.float32) + 100 * i), (RANK, i)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", RANK, "ok")
+"""
+
+
+def test_gather_stats_two_ranks_gloo(tmp_path):
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(2):
+        code = f"ROOT={ROOT!r}\nPORT={port}\nRANK={rank}\n" + _WORKER
+        procs.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for rank, p in enumerate(procs):
+        out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, out.decode()
+        assert f"rank {rank} ok" in out.decode()
+
+
+def test_golden_vad_stream_segments(fv):
+    # committed band volumes of a 120 s synthetic stream -> the exact segment list
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_vad_seed40.npz"))
+    m = fv.VadMachine()
+    for k in range(g["band"].shape[0]):
+        m.run(1024 * k, g["band"][k], float(g["ratio"][k]))
+    segs = m.segments()
+    assert [(s[0], s[1]) for s in segs] == [tuple(int(v) for v in r) for r in g["segments"]]
+    assert np.array_equal(np.array([s[2] for s in segs], np.float32), g["seg_ratio"])
+    assert np.array_equal(np.array([s[3] for s in segs], np.float32), g["seg_met"])
+    assert len(segs) == 9
