@@ -145,6 +145,7 @@ SIGNATURES = {
     "fvad_last_error": (C.c_char_p, [vp]),
     "fvad_ctx_synchronize": (C.c_int, [vp]),
     "fvad_ctx_stream": (vp, [vp]),
+    "fvad_ctx_copy_to_host": (C.c_int, [vp, vp, vp, sz]),
     "fvad_load_nsnet2_onnx": (C.c_int, [vp, C.c_char_p]),
     "fvad_load_nsnet2_weights": (C.c_int, [vp, C.POINTER(Weights)]),
     "fvad_load_nsnet2_synth": (C.c_int, [vp, C.c_uint64]),

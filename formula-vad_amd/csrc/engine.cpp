@@ -383,6 +383,13 @@ int fvad_ctx_synchronize(fvad_ctx* ctx)
 }
 void* fvad_ctx_stream(fvad_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+int fvad_ctx_copy_to_host(fvad_ctx* ctx, void* dst_host, const void* src_device, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst_host || !src_device))) return FVAD_ERR_INVALID_ARGUMENT;
+    if (bytes) FVAD_HIP(ctx, hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return FVAD_OK;
+}
+
 int fvad_ctx_enable_timing(fvad_ctx* ctx, int on)
 {
     if (!ctx) return FVAD_ERR_INVALID_ARGUMENT;

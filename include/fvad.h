@@ -78,6 +78,9 @@ const char *fvad_last_error(const fvad_ctx *ctx);
 int fvad_ctx_synchronize(fvad_ctx *ctx);
 /* The context's hipStream_t as an opaque pointer, so a caller can time it with HIP events. */
 void *fvad_ctx_stream(fvad_ctx *ctx);
+/* hipMemcpyAsync(device -> host) on the context's stream: ordered after everything queued so
+ * far; the bytes are valid after fvad_ctx_synchronize. */
+int fvad_ctx_copy_to_host(fvad_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
 
 /* ------------------------------------------------------------------ NSNet2 model
  * Replaces onnx.OnnxInstance.init(allocator, .{ .model_path = ... }) (NSNet2.zig:53-61): the
