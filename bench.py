@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--lanes", type=int, default=128, help="streams per GPU per step")
+    ap.add_argument("--lanes", type=int, default=256, help="streams per GPU per step")
     ap.add_argument("--seconds", type=int, default=64, help="audio seconds per stream per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-2 / config-3 side measurements")

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "internal.h"
@@ -68,12 +69,45 @@ int upload_model(fvad_ctx* ctx)
     pack_gru_r(w.gru1_r.data(), H, f);
     if ((rc = upload(ctx, m.r1, f))) return rc;
     if ((rc = upload(ctx, m.br1, std::vector<float>(w.gru1_b.begin() + 3 * H, w.gru1_b.end())))) return rc;
+    pack_gru_r2(w.gru1_r.data(), H, f);
+    if ((rc = upload(ctx, m.r1v2, f))) return rc;
     pack_panel(w.gru2_w.data(), 1200, 400, 3, 25, 25, f);
     if ((rc = upload(ctx, m.gi2_w, f))) return rc;
     if ((rc = upload(ctx, m.gi2_b, std::vector<float>(w.gru2_b.begin(), w.gru2_b.begin() + 3 * H)))) return rc;
     pack_gru_r(w.gru2_r.data(), H, f);
     if ((rc = upload(ctx, m.r2, f))) return rc;
     if ((rc = upload(ctx, m.br2, std::vector<float>(w.gru2_b.begin() + 3 * H, w.gru2_b.end())))) return rc;
+    pack_gru_r2(w.gru2_r.data(), H, f);
+    if ((rc = upload(ctx, m.r2v2, f))) return rc;
+    // large-batch layouts: 1200 = 5 column blocks of 15 tiles
+    pack_panel(w.gru1_w.data(), 1200, 400, 5, 15, 25, f);
+    if ((rc = upload(ctx, m.gi1v2_w, f))) return rc;
+    pack_panel(w.gru2_w.data(), 1200, 400, 5, 15, 25, f);
+    if ((rc = upload(ctx, m.gi2v2_w, f))) return rc;
+    {
+        // fc1 has no activation (x = fc1(x); x, _ = rnn1(x)), so fc1 followed by GRU1's input
+        // projection is one linear map 161 -> 1200: W' = W_ih W_fc1, b' = W_ih b_fc1 + Wb.  Folded
+        // once on the host in double and rounded to f32: algebraically exact, differs from the
+        // two-GEMM form only by round-off (~1e-7 rel), and removes 12 % of the network's FLOPs.
+        std::vector<float> wf((size_t)1200 * 161), bf(1200);
+        std::vector<double> row(161);
+        for (int o = 0; o < 1200; ++o) {
+            std::fill(row.begin(), row.end(), 0.0);
+            double b = (double)w.gru1_b[o];
+            const float* wi = w.gru1_w.data() + (size_t)o * 400;
+            for (int j = 0; j < 400; ++j) {
+                const double a = (double)wi[j];
+                const float* f1 = w.fc1_w.data() + (size_t)j * 161;
+                for (int k = 0; k < 161; ++k) row[k] += a * (double)f1[k];
+                b += a * (double)w.fc1_b[j];
+            }
+            for (int k = 0; k < 161; ++k) wf[(size_t)o * 161 + k] = (float)row[k];
+            bf[o] = (float)b;
+        }
+        pack_panel(wf.data(), 1200, 161, 5, 15, 11, f);
+        if ((rc = upload(ctx, m.gi1f_w, f))) return rc;
+        if ((rc = upload(ctx, m.gi1f_b, bf))) return rc;
+    }
     // fc2: 400 -> 600 (N padded to 608 = 2 blocks of 19 tiles)
     pack_panel(w.fc2_w.data(), 600, 400, 2, 19, 25, f);
     if ((rc = upload(ctx, m.fc2_w, f))) return rc;
@@ -145,14 +179,20 @@ void time_end(fvad_ctx* ctx)
     hipEventRecord(ctx->times.back().e1, ctx->stream);
 }
 
-static int gru_waves_for(long n_pad)
+// Large batches: the LDS-DMA kernel with 128 (or 64) sequences per workgroup; small batches keep
+// one wavefront (16 sequences) per workgroup so that more CUs take part.
+static int launch_gru(fvad_ctx* ctx, const float* gi, const DevBuf& r_v1, const DevBuf& r_v2, const float* bR,
+                      float* hout, long n_pad, int T)
 {
-    // most chunks per workgroup that still leaves >= 256 workgroups (one per CU); R is streamed
-    // from L2 once per workgroup per step, so wider workgroups amortise it over more chunks
-    if (n_pad / 128 >= 256) return 8;
-    if (n_pad / 64 >= 256) return 4;
-    if (n_pad / 64 >= 64) return 4;
-    return 1;
+    const char* force = getenv("FVAD_GRU_KERNEL"); // tuning aid: "v1w4", "v2w8", ...
+    if (force) {
+        const int w = atoi(force + 3);
+        if (force[1] == '2') return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, w, ctx->stream);
+        return fvad_launch_gru_rec(gi, r_v1.p, bR, hout, n_pad, T, w, ctx->stream);
+    }
+    if (n_pad / 128 >= 256) return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, 8, ctx->stream);
+    if (n_pad / 64 >= 64) return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, 4, ctx->stream);
+    return fvad_launch_gru_rec(gi, r_v1.p, bR, hout, n_pad, T, 1, ctx->stream);
 }
 
 int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
@@ -164,21 +204,58 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     const long rows = n_pad * T;
     const long rows_out = n_pad * (T - skip);
     int rc = 0;
+    const char* force = getenv("FVAD_GEMM_KERNEL"); // tuning aid: "v1" / "v2" / "v2nofold"
+    const bool big = force ? force[1] == '2' : (n_pad >= 2048);
+    if (big && rows % 256 == 0 && rows_out % 256 == 0) {
+        const bool fold = !(force && strstr(force, "nofold"));
+        if (fold) {
+            time_begin(ctx, "gru1_in_gemm_fc1folded");
+            rc |= fvad_launch_panel_gemm2(ws.feat, kFeatStride, m.gi1f_w.p, m.gi1f_b.p, ws.gi, 1200, rows, 15, 5, 11, FVAD_ACT_NONE, 75, 0, 0, st);
+            time_end(ctx);
+        } else {
+            time_begin(ctx, "fc1_gemm");
+            rc |= fvad_launch_panel_gemm(ws.feat, kFeatStride, m.fc1_w.p, m.fc1_b.p, ws.a1, 400, rows, 25, 1, 11, FVAD_ACT_NONE, 0, 0, st);
+            time_end(ctx);
+            time_begin(ctx, "gru1_in_gemm");
+            rc |= fvad_launch_panel_gemm2(ws.a1, 400, m.gi1v2_w.p, m.gi1_b.p, ws.gi, 1200, rows, 15, 5, 25, FVAD_ACT_NONE, 75, 0, 0, st);
+            time_end(ctx);
+        }
+        time_begin(ctx, "gru1_rec");
+        rc |= launch_gru(ctx, ws.gi, m.r1, m.r1v2, m.br1.p, ws.h1, n_pad, T);
+        time_end(ctx);
+        time_begin(ctx, "gru2_in_gemm");
+        rc |= fvad_launch_panel_gemm2(ws.h1, 400, m.gi2v2_w.p, m.gi2_b.p, ws.gi, 1200, rows, 15, 5, 25, FVAD_ACT_NONE, 75, 0, 0, st);
+        time_end(ctx);
+        time_begin(ctx, "gru2_rec");
+        rc |= launch_gru(ctx, ws.gi, m.r2, m.r2v2, m.br2.p, ws.h2, n_pad, T);
+        time_end(ctx);
+        time_begin(ctx, "fc2_gemm");
+        rc |= fvad_launch_panel_gemm2(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, 38, skip ? T : 0, skip, st);
+        time_end(ctx);
+        time_begin(ctx, "fc3_gemm");
+        rc |= fvad_launch_panel_gemm2(ws.f2, 608, m.fc3_w.p, m.fc3_b.p, ws.f3, 608, rows_out, 19, 2, 38, FVAD_ACT_RELU, 38, 0, 0, st);
+        time_end(ctx);
+        time_begin(ctx, "fc4_gemm");
+        rc |= fvad_launch_panel_gemm2(ws.f3, 608, m.fc4_w.p, m.fc4_b.p, ws.gains, kFeatStride, rows_out, 11, 1, 38, FVAD_ACT_SIGMOID, 11, 0, 0, st);
+        time_end(ctx);
+        if (rc) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "no kernel instance for this layer shape");
+        FVAD_HIP(ctx, hipGetLastError());
+        return FVAD_OK;
+    }
     time_begin(ctx, "fc1_gemm");
     rc |= fvad_launch_panel_gemm(ws.feat, kFeatStride, m.fc1_w.p, m.fc1_b.p, ws.a1, 400, rows, 25, 1, 11, FVAD_ACT_NONE, 0, 0, st);
     time_end(ctx);
     time_begin(ctx, "gru1_in_gemm");
     rc |= fvad_launch_panel_gemm(ws.a1, 400, m.gi1_w.p, m.gi1_b.p, ws.gi, 1200, rows, 25, 3, 25, FVAD_ACT_NONE, 0, 0, st);
     time_end(ctx);
-    const int waves = gru_waves_for(n_pad);
     time_begin(ctx, "gru1_rec");
-    rc |= fvad_launch_gru_rec(ws.gi, m.r1.p, m.br1.p, ws.h1, n_pad, T, waves, st);
+    rc |= launch_gru(ctx, ws.gi, m.r1, m.r1v2, m.br1.p, ws.h1, n_pad, T);
     time_end(ctx);
     time_begin(ctx, "gru2_in_gemm");
     rc |= fvad_launch_panel_gemm(ws.h1, 400, m.gi2_w.p, m.gi2_b.p, ws.gi, 1200, rows, 25, 3, 25, FVAD_ACT_NONE, 0, 0, st);
     time_end(ctx);
     time_begin(ctx, "gru2_rec");
-    rc |= fvad_launch_gru_rec(ws.gi, m.r2.p, m.br2.p, ws.h2, n_pad, T, waves, st);
+    rc |= launch_gru(ctx, ws.gi, m.r2, m.r2v2, m.br2.p, ws.h2, n_pad, T);
     time_end(ctx);
     time_begin(ctx, "fc2_gemm");
     rc |= fvad_launch_panel_gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, skip ? T : 0, skip, st);
@@ -197,7 +274,7 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
 // K1 -> NSNet2 -> K3 over every chunk of every job, in launches of <= max_chunks chunks.
 int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks)
 {
-    if (max_chunks <= 0) max_chunks = 16384;
+    if (max_chunks <= 0) max_chunks = 32768;
     long total = 0;
     for (auto& j : jobs) total += (long)j.n_chunks;
     if (total == 0) return FVAD_OK;
@@ -365,7 +442,7 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     if (ws.carries) hipFree(ws.carries);
     DeviceModel& m = ctx->dm;
     DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.gi1_w, &m.gi1_b, &m.r1, &m.br1, &m.gi2_w, &m.gi2_b, &m.r2, &m.br2,
-                      &m.fc2_w, &m.fc2_b, &m.fc3_w, &m.fc3_b, &m.fc4_w, &m.fc4_b};
+                      &m.fc2_w, &m.fc2_b, &m.fc3_w, &m.fc3_b, &m.fc4_w, &m.fc4_b, &m.r1v2, &m.r2v2, &m.gi1f_w, &m.gi1f_b, &m.gi1v2_w, &m.gi2v2_w};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (ctx->d_tables) hipFree(ctx->d_tables);
     for (auto& kt : ctx->times) { hipEventDestroy(kt.e0); hipEventDestroy(kt.e1); }

@@ -208,6 +208,22 @@ void pack_gru_r(const float* R, int H, std::vector<float>& out)
                         }
 }
 
+// v2 layout: one contiguous 75 KB slab per unit tile: [J][g][S][64][4]
+void pack_gru_r2(const float* R, int H, std::vector<float>& out)
+{
+    const int J = H / 16;
+    out.assign((size_t)J * 3 * J * 256, 0.0f);
+    for (int j = 0; j < J; ++j)
+        for (int g = 0; g < 3; ++g)
+            for (int s = 0; s < J; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = g * H + 16 * j + (lane & 15);
+                        const int k = 16 * s + 4 * (lane >> 4) + r;
+                        out[(((size_t)j * 3 + g) * J + s) * 256 + lane * 4 + r] = R[(size_t)n * H + k];
+                    }
+}
+
 // ------------------------------------------------------------------ ONNX (protobuf) reader
 // Wire format only: varint, 64-bit, length-delimited, 32-bit.  Message/field numbers from
 // onnx.proto3: ModelProto.graph = 7; GraphProto.node = 1, .initializer = 5; NodeProto.input = 1,
