@@ -43,8 +43,8 @@ NSNET2_FLOP_PER_CHUNK = 2 * (54 * (161 * 400 + 2 * 1200 * 400) + 53 * 2 * 1200 *
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--lanes", type=int, default=256, help="streams per GPU per step")
     ap.add_argument("--seconds", type=int, default=64, help="audio seconds per stream per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -140,9 +140,11 @@ def main():
     vad_threads = args.vad_threads or min(lanes, 16, max(1, (os.cpu_count() or 2) - 1))
 
     results = {}
+    host_ms = []
 
     def host_stage(step, slot):
         """band sums + chunk RMS -> per-frame volume ratio -> VAD state machine -> segments"""
+        t_h0 = time.perf_counter()
         band = h_band[slot]
         rms = h_rms[slot]
         # mono: ratio = min/max of one channel = 1 (0 for digital silence), BufferedVolumeAnalyzer.zig:48-69
@@ -157,10 +159,13 @@ def main():
             r0, r1 = ratio_chunk[lane][frame_chunk], ratio_chunk[lane][frame_chunk_end]
             ratios.append(((r0 * w0 + np.where(w1 > 0, r1 * w1, np.float32(0))) / (w0 + w1)).astype(np.float32))
         ms = [fv.VadMachine() for _ in range(lanes)]
+        t_h1 = time.perf_counter()
         fv.vad_run_many(ms, [band[lane][:, None] for lane in range(lanes)], ratios, n_threads=vad_threads)
+        t_h2 = time.perf_counter()
         results[step] = [m.segments() for m in ms]
         for m in ms:
             m.close()
+        host_ms.append(((t_h1 - t_h0) * 1e3, (t_h2 - t_h1) * 1e3, (time.perf_counter() - t_h2) * 1e3))
 
     def gpu_stage(slot):
         rc = L.fvad_engine_enqueue_device(ctx.h, d_pcm.data_ptr(), lanes, d_pcm.stride(0), seconds * 48000,
@@ -171,14 +176,21 @@ def main():
         fv.check(L.fvad_ctx_copy_to_host(ctx.h, h_rms[slot].ctypes.data, d_rms[slot].data_ptr(), h_rms[slot].nbytes),
                  "copy rms", ctx.h)
 
+    gpu_wall_ms = []
+    join_ms = []
+
     def run_steps(k, tag):
         worker = None
         for i in range(k):
             slot = i & 1
+            t_g = time.perf_counter()
             gpu_stage(slot)
             ctx.synchronize()                    # band sums of step i are on the host
+            gpu_wall_ms.append((time.perf_counter() - t_g) * 1e3)
+            t_j = time.perf_counter()
             if worker is not None:
                 worker.join()                    # host stage of step i-1 (overlapped the GPU stage of i)
+            join_ms.append((time.perf_counter() - t_j) * 1e3)
             worker = threading.Thread(target=host_stage, args=((tag, i), slot))
             worker.start()
         if worker is not None:
@@ -270,6 +282,12 @@ def main():
             "aggregate": {"ms": agg_ms, "n_streams": lanes * world, "tpr": agg.true_positive_rate.overall,
                           "ppv": agg.precision.overall, "collective": "all_gather(nccl)" if world > 1 else "none"},
             "host_vad_threads": vad_threads,
+            "gpu_stage_wall_ms": float(np.mean(gpu_wall_ms[args.warmup:])),
+            "kernel_ms_sum": float(sum(ktimes.values()) / args.steps),
+            "join_wait_ms": [round(j, 1) for j in join_ms],
+            "host_stage_ms": {"prepare": float(np.mean([h[0] for h in host_ms])),
+                              "vad_run_many": float(np.mean([h[1] for h in host_ms])),
+                              "collect": float(np.mean([h[2] for h in host_ms]))},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, fv, weights, min(os.cpu_count() or 1, 16))

@@ -24,6 +24,7 @@ RollingAverage::RollingAverage(size_t count, bool has_initial, double initial_va
         std::fill(data.begin(), data.begin() + (long)count, initial_val);
         written_count = count;
         avg();
+        if (count) enter_steady();
     }
 }
 
@@ -38,12 +39,45 @@ double RollingAverage::avg() // RollingAverage.zig:45-56
     return a;
 }
 
+// The reference re-sums the whole ring on every push (RollingAverage.zig:45-56): a chain of `len`
+// dependent f64 adds.  Once the ring is full the terms below the write index have not changed since
+// the previous push, so the running sum up to (not including) the write index -- `pref` -- is still
+// exactly what the reference's loop would have in its accumulator at that point.  Resuming the
+// chain from there performs the very same additions in the very same order for the remaining
+// terms: bit-identical result, half the work on average.
 double RollingAverage::push(float sample) // RollingAverage.zig:34-43
 {
+    if (steady) {
+        const size_t w = write_idx;
+        data[w] = (double)sample;
+        q[w] = data[w] * scalar;
+        double acc = (w == 0) ? 0.0 : pref;
+        acc += q[w];
+        const double new_pref = acc;
+        const double* qq = q.data();
+        for (size_t i = w + 1; i < len; ++i) acc += qq[i];
+        last_avg = acc;
+        has_last_avg = true;
+        write_idx = (w + 1) % len;
+        pref = (write_idx == 0) ? 0.0 : new_pref;
+        return acc;
+    }
     data[write_idx] = (double)sample;
     write_idx = (write_idx + 1) % len;
     if (written_count < len) written_count += 1;
-    return avg();
+    const double a = avg();
+    if (written_count == len && write_idx == 0) enter_steady();
+    return a;
+}
+
+void RollingAverage::enter_steady()
+{
+    scalar = 1.0 / (double)len;
+    q.resize(len);
+    for (size_t i = 0; i < len; ++i) q[i] = data[i] * scalar;
+    pref = 0.0;
+    for (size_t i = 0; i < write_idx; ++i) pref += q[i]; // same chain the full loop would run
+    steady = true;
 }
 
 // ------------------------------------------------------------------ VADMetadata
@@ -235,26 +269,30 @@ fvad_vad_result VadMachine::run(uint64_t index, const float* channel_volumes, bo
 // structure-of-arrays copy of their rings: data[i][lane].  Every lane still adds its own terms in
 // index order, so each stream's result is bit-identical to VadMachine::run.
 namespace {
-constexpr int LANES = 8;
+// 16 streams per group: the ring contents are kept as the f32 values that were pushed
+// (data[i] is always an exact f32, RollingAverage.zig:35), structure-of-arrays [len][16] = 540 KB,
+// which stays L2-resident; each row is widened, multiplied by 1/len and added to 16 independent
+// f64 accumulators -- four AVX2 (two AVX-512) dependent chains, enough to cover the add latency.
+constexpr int LANES = 16;
 
 struct Group {
-    std::vector<VadMachine*> m;            // <= LANES machines with identical ring length
-    std::vector<double> soa;               // [len][LANES]
+    std::vector<VadMachine*> m;            // <= LANES machines with identical, full long-term rings
+    std::vector<float> soa;                // [len][LANES]
     size_t len = 0;
 };
 
-void group_resum(Group& g, const bool* pushed, double* out)
+// avg_l = sum_i data_l[i] * scalar, i ascending, for every lane at once: per lane exactly the
+// reference's loop (RollingAverage.zig:45-56: mul, then add, no contraction).
+__attribute__((target_clones("avx512f", "avx2", "default")))
+void group_resum(const float* d, size_t len, double scalar, double* out)
 {
-    // all lanes have written_count == len once initialised with a value (the reference default);
-    // lanes that are still filling fall back to the scalar path in the caller.
-    double acc[LANES] = {0};
-    const double scalar = 1.0 / (double)g.len;
-    const double* d = g.soa.data();
-    for (size_t i = 0; i < g.len; ++i) {
-#pragma omp simd
-        for (int l = 0; l < LANES; ++l) acc[l] += d[i * LANES + l] * scalar;
+    double acc[LANES];
+    for (int l = 0; l < LANES; ++l) acc[l] = 0.0;
+    for (size_t i = 0; i < len; ++i) {
+        const float* row = d + i * LANES;
+        for (int l = 0; l < LANES; ++l) acc[l] += (double)row[l] * scalar;
     }
-    for (int l = 0; l < LANES; ++l) if (pushed[l]) out[l] = acc[l];
+    for (int l = 0; l < LANES; ++l) out[l] = acc[l];
 }
 } // namespace
 
@@ -272,7 +310,7 @@ void run_many(VadMachine* const* vads, size_t n_streams, const float* const* ban
         for (size_t i = 0; i < n_streams; ++i) {
             if (used[i]) continue;
             used[i] = true;
-            const RollingAverage& a = vads[i]->long_term;
+            RollingAverage& a = vads[i]->long_term;
             if (a.written_count != a.len) { scalar_streams.push_back(i); continue; }
             std::vector<size_t> idx{i};
             for (size_t j = i + 1; j < n_streams && idx.size() < (size_t)LANES; ++j) {
@@ -282,10 +320,12 @@ void run_many(VadMachine* const* vads, size_t n_streams, const float* const* ban
             if (idx.size() < 2) { scalar_streams.push_back(i); continue; }
             Group g;
             g.len = a.len;
-            g.soa.assign(g.len * LANES, 0.0);
+            g.soa.assign(g.len * LANES, 0.0f);
             for (size_t l = 0; l < idx.size(); ++l) {
+                RollingAverage& ra = vads[idx[l]]->long_term;
                 g.m.push_back(vads[idx[l]]);
-                for (size_t k = 0; k < g.len; ++k) g.soa[k * LANES + l] = vads[idx[l]]->long_term.data[k];
+                for (size_t k = 0; k < g.len; ++k) g.soa[k * LANES + l] = (float)ra.data[k];
+                ra.steady = false; // q / pref are rebuilt when the group is done
             }
             groups.push_back(std::move(g));
             group_sid.push_back(idx);
@@ -297,6 +337,7 @@ void run_many(VadMachine* const* vads, size_t n_streams, const float* const* ban
         const size_t L = g.m.size();
         size_t sid[LANES]; size_t nf[LANES]; size_t max_f = 0;
         for (size_t l = 0; l < L; ++l) { sid[l] = group_sid[gi][l]; nf[l] = n_frames[sid[l]]; max_f = std::max(max_f, nf[l]); }
+        const double scalar = 1.0 / (double)g.len;
         for (size_t k = 0; k < max_f; ++k) {
             bool pushed[LANES] = {false};
             bool met[LANES] = {false};
@@ -316,7 +357,7 @@ void run_many(VadMachine* const* vads, size_t n_streams, const float* const* ban
                     // RollingAverage.push without the re-sum (done for the whole group below)
                     RollingAverage& ra = m->long_term;
                     ra.data[ra.write_idx] = (double)mv[l];
-                    g.soa[ra.write_idx * LANES + l] = (double)mv[l];
+                    g.soa[ra.write_idx * LANES + l] = mv[l];
                     ra.write_idx = (ra.write_idx + 1) % ra.len;
                     pushed[l] = true;
                     any = true;
@@ -324,8 +365,9 @@ void run_many(VadMachine* const* vads, size_t n_streams, const float* const* ban
             }
             if (any) {
                 double out[LANES];
-                group_resum(g, pushed, out);
-                for (size_t l = 0; l < L; ++l) if (pushed[l]) { g.m[l]->long_term.last_avg = out[l]; g.m[l]->long_term.has_last_avg = true; }
+                group_resum(g.soa.data(), g.len, scalar, out);
+                for (size_t l = 0; l < L; ++l)
+                    if (pushed[l]) { g.m[l]->long_term.last_avg = out[l]; g.m[l]->long_term.has_last_avg = true; }
             }
             for (size_t l = 0; l < L; ++l) {
                 if (k >= nf[l]) continue;
@@ -335,6 +377,7 @@ void run_many(VadMachine* const* vads, size_t n_streams, const float* const* ban
                 g.m[l]->finish_step(first_index[s] + (uint64_t)k * fft_size, met[l], has_ratio, r);
             }
         }
+        for (size_t l = 0; l < L; ++l) g.m[l]->long_term.enter_steady();
     };
     auto run_scalar = [&](size_t s) {
         VadMachine* m = vads[s];

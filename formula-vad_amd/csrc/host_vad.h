@@ -16,9 +16,14 @@ struct RollingAverage {            // src/structures/RollingAverage.zig
     double last_avg = 0;
     size_t write_idx = 0;
     size_t written_count = 0;
+    // steady state (ring full): products data[i] * (1/len) and the running sum below write_idx
+    bool steady = false;
+    double scalar = 0, pref = 0;
+    std::vector<double> q;
     RollingAverage(size_t count, bool has_initial, double initial_val);
     double push(float sample);
     double avg();
+    void enter_steady();
 };
 
 struct MetaResult {                // VADMetadata.Result, VADMetadata.zig:5-9 (optionals)
