@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-2 / config-3 side measurements")
     ap.add_argument("--vad-threads", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="nccl (= RCCL; one rank per GPU) or gloo (rehearsal: every rank on cuda:0)")
     return ap.parse_args()
 
 
@@ -105,6 +107,23 @@ def cpu_baseline(pkg, fv, weights, n_threads):
                       f"(oracle/, -O3 -march=native), one thread per stream; {dt:.1f} s wall"}
 
 
+def pmc_traffic(chunks_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_summary.json; counters cannot be read from inside the benchmark), or None when
+    the profile was taken at a different launch size."""
+    try:
+        files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
+        d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
+        if d["chunks_per_launch"] != min(chunks_per_launch, 32768):
+            return None
+        for k, v in d["kernels"].items():
+            if k.startswith("gru_rec2_kernel"):
+                return v["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -112,10 +131,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
+    rehearsal = args.dist_backend == "gloo"
+    if rehearsal:
+        local_rank = 0                       # several ranks share the one GPU of a rehearsal box
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    cdev = torch.device("cpu") if rehearsal else dev  # where the tiny collectives' tensors live
 
     pkg = load_package()
     fv = pkg.binding
@@ -231,11 +257,11 @@ def main():
         local_stats.append(fv.single_stats_to_array(fv.stats_from_segments(segs, labels[lane], stat_cfg)))
     ta = time.perf_counter()
     allst = pkg.shard.gather_stats(local_ids, local_stats, lanes * world, dist=dist if world > 1 else None,
-                                   device=dev if world > 1 else None)
+                                   device=cdev if world > 1 else None)
     agg = fv.stats_aggregate([fv.array_to_single_stats(a) for a in allst])
     agg_ms = (time.perf_counter() - ta) * 1e3
 
-    t = torch.tensor([elapsed, dev_elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, dev_elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, dev_elapsed = float(t[0]), float(t[1])
@@ -272,7 +298,7 @@ def main():
             "device_only_frames_per_s": total_frames / dev_elapsed,
             "roofline": {"bound": "mfma", "kernel": "gru_rec_kernel (fp32 v_mfma_f32_16x16x4_f32)",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(lanes * n_chunks),
                          "launch_ms": gru_ms, "flop_per_launch": gru_flop},
             "roofline_pipeline": {
                 "nsnet2_tflops": lanes * n_chunks * NSNET2_FLOP_PER_CHUNK / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
@@ -280,7 +306,7 @@ def main():
                 "hbm_frac_of_8TBps": frames_per_step * 3840 / (dev_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS if dev_ms_step else 0.0},
             "kernel_ms_per_step": {k: v / args.steps for k, v in ktimes.items()},
             "aggregate": {"ms": agg_ms, "n_streams": lanes * world, "tpr": agg.true_positive_rate.overall,
-                          "ppv": agg.precision.overall, "collective": "all_gather(nccl)" if world > 1 else "none"},
+                          "ppv": agg.precision.overall, "collective": f"all_gather({args.dist_backend})" if world > 1 else "none"},
             "host_vad_threads": vad_threads,
             "gpu_stage_wall_ms": float(np.mean(gpu_wall_ms[args.warmup:])),
             "kernel_ms_sum": float(sum(ktimes.values()) / args.steps),

@@ -302,6 +302,7 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks)
                 d.carry_out = lj.carry[lj.cur ^ 1];
                 d.first = (k == 0);
                 d.last = (k + 1 == take);
+                d.rms = lj.d_rms ? lj.d_rms + (c + k) : nullptr;
             }
             touched.push_back(j);
             // per-chunk RMS lands in ws.rms[n..]; remember where to copy it
@@ -312,7 +313,7 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks)
         // the stream orders this copy after the previous launch's kernels
         FVAD_HIP(ctx, hipMemcpyAsync(ws.descs, hd, (size_t)n * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
         time_begin(ctx, "stft320_logpow");
-        fvad_launch_stft(ws.descs, (int)n, ctx->tb, ws.feat, ws.spec, ws.rms, ctx->stream);
+        fvad_launch_stft(ws.descs, (int)n, ctx->tb, ws.feat, ws.spec, ctx->stream);
         time_end(ctx);
         const long n_pad = ((n + 127) / 128) * 128;
         rc = run_nn(ctx, n_pad, kRowsPerChunk, kWarmupRows);
@@ -320,21 +321,6 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks)
         time_begin(ctx, "istft320_ola_up3");
         fvad_launch_istft(ws.descs, (int)n, ctx->tb, ws.spec, ws.gains, kFramesPerChunk, 0, ctx->stream);
         time_end(ctx);
-        // scatter the RMS values to the jobs
-        {
-            long off = 0;
-            size_t jj = job, cc = chunk_in_job;
-            while (off < n) {
-                LaneJob& lj = jobs[jj];
-                if (lj.n_chunks == 0) { ++jj; cc = 0; continue; }
-                const size_t take = std::min<size_t>(lj.n_chunks - cc, (size_t)(n - off));
-                if (lj.d_rms)
-                    FVAD_HIP(ctx, hipMemcpyAsync(lj.d_rms + cc, ws.rms + off, take * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-                off += (long)take;
-                cc += take;
-                if (cc == lj.n_chunks) { ++jj; cc = 0; }
-            }
-        }
         for (size_t t : touched) jobs[t].cur ^= 1;
         // the pinned descriptor table is reused by the next launch
         FVAD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -440,6 +426,8 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     if (ws.band) hipFree(ws.band);
     if (ws.bins) hipFree(ws.bins);
     if (ws.carries) hipFree(ws.carries);
+    if (ws.fft_jobs) hipFree(ws.fft_jobs);
+    if (ws.h_fft_jobs) hipHostFree(ws.h_fft_jobs);
     DeviceModel& m = ctx->dm;
     DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.gi1_w, &m.gi1_b, &m.r1, &m.br1, &m.gi2_w, &m.gi2_b, &m.r2, &m.br2,
                       &m.fc2_w, &m.fc2_b, &m.fc3_w, &m.fc3_b, &m.fc4_w, &m.fc4_b, &m.r1v2, &m.r2v2, &m.gi1f_w, &m.gi1f_b, &m.gi1v2_w, &m.gi2v2_w};
@@ -769,10 +757,23 @@ int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes
         jobs[l].d_rms = d_chunk_rms ? d_chunk_rms + l * n_chunks : nullptr;
     }
     if ((rc = run_chunks(ctx, jobs, opts.max_chunks_per_launch))) return rc;
-    time_begin(ctx, "fft1024_bandsum");
-    for (size_t l = 0; l < n_lanes; ++l)
-        fvad_launch_vadfft(den + l * n_den, (long)n_frames, ctx->tb, opts.min_bin, opts.max_bin, d_band_sum + l * n_frames, nullptr, st);
-    time_end(ctx);
+    {
+        // one launch for every lane's frames
+        if (ws.fft_jobs_cap < n_lanes) {
+            if (ws.fft_jobs) hipFree(ws.fft_jobs);
+            if (ws.h_fft_jobs) hipHostFree(ws.h_fft_jobs);
+            ws.fft_jobs = nullptr; ws.h_fft_jobs = nullptr; ws.fft_jobs_cap = 0;
+            FVAD_HIP(ctx, hipMalloc((void**)&ws.fft_jobs, n_lanes * sizeof(VadFftJob)));
+            FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_fft_jobs, n_lanes * sizeof(VadFftJob), hipHostMallocDefault));
+            ws.fft_jobs_cap = n_lanes;
+        }
+        for (size_t l = 0; l < n_lanes; ++l) ws.h_fft_jobs[l] = {den + l * n_den, d_band_sum + l * n_frames, nullptr, (long)n_frames};
+        FVAD_HIP(ctx, hipMemcpyAsync(ws.fft_jobs, ws.h_fft_jobs, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice, st));
+        time_begin(ctx, "fft1024_bandsum");
+        fvad_launch_vadfft_jobs(ws.fft_jobs, (int)n_lanes, (long)n_frames, ctx->tb, opts.min_bin, opts.max_bin, st);
+        time_end(ctx);
+        FVAD_HIP(ctx, hipStreamSynchronize(st)); // the pinned job table is reused by the next call
+    }
     FVAD_HIP(ctx, hipGetLastError());
     return FVAD_OK;
 }

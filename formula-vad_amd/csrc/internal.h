@@ -64,6 +64,7 @@ struct Workspace {
     float* band = nullptr; size_t band_cap = 0;
     float* bins = nullptr; size_t bins_cap = 0;
     LaneCarry* carries = nullptr; size_t carries_cap = 0; // scratch carries (2 per lane)
+    VadFftJob* fft_jobs = nullptr; VadFftJob* h_fft_jobs = nullptr; size_t fft_jobs_cap = 0;
 };
 
 struct KernelTime {

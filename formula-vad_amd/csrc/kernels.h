@@ -36,6 +36,15 @@ struct ChunkDesc {
     LaneCarry* carry_out;      // written by the lane's last chunk of a launch (!= carry_in)
     uint32_t first;     // first chunk of its lane in this launch -> history comes from carry_in
     uint32_t last;      // last chunk of its lane in this launch -> writes carry_out
+    float* rms;         // where this chunk's RMS goes (device), or null
+};
+
+// one lane's worth of 1024-sample frames for K4
+struct VadFftJob {
+    const float* den;   // first frame's first sample (device, 8-byte aligned)
+    float* band_sum;    // [n_frames]
+    float* bins;        // [n_frames][513] or null
+    long n_frames;
 };
 
 // constant tables (device), built on the host in double like kissfft does and rounded once
@@ -63,7 +72,7 @@ int fvad_launch_gru_rec2(const float* gi, const float* R2frag, const float* bR, 
 
 // K1: per chunk: RMS, decimate, STFT-320, log-power features (+ warm-up rows)
 void fvad_launch_stft(const ChunkDesc* descs, int n_chunks, FftTables tb, float* feat,
-                      float* spec, float* rms, hipStream_t stream);
+                      float* spec, hipStream_t stream);
 // K3: per chunk: gain, inverse STFT, overlap-add, x3 upsample
 void fvad_launch_istft(const ChunkDesc* descs, int n_chunks, FftTables tb, const float* spec,
                        const float* gains, int gains_rows_per_chunk, int gains_row0,
@@ -71,6 +80,9 @@ void fvad_launch_istft(const ChunkDesc* descs, int n_chunks, FftTables tb, const
 // K4: 1024-point periodic-Hann rFFT magnitude + band sum over [min_bin, max_bin]
 void fvad_launch_vadfft(const float* den, long n_frames, FftTables tb, int min_bin, int max_bin,
                         float* band_sum, float* bins_or_null, hipStream_t stream);
+// all lanes in one launch: jobs is a device array of n_jobs entries, max_frames = max n_frames
+void fvad_launch_vadfft_jobs(const VadFftJob* jobs, int n_jobs, long max_frames, FftTables tb,
+                             int min_bin, int max_bin, hipStream_t stream);
 // batched FFT.fft for B3 / BASELINE config 2: n_fft in {320, 1024}
 void fvad_launch_rfft_batch(const float* frames, long n_frames, int n_fft, const float* window,
                             FftTables tb, float* bins_or_null, float* mag_or_null,

@@ -185,8 +185,7 @@ constexpr int K1_DEC = (kRowsPerChunk + 1) * kNHop; // 8800 decimated samples: f
 
 __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __restrict__ descs,
                                                           FftTables tb, float* __restrict__ feat,
-                                                          float* __restrict__ spec,
-                                                          float* __restrict__ rms_out)
+                                                          float* __restrict__ spec)
 {
     __shared__ __attribute__((aligned(16))) float dec[K1_DEC];
     __shared__ __attribute__((aligned(16))) float zb[4][2][2 * 160];
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
     __syncthreads();
     if (tid == 0) {
         const float sum = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-        rms_out[g] = sqrtf(sum / (float)kChunk48);
+        if (d.rms) *d.rms = sqrtf(sum / (float)kChunk48);
     }
 
     // ---- warm-up feature rows of the first chunk of a call come from the carry (zeros at t=0:
@@ -330,10 +329,10 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
 }
 
 void fvad_launch_stft(const ChunkDesc* descs, int n_chunks, FftTables tb, float* feat, float* spec,
-                      float* rms, hipStream_t stream)
+                      hipStream_t stream)
 {
     hipLaunchKernelGGL(stft_kernel, dim3(n_chunks), dim3(K1_THREADS), 0, stream, descs, tb, feat,
-                       spec, rms);
+                       spec);
 }
 
 // ============================================================================ K3
@@ -512,16 +511,13 @@ __device__ __forceinline__ cpx rfft1024_bin(const float* zl, const float* st, in
     return (k < 256) ? xk : xnk; // k == 256: the X[ncfft-k] form is written last in kissfft
 }
 
-__global__ __launch_bounds__(256) void vadfft_kernel(const float* __restrict__ den, long n_frames,
-                                                     FftTables tb, int min_bin, int max_bin,
-                                                     float* __restrict__ band_sum,
-                                                     float* __restrict__ bins_out)
+__device__ __forceinline__ void vadfft_body(const float* __restrict__ den, long n_frames, long frame,
+                                            const FftTables& tb, int min_bin, int max_bin,
+                                            float* __restrict__ band_sum, float* __restrict__ bins_out,
+                                            float (*zl)[1024], float (*mag)[64])
 {
-    __shared__ __attribute__((aligned(16))) float zl[4][1024];
-    __shared__ float mag[4][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const long frame = (long)blockIdx.x * 4 + wave;
     const bool active = frame < n_frames;
     if (active) rfft1024_wave(den + frame * kVadFft, tb.win1024, tb, zl[wave], lane);
     __syncthreads();
@@ -551,12 +547,42 @@ __global__ __launch_bounds__(256) void vadfft_kernel(const float* __restrict__ d
     if (active && lane == 0) band_sum[frame] = acc;
 }
 
+__global__ __launch_bounds__(256) void vadfft_kernel(const float* __restrict__ den, long n_frames,
+                                                     FftTables tb, int min_bin, int max_bin,
+                                                     float* __restrict__ band_sum,
+                                                     float* __restrict__ bins_out)
+{
+    __shared__ __attribute__((aligned(16))) float zl[4][1024];
+    __shared__ float mag[4][64];
+    const long frame = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    vadfft_body(den, n_frames, frame, tb, min_bin, max_bin, band_sum, bins_out, zl, mag);
+}
+
+__global__ __launch_bounds__(256) void vadfft_jobs_kernel(const VadFftJob* __restrict__ jobs, FftTables tb,
+                                                          int min_bin, int max_bin)
+{
+    __shared__ __attribute__((aligned(16))) float zl[4][1024];
+    __shared__ float mag[4][64];
+    const VadFftJob j = jobs[blockIdx.y];
+    if ((long)blockIdx.x * 4 >= j.n_frames) return; // whole workgroup past this lane's frames
+    const long frame = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    vadfft_body(j.den, j.n_frames, frame, tb, min_bin, max_bin, j.band_sum, j.bins, zl, mag);
+}
+
 void fvad_launch_vadfft(const float* den, long n_frames, FftTables tb, int min_bin, int max_bin,
                         float* band_sum, float* bins_or_null, hipStream_t stream)
 {
     if (n_frames <= 0) return;
     hipLaunchKernelGGL(vadfft_kernel, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0, stream, den,
                        n_frames, tb, min_bin, max_bin, band_sum, bins_or_null);
+}
+
+void fvad_launch_vadfft_jobs(const VadFftJob* jobs, int n_jobs, long max_frames, FftTables tb,
+                             int min_bin, int max_bin, hipStream_t stream)
+{
+    if (n_jobs <= 0 || max_frames <= 0) return;
+    hipLaunchKernelGGL(vadfft_jobs_kernel, dim3((unsigned)((max_frames + 3) / 4), (unsigned)n_jobs), dim3(256), 0,
+                       stream, jobs, tb, min_bin, max_bin);
 }
 
 // ============================================================================ batched FFT.fft
