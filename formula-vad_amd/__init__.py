@@ -6,6 +6,6 @@ include/fvad.h; this package is the thin Python plumbing over it (ctypes binding
 generator, multi-GPU stream sharding).  The directory name is not a Python identifier; load it
 with `importlib` as `formula_vad_amd` (tests/conftest.py, bench.py and __graft_entry__.py do).
 """
-from . import binding, synth, shard  # noqa: F401
+from . import binding, synth, shard, simulator  # noqa: F401
 
-__all__ = ["binding", "synth", "shard"]
+__all__ = ["binding", "synth", "shard", "simulator"]

@@ -217,6 +217,9 @@ SIGNATURES = {
                                            C.POINTER(StatConfig), C.POINTER(SingleStats)]),
     "fvad_stats_aggregate": (C.c_int, [C.POINTER(SingleStats), sz, C.POINTER(AggregateStats)]),
     "fvad_parse_audacity": (C.c_int, [C.c_char_p, sz, C.POINTER(SegmentSec), sz, C.POINTER(sz)]),
+    "fvad_wav_read": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(c_float_p)), C.POINTER(sz),
+                                C.POINTER(sz), C.POINTER(sz)]),
+    "fvad_wav_free": (None, [C.POINTER(c_float_p), sz]),
 }
 
 _lib = None
@@ -636,6 +639,31 @@ def vad_run_many(machines, bands, ratios, first_index=None, fft_size=1024, n_thr
     fi = (C.c_uint64 * n)(*(first_index or [0] * n))
     check(lib().fvad_vad_run_many(hs, n, bp, rp, nf, C_, fi, fft_size, n_threads),
           "fvad_vad_run_many")
+
+
+def wav_read(path):
+    """-> (pcm [n_channels][n_frames] float32, sample_rate)"""
+    pcm = C.POINTER(c_float_p)()
+    nc, nf, sr = sz(), sz(), sz()
+    check(lib().fvad_wav_read(path.encode(), C.byref(pcm), C.byref(nc), C.byref(nf), C.byref(sr)),
+          f"fvad_wav_read({path})")
+    try:
+        out = np.empty((nc.value, nf.value), np.float32)
+        for c in range(nc.value):
+            if nf.value:
+                out[c] = np.ctypeslib.as_array(pcm[c], shape=(nf.value,))
+        return out, sr.value
+    finally:
+        lib().fvad_wav_free(pcm, nc.value)
+
+
+def parse_audacity(text):
+    raw = text.encode() if isinstance(text, str) else text
+    cap = raw.count(b"\n") + 2
+    out = (SegmentSec * cap)()
+    n = sz()
+    check(lib().fvad_parse_audacity(raw, len(raw), out, cap, C.byref(n)), "formats.parseAudacitySegments")
+    return [(out[i].from_sec, out[i].to_sec) for i in range(n.value)]
 
 
 def stats_from_segments(vad, ref, cfg):

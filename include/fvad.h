@@ -356,6 +356,14 @@ int fvad_stats_aggregate(const fvad_single_stats *stats, size_t n, fvad_aggregat
 int fvad_parse_audacity(const char *txt, size_t len, fvad_segment_sec *out, size_t cap,
                         size_t *n);
 
+/* ------------------------------------------------------------------ audio file input (host)
+ * Minimal RIFF/WAVE reader standing in for AudioBuffer.loadFromFile / AudioFileStream
+ * (src/audio_utils/AudioBuffer.zig:26-59, AudioFileStream.zig:18-102): PCM16 or float32, any
+ * channel count, returned channel-planar f32.  Free with fvad_wav_free. */
+int fvad_wav_read(const char *path, float ***channel_pcm, size_t *n_channels, size_t *n_frames,
+                  size_t *sample_rate);
+void fvad_wav_free(float **channel_pcm, size_t n_channels);
+
 #ifdef __cplusplus
 }
 #endif
