@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--lanes", type=int, default=256, help="streams per GPU per step")
+    ap.add_argument("--lanes", type=int, default=384, help="streams per GPU per step")
     ap.add_argument("--seconds", type=int, default=64, help="audio seconds per stream per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-2 / config-3 side measurements")
@@ -114,7 +114,7 @@ def pmc_traffic(chunks_per_launch):
     try:
         files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
         d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
-        if d["chunks_per_launch"] != min(chunks_per_launch, 32768):
+        if d["chunks_per_launch"] != min(chunks_per_launch, 49152):
             return None
         for k, v in d["kernels"].items():
             if k.startswith("gru_rec2_kernel"):

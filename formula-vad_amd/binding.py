@@ -603,7 +603,7 @@ class VadMachine:
 
     def segments(self):
         n = sz()
-        cap = 4096
+        cap = max(1, lib().fvad_vad_segment_count(self.h))
         buf = (SpeechSegment * cap)()
         check(lib().fvad_vad_segments(self.h, buf, cap, C.byref(n)), "vad_segments")
         return [(buf[i].sample_from, buf[i].sample_to, buf[i].avg_channel_vol_ratio,

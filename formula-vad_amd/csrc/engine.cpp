@@ -137,7 +137,7 @@ static void free_workspace_nn(Workspace& ws)
 int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
 {
     Workspace& ws = ctx->ws;
-    const long need = ((n_chunks + 127) / 128) * 128;
+    const long need = ((n_chunks + 383) / 384) * 384; // 384 = lcm of the 128- and 192-sequence workgroups
     if (need <= ws.cap_chunks && T <= ws.T) return FVAD_OK;
     hipStreamSynchronize(ctx->stream);
     free_workspace_nn(ws);
@@ -187,9 +187,12 @@ static int launch_gru(fvad_ctx* ctx, const float* gi, const DevBuf& r_v1, const 
     const char* force = getenv("FVAD_GRU_KERNEL"); // tuning aid: "v1w4", "v2w8", ...
     if (force) {
         const int w = atoi(force + 3);
+        const int real_w = (w == 13) ? 12 : (w == 9) ? 8 : w;
+        if (n_pad % (16 * real_w)) return -1;
         if (force[1] == '2') return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, w, ctx->stream);
         return fvad_launch_gru_rec(gi, r_v1.p, bR, hout, n_pad, T, w, ctx->stream);
     }
+    if (n_pad / 192 >= 256) return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, 12, ctx->stream);
     if (n_pad / 128 >= 256) return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, 8, ctx->stream);
     if (n_pad / 64 >= 64) return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, 4, ctx->stream);
     return fvad_launch_gru_rec(gi, r_v1.p, bR, hout, n_pad, T, 1, ctx->stream);
@@ -207,36 +210,39 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     const char* force = getenv("FVAD_GEMM_KERNEL"); // tuning aid: "v1" / "v2" / "v2nofold"
     const bool big = force ? force[1] == '2' : (n_pad >= 2048);
     if (big && rows % 256 == 0 && rows_out % 256 == 0) {
+        const char* fw = getenv("FVAD_GEMM_WAVES"); // tuning aid
+        int gw = 8; // 12 (three waves per SIMD) measured no faster than 8 for the GEMMs
+        if (fw) gw = atoi(fw);
         const bool fold = !(force && strstr(force, "nofold"));
         if (fold) {
             time_begin(ctx, "gru1_in_gemm_fc1folded");
-            rc |= fvad_launch_panel_gemm2(ws.feat, kFeatStride, m.gi1f_w.p, m.gi1f_b.p, ws.gi, 1200, rows, 15, 5, 11, FVAD_ACT_NONE, 75, 0, 0, st);
+            rc |= fvad_launch_panel_gemm2(ws.feat, kFeatStride, m.gi1f_w.p, m.gi1f_b.p, ws.gi, 1200, rows, 15, 5, 11, FVAD_ACT_NONE, 75, 0, 0, gw, st);
             time_end(ctx);
         } else {
             time_begin(ctx, "fc1_gemm");
             rc |= fvad_launch_panel_gemm(ws.feat, kFeatStride, m.fc1_w.p, m.fc1_b.p, ws.a1, 400, rows, 25, 1, 11, FVAD_ACT_NONE, 0, 0, st);
             time_end(ctx);
             time_begin(ctx, "gru1_in_gemm");
-            rc |= fvad_launch_panel_gemm2(ws.a1, 400, m.gi1v2_w.p, m.gi1_b.p, ws.gi, 1200, rows, 15, 5, 25, FVAD_ACT_NONE, 75, 0, 0, st);
+            rc |= fvad_launch_panel_gemm2(ws.a1, 400, m.gi1v2_w.p, m.gi1_b.p, ws.gi, 1200, rows, 15, 5, 25, FVAD_ACT_NONE, 75, 0, 0, gw, st);
             time_end(ctx);
         }
         time_begin(ctx, "gru1_rec");
         rc |= launch_gru(ctx, ws.gi, m.r1, m.r1v2, m.br1.p, ws.h1, n_pad, T);
         time_end(ctx);
         time_begin(ctx, "gru2_in_gemm");
-        rc |= fvad_launch_panel_gemm2(ws.h1, 400, m.gi2v2_w.p, m.gi2_b.p, ws.gi, 1200, rows, 15, 5, 25, FVAD_ACT_NONE, 75, 0, 0, st);
+        rc |= fvad_launch_panel_gemm2(ws.h1, 400, m.gi2v2_w.p, m.gi2_b.p, ws.gi, 1200, rows, 15, 5, 25, FVAD_ACT_NONE, 75, 0, 0, gw, st);
         time_end(ctx);
         time_begin(ctx, "gru2_rec");
         rc |= launch_gru(ctx, ws.gi, m.r2, m.r2v2, m.br2.p, ws.h2, n_pad, T);
         time_end(ctx);
         time_begin(ctx, "fc2_gemm");
-        rc |= fvad_launch_panel_gemm2(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, 38, skip ? T : 0, skip, st);
+        rc |= fvad_launch_panel_gemm2(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, 38, skip ? T : 0, skip, 8, st);
         time_end(ctx);
         time_begin(ctx, "fc3_gemm");
-        rc |= fvad_launch_panel_gemm2(ws.f2, 608, m.fc3_w.p, m.fc3_b.p, ws.f3, 608, rows_out, 19, 2, 38, FVAD_ACT_RELU, 38, 0, 0, st);
+        rc |= fvad_launch_panel_gemm2(ws.f2, 608, m.fc3_w.p, m.fc3_b.p, ws.f3, 608, rows_out, 19, 2, 38, FVAD_ACT_RELU, 38, 0, 0, 8, st);
         time_end(ctx);
         time_begin(ctx, "fc4_gemm");
-        rc |= fvad_launch_panel_gemm2(ws.f3, 608, m.fc4_w.p, m.fc4_b.p, ws.gains, kFeatStride, rows_out, 11, 1, 38, FVAD_ACT_SIGMOID, 11, 0, 0, st);
+        rc |= fvad_launch_panel_gemm2(ws.f3, 608, m.fc4_w.p, m.fc4_b.p, ws.gains, kFeatStride, rows_out, 11, 1, 38, FVAD_ACT_SIGMOID, 11, 0, 0, gw, st);
         time_end(ctx);
         if (rc) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "no kernel instance for this layer shape");
         FVAD_HIP(ctx, hipGetLastError());
@@ -274,7 +280,10 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
 // K1 -> NSNet2 -> K3 over every chunk of every job, in launches of <= max_chunks chunks.
 int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks)
 {
-    if (max_chunks <= 0) max_chunks = 32768;
+    if (max_chunks <= 0) {
+        const char* e = getenv("FVAD_MAX_CHUNKS"); // tuning aid
+        max_chunks = e ? atol(e) : 49152;
+    }
     long total = 0;
     for (auto& j : jobs) total += (long)j.n_chunks;
     if (total == 0) return FVAD_OK;
@@ -315,7 +324,7 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks)
         time_begin(ctx, "stft320_logpow");
         fvad_launch_stft(ws.descs, (int)n, ctx->tb, ws.feat, ws.spec, ctx->stream);
         time_end(ctx);
-        const long n_pad = ((n + 127) / 128) * 128;
+        const long n_pad = ((n + 383) / 384) * 384;
         rc = run_nn(ctx, n_pad, kRowsPerChunk, kWarmupRows);
         if (rc) return rc;
         time_begin(ctx, "istft320_ola_up3");
@@ -531,7 +540,7 @@ int fvad_nsnet2_forward(fvad_ctx* ctx, const float* features, size_t n_seq, size
     int rc = ensure_workspace(ctx, (long)n_seq, (int)T);
     if (rc) return rc;
     Workspace& ws = ctx->ws;
-    const long n_pad = (((long)n_seq + 127) / 128) * 128;
+    const long n_pad = (((long)n_seq + 383) / 384) * 384;
     // rows are [n_seq*T][161] on the host, [.][176] on the device
     FVAD_HIP(ctx, hipMemsetAsync(ws.feat, 0, (size_t)n_pad * T * kFeatStride * sizeof(float), ctx->stream));
     FVAD_HIP(ctx, hipMemcpy2DAsync(ws.feat, kFeatStride * sizeof(float), features, kNBins * sizeof(float),

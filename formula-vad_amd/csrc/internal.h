@@ -52,7 +52,7 @@ struct DeviceModel {
 };
 
 struct Workspace {
-    long cap_chunks = 0; // padded chunk capacity (multiple of 128)
+    long cap_chunks = 0; // padded chunk capacity (multiple of 384)
     int T = 0;
     ChunkDesc* descs = nullptr;
     ChunkDesc* h_descs = nullptr; // pinned

@@ -167,13 +167,12 @@ int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const fl
 //   * 1-D grid with the column block as the fastest index, so the workgroups that re-read the
 //     same activation rows run next to each other and hit in L2.
 // n_valid_tiles guards the store when the last column block is padded beyond ldc.
-template <int NT, int RT, int ACT, int SP>
-__global__ __launch_bounds__(512) void panel_gemm2_kernel(
+template <int NT, int RT, int ACT, int SP, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void panel_gemm2_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ Wfrag,
     const float* __restrict__ bias, float* __restrict__ C, int ldc, int S_steps, int n_blocks,
     int n_valid_tiles, int row_map_T, int row_map_skip)
 {
-    constexpr int WAVES = 8;
     __shared__ __attribute__((aligned(16))) float slab[2][NT * SP * 256];
 
     const int tid = threadIdx.x;
@@ -271,22 +270,25 @@ __global__ __launch_bounds__(512) void panel_gemm2_kernel(
     }
 }
 
-// rows must be a multiple of 256 (RT = 2).
+// rows must be a multiple of 32 * waves (RT = 2); waves = 8 or 12 (12: three wavefronts per SIMD,
+// only for the variants whose register budget allows it).
 int fvad_launch_panel_gemm2(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
                             int ldc, long rows, int nt, int n_blocks, int S_steps, int act,
-                            int n_valid_tiles, int map_T, int map_skip, hipStream_t stream)
+                            int n_valid_tiles, int map_T, int map_skip, int waves, hipStream_t stream)
 {
-    const unsigned grid = (unsigned)((rows / 256) * n_blocks);
-#define CASE2(NT_, ACT_, SP_)                                                                        \
-    if (nt == NT_ && act == ACT_) {                                                                  \
-        hipLaunchKernelGGL((panel_gemm2_kernel<NT_, 2, ACT_, SP_>), dim3(grid), dim3(512), 0, stream, \
-                           A, lda, Wfrag, bias, C, ldc, S_steps, n_blocks, n_valid_tiles, map_T,     \
-                           map_skip);                                                                \
+#define CASE2(NT_, ACT_, SP_, W_)                                                                    \
+    if (nt == NT_ && act == ACT_ && waves == W_) {                                                   \
+        const unsigned grid = (unsigned)((rows / (32 * W_)) * n_blocks);                             \
+        hipLaunchKernelGGL((panel_gemm2_kernel<NT_, 2, ACT_, SP_, W_>), dim3(grid), dim3(64 * W_), 0, \
+                           stream, A, lda, Wfrag, bias, C, ldc, S_steps, n_blocks, n_valid_tiles,    \
+                           map_T, map_skip);                                                         \
         return 0;                                                                                    \
     }
-    CASE2(15, FVAD_ACT_NONE, 5)
-    CASE2(19, FVAD_ACT_RELU, 3)
-    CASE2(11, FVAD_ACT_SIGMOID, 6)
+    CASE2(15, FVAD_ACT_NONE, 5, 8)
+    CASE2(15, FVAD_ACT_NONE, 5, 12)
+    CASE2(19, FVAD_ACT_RELU, 3, 8)
+    CASE2(11, FVAD_ACT_SIGMOID, 6, 8)
+    CASE2(11, FVAD_ACT_SIGMOID, 6, 12)
 #undef CASE2
     return -1;
 }
@@ -577,7 +579,9 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec2_kernel(const float* __res
 int fvad_launch_gru_rec2(const float* gi, const float* R2frag, const float* bR, float* hout,
                          long n_seq_pad, int T, int waves, hipStream_t stream)
 {
-    if (waves == 8) {
+    if (waves == 12) {
+        hipLaunchKernelGGL((gru_rec2_kernel<12>), dim3((unsigned)(n_seq_pad / 192)), dim3(768), 0, stream, gi, R2frag, bR, hout, T);
+    } else if (waves == 8) {
         hipLaunchKernelGGL((gru_rec2_kernel<8>), dim3((unsigned)(n_seq_pad / 128)), dim3(512), 0, stream, gi, R2frag, bR, hout, T);
     } else if (waves == 4) {
         hipLaunchKernelGGL((gru_rec2_kernel<4>), dim3((unsigned)(n_seq_pad / 64)), dim3(256), 0, stream, gi, R2frag, bR, hout, T);

@@ -199,7 +199,7 @@ typedef struct {
                                 fft_bins are always host pointers */
     int32_t min_bin;         /* band edges, inclusive; default 11..43 = freqToBin(500/2000) */
     int32_t max_bin;
-    int32_t max_chunks_per_launch; /* 0 = default (32768) */
+    int32_t max_chunks_per_launch; /* 0 = default (49152) */
 } fvad_engine_opts;
 void fvad_engine_opts_default(fvad_engine_opts *o);
 
