@@ -92,7 +92,13 @@ class EngineOpts(C.Structure):
                 ("max_chunks_per_launch", C.c_int32)]
 
 
-RecordingCb = C.CFUNCTYPE(None, vp, vp)
+class AudioBuffer(C.Structure):
+    _fields_ = [("channel_pcm", C.POINTER(c_float_p)), ("n_channels", sz), ("length", sz),
+                ("sample_rate", sz), ("duration_seconds", C.c_float),
+                ("global_start_frame_number", C.c_uint64)]
+
+
+RecordingCb = C.CFUNCTYPE(None, vp, C.POINTER(AudioBuffer))
 
 
 class Callbacks(C.Structure):
@@ -510,7 +516,7 @@ class AudioPipeline:
     """fvad_pipeline <-> reference src/AudioPipeline.zig"""
 
     def __init__(self, ctx, n_channels=1, sample_rate=48000, fft_size=1024, vad_overrides=None,
-                 alt_configs=None, skip_processing=False):
+                 alt_configs=None, skip_processing=False, record=False):
         self.ctx = ctx
         cfg = PipelineConfig()
         lib().fvad_pipeline_config_default(C.byref(cfg))
@@ -530,7 +536,20 @@ class AudioPipeline:
             cfg.alt_vad_machine_configs = self._alts
             cfg.n_alt_vad_machine_configs = len(alt_configs)
         self.h = vp()
-        ctx._ck(lib().fvad_pipeline_create(ctx.h, C.byref(cfg), None, C.byref(self.h)),
+        self.recordings = {"original": [], "denoised": []}
+        cbs = None
+        if record:
+            def mk(kind):
+                def cb(_ctx, ab):
+                    a = ab.contents
+                    assert a.n_channels == 1
+                    pcm = np.ctypeslib.as_array(a.channel_pcm[0], shape=(a.length,)).copy()
+                    self.recordings[kind].append((a.global_start_frame_number, pcm, a.duration_seconds))
+                return RecordingCb(cb)
+            self._cb_keep = (mk("original"), mk("denoised"))
+            self._cbs = Callbacks(None, self._cb_keep[0], self._cb_keep[1])
+            cbs = C.byref(self._cbs)
+        ctx._ck(lib().fvad_pipeline_create(ctx.h, C.byref(cfg), cbs, C.byref(self.h)),
                 "AudioPipeline.init")
         self.n_channels = n_channels
 

@@ -126,7 +126,7 @@ int upload_model(fvad_ctx* ctx)
 
 static void free_workspace_nn(Workspace& ws)
 {
-    float** bufs[] = {&ws.feat, &ws.spec, &ws.rms, &ws.a1, &ws.gi, &ws.h1, &ws.h2, &ws.f2, &ws.f3, &ws.gains};
+    float** bufs[] = {&ws.feat, &ws.spec, &ws.a1, &ws.gi, &ws.h1, &ws.h2, &ws.f2, &ws.f3, &ws.gains};
     for (float** b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
     if (ws.descs) hipFree(ws.descs);
     if (ws.h_descs) hipHostFree(ws.h_descs);
@@ -150,7 +150,6 @@ int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
     // zero-filled: padded rows / padded columns are read by the GEMMs and must stay finite
     if ((rc = dev_alloc(ctx, &ws.feat, rows * kFeatStride, true))) return rc;
     if ((rc = dev_alloc(ctx, &ws.spec, (size_t)G * kFramesPerChunk * kNBins * 2, true))) return rc;
-    if ((rc = dev_alloc(ctx, &ws.rms, (size_t)G, true))) return rc;
     if ((rc = dev_alloc(ctx, &ws.a1, rows * 400, true))) return rc;
     if ((rc = dev_alloc(ctx, &ws.gi, rows * 1200, true))) return rc;
     if ((rc = dev_alloc(ctx, &ws.h1, rows * 400, true))) return rc;
@@ -314,7 +313,6 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks)
                 d.rms = lj.d_rms ? lj.d_rms + (c + k) : nullptr;
             }
             touched.push_back(j);
-            // per-chunk RMS lands in ws.rms[n..]; remember where to copy it
             n += (long)take;
             c += take;
             if (c == lj.n_chunks) { ++j; c = 0; }

@@ -56,7 +56,7 @@ struct Workspace {
     int T = 0;
     ChunkDesc* descs = nullptr;
     ChunkDesc* h_descs = nullptr; // pinned
-    float *feat = nullptr, *spec = nullptr, *rms = nullptr, *a1 = nullptr, *gi = nullptr,
+    float *feat = nullptr, *spec = nullptr, *a1 = nullptr, *gi = nullptr,
           *h1 = nullptr, *h2 = nullptr, *f2 = nullptr, *f3 = nullptr, *gains = nullptr;
     // generic scratch (engine_run staging, denoised audio, band sums)
     float* in = nullptr;  size_t in_cap = 0;
@@ -91,10 +91,6 @@ struct fvad_ctx {
     std::vector<fvad::KernelTime> times;
     std::vector<std::string> time_names;
     std::vector<float> time_ms;
-    // cached descriptor table of the last enqueue_device call
-    const float* last_pcm = nullptr;
-    float* last_den = nullptr;
-    size_t last_lanes = 0, last_stride = 0, last_samples = 0;
 };
 
 struct fvad_lane_state {

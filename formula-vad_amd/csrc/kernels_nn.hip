@@ -591,17 +591,11 @@ int fvad_launch_gru_rec2(const float* gi, const float* R2frag, const float* bR, 
     return 0;
 }
 
-// n_seq_pad must be a multiple of 16*waves (waves = 4 or 8)
+// small-batch variant: one wavefront (16 sequences) per workgroup; n_seq_pad multiple of 16
 int fvad_launch_gru_rec(const float* gi, const float* Rfrag, const float* bR, float* hout,
                         long n_seq_pad, int T, int waves, hipStream_t stream)
 {
-    if (waves == 8) {
-        hipLaunchKernelGGL((gru_rec_kernel<8>), dim3((unsigned)(n_seq_pad / 128)), dim3(512), 0,
-                           stream, gi, Rfrag, bR, hout, T);
-    } else if (waves == 4) {
-        hipLaunchKernelGGL((gru_rec_kernel<4>), dim3((unsigned)(n_seq_pad / 64)), dim3(256), 0,
-                           stream, gi, Rfrag, bR, hout, T);
-    } else if (waves == 1) {
+    if (waves == 1) {
         hipLaunchKernelGGL((gru_rec_kernel<1>), dim3((unsigned)(n_seq_pad / 16)), dim3(64), 0,
                            stream, gi, Rfrag, bR, hout, T);
     } else {

@@ -244,6 +244,13 @@ struct fvad_pipeline {
     uint64_t frames_done = 0;                 // FFT frames handed to the state machine so far
     // traces
     std::vector<float> trace_band, trace_ratio;
+    // recorder (only when callbacks were given): processed original + denoised audio from
+    // hist_base on, and the state MRBRecorder/Recorder keep (MRBRecorder.zig:76-118)
+    std::vector<std::vector<float>> hist_orig, hist_den;
+    uint64_t hist_base = 0;
+    bool rec_active = false;
+    uint64_t rec_from = 0;
+    std::vector<std::vector<float>> den_host; // per-channel D2H landing buffers
     // scratch
     std::vector<std::vector<float>> band, rms;
 };
@@ -264,6 +271,50 @@ static MetaResult frame_metadata(const std::vector<float>& chunk_ratio, uint64_t
         m.push(r, (float)(hi - lo)); // weight = n_written, an integer -> @floatFromInt
     }
     return m.to_result();
+}
+
+// Recorder.findBestChannel (Recorder.zig:113-129) over rmsVolume (audio_utils.zig:14-24: sequential
+// f32 sum of squares): the first channel with the strictly smallest RMS
+static size_t best_channel(const std::vector<std::vector<float>>& hist, size_t off, size_t len)
+{
+    size_t best = 0;
+    float best_vol = 9999;
+    for (size_t c = 0; c < hist.size(); ++c) {
+        float sum = 0.0f;
+        const float* x = hist[c].data() + off;
+        for (size_t i = 0; i < len; ++i) sum += x[i] * x[i];
+        const float vol = std::sqrt(sum / (float)len);
+        if (vol < best_vol) { best = c; best_vol = vol; }
+    }
+    return best;
+}
+
+// pipeline.endRecording(to, keep = true): AudioPipeline.zig:187-191 -> MRBRecorder.stopRecording
+// (:88-118) -> Recorder.finalize / segmentToAudioBuffer (Recorder.zig:73-164).  The samples up to
+// `to` have always been processed by the time the state machine reports `completed` (the frame
+// that closes a segment starts at >= to), so both clips are cut immediately.
+static void emit_recordings(fvad_pipeline* p, uint64_t to)
+{
+    p->rec_active = false;
+    if (to < p->rec_from || p->rec_from < p->hist_base) return;
+    const size_t off = (size_t)(p->rec_from - p->hist_base);
+    const size_t len = (size_t)(to - p->rec_from);
+    if (off + len > p->hist_orig[0].size() || off + len > p->hist_den[0].size()) return;
+    const std::vector<std::vector<float>>* src[2] = {&p->hist_orig, &p->hist_den};
+    const fvad_recording_cb cbs[2] = {p->cb.on_original_recording, p->cb.on_denoised_recording};
+    for (int w = 0; w < 2; ++w) {
+        if (!cbs[w]) continue;
+        const size_t best = best_channel(*src[w], off, len);
+        const float* chan = (*src[w])[best].data() + off;
+        fvad_audio_buffer ab;
+        ab.channel_pcm = &chan;
+        ab.n_channels = 1;
+        ab.length = len;
+        ab.sample_rate = p->cfg.sample_rate;
+        ab.duration_seconds = (float)len / (float)p->cfg.sample_rate;
+        ab.global_start_frame_number = p->rec_from;
+        cbs[w](p->cb.ctx, &ab);
+    }
 }
 
 extern "C" {
@@ -296,6 +347,11 @@ int fvad_pipeline_create(fvad_ctx* ctx, const fvad_pipeline_config* cfg, const f
     p->pending.resize(cfg->n_channels);
     p->band.resize(cfg->n_channels);
     p->rms.resize(cfg->n_channels);
+    if (p->has_cb) {
+        p->hist_orig.resize(cfg->n_channels);
+        p->hist_den.resize(cfg->n_channels);
+        p->den_host.resize(cfg->n_channels);
+    }
     // band edges: FFT.freqToBin on the 1024-point / 48 kHz transform (BufferedFFT.zig:192-193)
     const float bin_width = (float)cfg->sample_rate / (float)cfg->fft_size;
     const float nyq = (float)cfg->sample_rate / 2;
@@ -361,6 +417,10 @@ int fvad_pipeline_push_samples(fvad_pipeline* p, const float* const* channel_pcm
         L.band_sum_capacity = max_frames;
         L.chunk_rms = p->rms[c].data();
         L.chunk_rms_capacity = n_chunks;
+        if (p->has_cb) {
+            p->den_host[c].resize(n_chunks * p->chunk_size);
+            L.denoised = p->den_host[c].data();
+        }
     }
     fvad_engine_opts opts;
     fvad_engine_opts_default(&opts);
@@ -369,6 +429,11 @@ int fvad_pipeline_push_samples(fvad_pipeline* p, const float* const* channel_pcm
     const int rc = fvad_engine_run(ctx, lanes.data(), C, &opts);
     if (rc) return rc;
     p->pipeline_read_count += (uint64_t)n_chunks * p->chunk_size;
+    if (p->has_cb)
+        for (size_t c = 0; c < C; ++c) {
+            p->hist_orig[c].insert(p->hist_orig[c].end(), p->pending[c].begin(), p->pending[c].begin() + (long)(n_chunks * p->chunk_size));
+            p->hist_den[c].insert(p->hist_den[c].end(), p->den_host[c].begin(), p->den_host[c].end());
+        }
     for (auto& v : p->pending) v.erase(v.begin(), v.begin() + (long)(n_chunks * p->chunk_size));
 
     // per-chunk metadata: BufferedVolumeAnalyzer.write then BufferedDenoiser.write each push the
@@ -391,12 +456,32 @@ int fvad_pipeline_push_samples(fvad_pipeline* p, const float* const* channel_pcm
         for (size_t c = 0; c < C; ++c) vols[c] = p->band[c][k];
         const MetaResult md = frame_metadata(p->chunk_ratio, p->frames_done + k, p->cfg.fft_size, p->chunk_size);
         const uint64_t index = first_index + (uint64_t)k * p->cfg.fft_size;
-        p->vad->run(index, vols.data(), md.has_ratio, md.volume_ratio);
+        const fvad_vad_result res = p->vad->run(index, vols.data(), md.has_ratio, md.volume_ratio);
+        if (p->has_cb) { // VADPipeline.zig:215-229
+            if (res.recording_state == FVAD_REC_STARTED) { p->rec_active = true; p->rec_from = res.sample_number; }
+            else if (res.recording_state == FVAD_REC_COMPLETED && p->rec_active) emit_recordings(p, res.sample_number);
+            else if (res.recording_state == FVAD_REC_ABORTED) p->rec_active = false;
+        }
         for (auto& a : p->alt) a->run(index, vols.data(), md.has_ratio, md.volume_ratio);
         p->trace_band.insert(p->trace_band.end(), vols.begin(), vols.end());
         p->trace_ratio.push_back(md.has_ratio ? md.volume_ratio : NAN);
     }
     p->frames_done += n_frames;
+    if (p->has_cb) {
+        // keep what a future `started` can still reach back to: its start is at most the opening
+        // time (>= 0.2 s, i.e. ~11 frames) plus the 2 s margin before the next frame
+        const uint64_t next_index = first_index + (uint64_t)n_frames * p->cfg.fft_size;
+        uint64_t keep_from = next_index > 3 * p->cfg.sample_rate ? next_index - 3 * p->cfg.sample_rate : 0;
+        if (p->rec_active) keep_from = std::min(keep_from, p->rec_from);
+        if (keep_from > p->hist_base) {
+            const size_t drop = (size_t)(keep_from - p->hist_base);
+            for (size_t c = 0; c < C; ++c) {
+                p->hist_orig[c].erase(p->hist_orig[c].begin(), p->hist_orig[c].begin() + (long)drop);
+                p->hist_den[c].erase(p->hist_den[c].begin(), p->hist_den[c].begin() + (long)drop);
+            }
+            p->hist_base = keep_from;
+        }
+    }
     return FVAD_OK;
 }
 

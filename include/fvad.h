@@ -281,11 +281,21 @@ int fvad_ra_last_avg(const fvad_rolling_average *ra, double *out);
 
 /* ------------------------------------------------------------------ B1: AudioPipeline
  * (src/AudioPipeline.zig) -- what simulator.zig / main.zig hold. */
-typedef struct fvad_audio_buffer {           /* audio_utils/AudioBuffer.zig (recording payload) */
+/* Recording payload == AudioBuffer (src/audio_utils/AudioBuffer.zig:16-24) as Recorder.finalize
+ * builds it (Recorder.zig:131-164): ONE channel -- the quietest of the stream's channels over the
+ * clip (findBestChannel, :113-129) -- covering samples [global_start_frame_number, + length).
+ * Unlike the reference (callee frees, MRBRecorder.zig:9-11) the buffer belongs to the library and
+ * is valid only during the callback. */
+typedef struct fvad_audio_buffer {
     const float *const *channel_pcm;
     size_t n_channels, length, sample_rate;
+    float duration_seconds;
     uint64_t global_start_frame_number;
 } fvad_audio_buffer;
+/* AudioPipeline.Callbacks (AudioPipeline.zig:14-18).  When callbacks are given, every segment the
+ * state machine completes (VADPipeline.zig:215-229) produces one original-audio clip and then one
+ * denoised-audio clip, in that order (AudioPipeline.zig:187-191); the denoised audio is then also
+ * copied back from the GPU (1920 B per frame). */
 typedef void (*fvad_recording_cb)(void *ctx, const fvad_audio_buffer *recording);
 typedef struct {                              /* AudioPipeline.Callbacks, AudioPipeline.zig:14-18 */
     void *ctx;

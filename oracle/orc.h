@@ -219,6 +219,14 @@ const float *orc_pipeline_chunk_rms(const orc_pipeline *p);      /* [n_chunks][n
 size_t orc_pipeline_n_chunks(const orc_pipeline *p);
 const float *orc_pipeline_denoised(const orc_pipeline *p, int channel); /* keep_denoised only */
 size_t orc_pipeline_n_denoised(const orc_pipeline *p);
+/* Recordings (MRBRecorder.zig:76-203 + Recorder.zig:60-164), kept only when keep_denoised: on a
+ * `started` result recording begins at its sample_number, on `completed` the samples
+ * [start, sample_number) of the quietest channel (Recorder.findBestChannel, :113-129) become one
+ * mono clip -- once from the original audio, once from the denoised audio
+ * (AudioPipeline.zig:181-191).  which: 0 = original, 1 = denoised. */
+size_t orc_pipeline_n_recordings(const orc_pipeline *p);
+const float *orc_pipeline_recording(const orc_pipeline *p, int which, size_t i, uint64_t *start,
+                                    size_t *length, int *best_channel);
 /* full 513-bin magnitudes of BufferedFFT result `frame` (kept only when keep_denoised) */
 const float *orc_pipeline_fft_bins(const orc_pipeline *p, size_t frame, int channel);
 

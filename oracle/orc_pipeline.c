@@ -156,6 +156,11 @@ struct orc_pipeline {
     float **denoised; size_t n_denoised, cap_denoised;
     float *all_bins; /* [frame][channel][n_bins] when keep_denoised */
     size_t cap_all_bins;
+    /* recorder (keep_denoised only) */
+    float **original; size_t n_original, cap_original; /* every processed original sample */
+    int rec_active; uint64_t rec_from;
+    struct { uint64_t start; size_t length; int best[2]; float *pcm[2]; } *recs;
+    size_t n_recs, cap_recs;
 };
 
 void orc_pipeline_config_default(orc_pipeline_config *c)
@@ -187,6 +192,7 @@ orc_pipeline *orc_pipeline_create(const orc_pipeline_config *cfg, const orc_nsne
     p->den_result = (float **)calloc((size_t)C, sizeof(float *));
     p->channel_bins = (float **)calloc((size_t)C, sizeof(float *));
     p->denoised = (float **)calloc((size_t)C, sizeof(float *));
+    p->original = (float **)calloc((size_t)C, sizeof(float *));
     const int n_bins = orc_fft_bin_count(cfg->fft_size);
     for (int c = 0; c < C; ++c) {
         p->denoisers[c] = orc_nsnet2_create(cfg->sample_rate, w); /* BufferedDenoiser.zig:38-41 */
@@ -220,7 +226,11 @@ void orc_pipeline_destroy(orc_pipeline *p)
         free(p->den_result[c]);
         free(p->channel_bins[c]);
         free(p->denoised[c]);
+        free(p->original[c]);
     }
+    for (size_t i = 0; i < p->n_recs; ++i) { free(p->recs[i].pcm[0]); free(p->recs[i].pcm[1]); }
+    free(p->recs);
+    free(p->original);
     free(p->pending); free(p->denoisers); free(p->den_result); free(p->channel_bins);
     free(p->denoised);
     sw_free(&p->den_buffer); sw_free(&p->fft_buffer);
@@ -230,6 +240,42 @@ void orc_pipeline_destroy(orc_pipeline *p)
     free(p->temp_channel_volumes);
     free(p->band_volumes); free(p->frame_ratio); free(p->chunk_rms); free(p->all_bins);
     free(p);
+}
+
+/* Recorder.findBestChannel (Recorder.zig:113-129): first channel with the strictly smallest RMS */
+static int find_best_channel(float *const *chan, int C, uint64_t from, size_t len)
+{
+    int best = 0;
+    float best_vol = 9999;
+    for (int c = 0; c < C; ++c) {
+        const float vol = orc_rms_volume(chan[c] + from, len, NULL, 0);
+        if (vol < best_vol) { best = c; best_vol = vol; }
+    }
+    return best;
+}
+
+/* pipeline.endRecording(to, keep = true) (VADPipeline.zig:220-223 -> AudioPipeline.zig:187-191 ->
+ * MRBRecorder.stopRecording -> Recorder.finalize -> segmentToAudioBuffer) */
+static void finalize_recording(orc_pipeline *p, uint64_t to)
+{
+    const int C = p->cfg.n_channels;
+    if (!p->rec_active || to < p->rec_from || to > p->n_original || to > p->n_denoised) abort();
+    if (p->n_recs == p->cap_recs) {
+        p->cap_recs = p->cap_recs ? p->cap_recs * 2 : 16;
+        p->recs = realloc(p->recs, sizeof(*p->recs) * p->cap_recs);
+    }
+    const size_t len = (size_t)(to - p->rec_from);
+    float *const *src[2] = { p->original, p->denoised };
+    for (int w = 0; w < 2; ++w) {
+        const int best = find_best_channel(src[w], C, p->rec_from, len);
+        p->recs[p->n_recs].best[w] = best;
+        p->recs[p->n_recs].pcm[w] = (float *)malloc(sizeof(float) * (len ? len : 1));
+        memcpy(p->recs[p->n_recs].pcm[w], src[w][best] + p->rec_from, sizeof(float) * len);
+    }
+    p->recs[p->n_recs].start = p->rec_from;
+    p->recs[p->n_recs].length = len;
+    p->n_recs++;
+    p->rec_active = 0;
 }
 
 /* VADPipeline.stateMachineStep (VADPipeline.zig:209-237) + VADMachine.run's first step,
@@ -258,7 +304,13 @@ static void state_machine_step(orc_pipeline *p, uint64_t index, const orc_meta_r
                    sizeof(float) * n_bins);
     }
     p->n_frames++;
-    orc_vad_run(p->vad, index, p->temp_channel_volumes, meta->has_ratio, meta->volume_ratio);
+    const orc_vad_result r =
+        orc_vad_run(p->vad, index, p->temp_channel_volumes, meta->has_ratio, meta->volume_ratio);
+    if (p->cfg.keep_denoised) { /* VADPipeline.zig:215-229 */
+        if (r.recording_state == ORC_REC_STARTED) { p->rec_active = 1; p->rec_from = r.sample_number; }
+        else if (r.recording_state == ORC_REC_COMPLETED) finalize_recording(p, r.sample_number);
+        else if (r.recording_state == ORC_REC_ABORTED) p->rec_active = 0;
+    }
 }
 
 /* VADPipeline.fftStep (VADPipeline.zig:191-207) driving BufferedFFT.write (BufferedFFT.zig:129-160) */
@@ -354,6 +406,14 @@ static void process_chunk(orc_pipeline *p, float *const *chunk, uint64_t from)
 
         /* pipeline.pushDenoisedSamples (VADPipeline.zig:183) */
         if (p->cfg.keep_denoised) {
+            if (p->n_original + n > p->cap_original) {
+                p->cap_original = (p->n_original + n) * 2;
+                for (int c = 0; c < C; ++c)
+                    p->original[c] = (float *)realloc(p->original[c], sizeof(float) * p->cap_original);
+            }
+            for (int c = 0; c < C; ++c)
+                memcpy(p->original[c] + p->n_original, p->den_buffer.chan[c], sizeof(float) * n);
+            p->n_original += n;
             if (p->n_denoised + n > p->cap_denoised) {
                 p->cap_denoised = (p->n_denoised + n) * 2;
                 for (int c = 0; c < C; ++c)
@@ -417,6 +477,16 @@ const float *orc_pipeline_chunk_rms(const orc_pipeline *p) { return p->chunk_rms
 size_t orc_pipeline_n_chunks(const orc_pipeline *p) { return p->n_chunks; }
 const float *orc_pipeline_denoised(const orc_pipeline *p, int channel) { return p->denoised[channel]; }
 size_t orc_pipeline_n_denoised(const orc_pipeline *p) { return p->n_denoised; }
+size_t orc_pipeline_n_recordings(const orc_pipeline *p) { return p->n_recs; }
+const float *orc_pipeline_recording(const orc_pipeline *p, int which, size_t i, uint64_t *start,
+                                    size_t *length, int *best_channel)
+{
+    if (i >= p->n_recs) return NULL;
+    if (start) *start = p->recs[i].start;
+    if (length) *length = p->recs[i].length;
+    if (best_channel) *best_channel = p->recs[i].best[which ? 1 : 0];
+    return p->recs[i].pcm[which ? 1 : 0];
+}
 const float *orc_pipeline_fft_bins(const orc_pipeline *p, size_t frame, int channel)
 {
     if (!p->all_bins) return NULL;

@@ -194,6 +194,9 @@ def lib(native=False):
         "orc_pipeline_denoised": (c_float_p, [vp, C.c_int]),
         "orc_pipeline_n_denoised": (sz, [vp]),
         "orc_pipeline_fft_bins": (c_float_p, [vp, sz, C.c_int]),
+        "orc_pipeline_n_recordings": (sz, [vp]),
+        "orc_pipeline_recording": (c_float_p, [vp, C.c_int, sz, C.POINTER(C.c_uint64), C.POINTER(sz),
+                                               C.POINTER(C.c_int)]),
         "orc_buffered_fft_frame": (None, [c_float_p, C.c_int, c_float_p]),
         "orc_band_sum": (C.c_float, [c_float_p, C.c_long, C.c_long]),
         "orc_sw_create": (vp, [sz]),
@@ -406,6 +409,19 @@ class Pipeline:
         nb = self.cfg.fft_size // 2 + 1
         return np.ctypeslib.as_array(lib().orc_pipeline_fft_bins(self.h, frame, channel),
                                      (nb,)).copy()
+
+    def recordings(self):
+        """[(start, best_channel_original, original clip, best_channel_denoised, denoised clip)]"""
+        out = []
+        for i in range(lib().orc_pipeline_n_recordings(self.h)):
+            start, length, best = C.c_uint64(), C.c_size_t(), C.c_int()
+            po = lib().orc_pipeline_recording(self.h, 0, i, C.byref(start), C.byref(length), C.byref(best))
+            orig = np.ctypeslib.as_array(po, (length.value,)).copy()
+            bo = best.value
+            pd = lib().orc_pipeline_recording(self.h, 1, i, None, None, C.byref(best))
+            den = np.ctypeslib.as_array(pd, (length.value,)).copy()
+            out.append((start.value, bo, orig, best.value, den))
+        return out
 
     def vad_traces(self):
         n = lib().orc_pipeline_n_fft_frames(self.h)

@@ -392,3 +392,32 @@ def test_golden_vectors(fv, gpu_ctx):
     assert_audio(out["denoised"], g["stream_denoised"], what="golden denoised")
     assert_rel(out["band_sum"], g["stream_band"], 1e-4, what="golden band")
     assert_rel(out["chunk_rms"], g["stream_rms"], 1e-4, what="golden rms")
+
+
+def test_pipeline_recordings_match_oracle(fv, gpu_ctx, weights7, pkg):
+    # AudioPipeline.Callbacks (AudioPipeline.zig:14-18): one original + one denoised clip per completed
+    # segment, quietest channel, cut at [segment.sample_from, segment.sample_to)
+    pcm, _ = pkg.synth.make_stream(60.0, seed=41, n_channels=2)
+    ref = orc.Pipeline(weights7, n_channels=2, keep_denoised=True)
+    ref.push(pcm)
+    recs_ref = ref.recordings()
+    p = fv.AudioPipeline(gpu_ctx, n_channels=2, record=True)
+    pos = 0
+    for step in (100000, 48000 * 7, 10**9):   # recordings that start in one push and end in a later one
+        nxt = min(pcm.shape[1], pos + step)
+        p.push_samples(pcm[:, pos:nxt])
+        pos = nxt
+    segs = p.segments()
+    assert len(recs_ref) == len(segs) >= 2
+    assert len(p.recordings["original"]) == len(p.recordings["denoised"]) == len(segs)
+    for seg, r, (so, po, duro), (sd, pd, durd) in zip(segs, recs_ref, p.recordings["original"], p.recordings["denoised"]):
+        start, best_o, clip_o, best_d, clip_d = r
+        assert so == sd == start == seg[0] and len(po) == len(pd) == seg[1] - seg[0]
+        assert duro == np.float32(len(po)) / np.float32(48000)
+        assert np.array_equal(po, clip_o)                      # original audio: bit-exact, same channel
+        assert np.array_equal(po, pcm[best_o, start:start + len(po)])
+        assert_audio(pd, clip_d, what="denoised recording")
+    # without callbacks nothing is copied back or recorded
+    q = fv.AudioPipeline(gpu_ctx, n_channels=2)
+    q.push_samples(pcm)
+    assert q.segments() == segs and q.recordings == {"original": [], "denoised": []}
