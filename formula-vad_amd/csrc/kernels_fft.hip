@@ -210,14 +210,29 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
         const int n4 = (hist + kChunk48) / 4;
         const int dec0 = d.first ? (kWarmupRows + 1) * kNHop : 0;          // 800
         const f32x4* src4 = reinterpret_cast<const f32x4*>(src);
-        for (int i4 = tid; i4 < n4; i4 += K1_THREADS) {
-            const f32x4 v = src4[i4];
+        // batches of 9 independent 16-byte loads per thread are issued before any is consumed, so the
+        // chunk's 96-105 KB stream in with ~37 KB per workgroup in flight instead of one L2/HBM round
+        // trip per loop iteration
+        constexpr int LD_BATCH = 9;
+        for (int base = 0; base < n4; base += LD_BATCH * K1_THREADS) {
+            f32x4 v[LD_BATCH];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned s = 4u * i4 + e;
-                const unsigned s3 = s / 3u;
-                if (s3 * 3u == s) dec[dec0 + s3] = v[e];
-                if ((int)s >= hist) ss += v[e] * v[e];
+            for (int b = 0; b < LD_BATCH; ++b) {
+                const int i4 = base + b * K1_THREADS + tid;
+                v[b] = (i4 < n4) ? src4[i4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int b = 0; b < LD_BATCH; ++b) {
+                const int i4 = base + b * K1_THREADS + tid;
+                if (i4 < n4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned s = 4u * i4 + e;
+                        const unsigned s3 = s / 3u;
+                        if (s3 * 3u == s) dec[dec0 + s3] = v[b][e];
+                        if ((int)s >= hist) ss += v[b][e] * v[b][e];
+                    }
+                }
             }
         }
         if (d.first) {
@@ -369,24 +384,50 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
     // frames fr = -2..49; fr < 0 belong to the previous chunk of the same lane (g - 1)
     const int fr_begin = d.first ? 0 : -2;
     constexpr int N_PAIRS = K3_FR / 2; // 26
-    for (int it = 0; it < (N_PAIRS + 3) / 4; ++it) {
-        const int pi = it * 4 + wave;
-        // pre-mix gain * X into the length-160 complex sequence
-        for (int item = lane; item < 2 * 81; item += 64) {
+    // The spectrogram / gain operands of a frame pair are fetched one iteration ahead (3 items per
+    // lane: 12 spectrum floats + 6 gains), so each iteration's global-memory round trip overlaps the
+    // previous pair's FFT instead of heading the critical path.
+    struct Item { float sk_r, sk_i, snk_r, snk_i, gk, gnk; };
+    auto fetch = [&](int pi, Item (&itm)[3]) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int item = lane + 64 * u;
             const int hh = item / 81;
             const int k = item - hh * 81;
             const int fr = 2 * pi + hh - 2;
-            if (pi < N_PAIRS && fr >= fr_begin) {
+            itm[u] = Item{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (item < 2 * 81 && pi < N_PAIRS && fr >= fr_begin) {
                 const int gg = fr < 0 ? g - 1 : g;
                 const int f = fr < 0 ? fr + kFramesPerChunk : fr;
                 const float* srow = spec + ((size_t)gg * kFramesPerChunk + f) * kNBins * 2;
                 const float* grow = gains + ((size_t)gg * g_rows + g_row0 + f) * kFeatStride;
                 const int kn = 160 - k;
-                float gk = grow[k], gnk = grow[kn];
+                itm[u].sk_r = srow[2 * k]; itm[u].sk_i = srow[2 * k + 1];
+                itm[u].snk_r = srow[2 * kn]; itm[u].snk_i = srow[2 * kn + 1];
+                itm[u].gk = grow[k]; itm[u].gnk = grow[kn];
+            }
+        }
+    };
+    Item cur[3];
+    fetch(wave, cur);
+    for (int it = 0; it < (N_PAIRS + 3) / 4; ++it) {
+        const int pi = it * 4 + wave;
+        Item nxt[3];
+        fetch(pi + 4, nxt);
+        // pre-mix gain * X into the length-160 complex sequence
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int item = lane + 64 * u;
+            const int hh = item / 81;
+            const int k = item - hh * 81;
+            const int fr = 2 * pi + hh - 2;
+            if (item < 2 * 81 && pi < N_PAIRS && fr >= fr_begin) {
+                const int kn = 160 - k;
+                float gk = cur[u].gk, gnk = cur[u].gnk;
                 gk = gk < -80.0f ? -80.0f : (gk > 1.0f ? 1.0f : gk);   // NSNet2.zig:295-305
                 gnk = gnk < -80.0f ? -80.0f : (gnk > 1.0f ? 1.0f : gnk);
-                const cpx yk = {srow[2 * k] * gk, srow[2 * k + 1] * gk};
-                const cpx ynk = {srow[2 * kn] * gnk, srow[2 * kn + 1] * gnk};
+                const cpx yk = {cur[u].sk_r * gk, cur[u].sk_i * gk};
+                const cpx ynk = {cur[u].snk_r * gnk, cur[u].snk_i * gnk};
                 float* z = zb[wave][hh];
                 if (k == 0) {
                     z[0] = yk.r + ynk.r;
@@ -400,6 +441,8 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
                 }
             }
         }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) cur[u] = nxt[u];
         __syncthreads();
         {
             const int fr = 2 * pi + half - 2;
