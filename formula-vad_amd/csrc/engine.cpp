@@ -206,42 +206,52 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     const long rows = n_pad * T;
     const long rows_out = n_pad * (T - skip);
     int rc = 0;
-    const char* force = getenv("FVAD_GEMM_KERNEL"); // tuning aid: "v1" / "v2" / "v2nofold"
-    const bool big = force ? force[1] == '2' : (n_pad >= 2048);
+    const char* force = getenv("FVAD_GEMM_KERNEL"); // tuning aid: "v1" / "v2" / "v2nofold" / "v3"
+    const bool big = force ? force[1] != '1' : (n_pad >= 2048);
     if (big && rows % 256 == 0 && rows_out % 256 == 0) {
         const char* fw = getenv("FVAD_GEMM_WAVES"); // tuning aid
         int gw = 8; // 12 (three waves per SIMD) measured no faster than 8 for the GEMMs
         if (fw) gw = atoi(fw);
+        // The persistent kernel (one workgroup per CU walking all (row panel, column block) items) is
+        // the default where it has an instance: the 15- and 11-tile column blocks.  The 19-tile blocks
+        // of fc2/fc3 leave it no room for its fragment ring in 256 VGPRs and stay on panel_gemm2.
+        const bool allow_v3 = !(force && strstr(force, "v2"));
+        auto gemm = [&](const float* A, int lda, const float* W, const float* b, float* Cc, int ldc, long r, int nt,
+                        int nblk, int S, int act, int valid, int mT, int mskip) {
+            if (allow_v3 && fvad_launch_panel_gemm3(A, lda, W, b, Cc, ldc, r, nt, nblk, S, act, valid, mT, mskip, ctx->n_cu, st) == 0)
+                return 0;
+            return fvad_launch_panel_gemm2(A, lda, W, b, Cc, ldc, r, nt, nblk, S, act, valid, mT, mskip, gw, st);
+        };
         const bool fold = !(force && strstr(force, "nofold"));
         if (fold) {
             time_begin(ctx, "gru1_in_gemm_fc1folded");
-            rc |= fvad_launch_panel_gemm2(ws.feat, kFeatStride, m.gi1f_w.p, m.gi1f_b.p, ws.gi, 1200, rows, 15, 5, 11, FVAD_ACT_NONE, 75, 0, 0, gw, st);
+            rc |= gemm(ws.feat, kFeatStride, m.gi1f_w.p, m.gi1f_b.p, ws.gi, 1200, rows, 15, 5, 11, FVAD_ACT_NONE, 75, 0, 0);
             time_end(ctx);
         } else {
             time_begin(ctx, "fc1_gemm");
             rc |= fvad_launch_panel_gemm(ws.feat, kFeatStride, m.fc1_w.p, m.fc1_b.p, ws.a1, 400, rows, 25, 1, 11, FVAD_ACT_NONE, 0, 0, st);
             time_end(ctx);
             time_begin(ctx, "gru1_in_gemm");
-            rc |= fvad_launch_panel_gemm2(ws.a1, 400, m.gi1v2_w.p, m.gi1_b.p, ws.gi, 1200, rows, 15, 5, 25, FVAD_ACT_NONE, 75, 0, 0, gw, st);
+            rc |= gemm(ws.a1, 400, m.gi1v2_w.p, m.gi1_b.p, ws.gi, 1200, rows, 15, 5, 25, FVAD_ACT_NONE, 75, 0, 0);
             time_end(ctx);
         }
         time_begin(ctx, "gru1_rec");
         rc |= launch_gru(ctx, ws.gi, m.r1, m.r1v2, m.br1.p, ws.h1, n_pad, T);
         time_end(ctx);
         time_begin(ctx, "gru2_in_gemm");
-        rc |= fvad_launch_panel_gemm2(ws.h1, 400, m.gi2v2_w.p, m.gi2_b.p, ws.gi, 1200, rows, 15, 5, 25, FVAD_ACT_NONE, 75, 0, 0, gw, st);
+        rc |= gemm(ws.h1, 400, m.gi2v2_w.p, m.gi2_b.p, ws.gi, 1200, rows, 15, 5, 25, FVAD_ACT_NONE, 75, 0, 0);
         time_end(ctx);
         time_begin(ctx, "gru2_rec");
         rc |= launch_gru(ctx, ws.gi, m.r2, m.r2v2, m.br2.p, ws.h2, n_pad, T);
         time_end(ctx);
         time_begin(ctx, "fc2_gemm");
-        rc |= fvad_launch_panel_gemm2(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, 38, skip ? T : 0, skip, 8, st);
+        rc |= gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, 38, skip ? T : 0, skip);
         time_end(ctx);
         time_begin(ctx, "fc3_gemm");
-        rc |= fvad_launch_panel_gemm2(ws.f2, 608, m.fc3_w.p, m.fc3_b.p, ws.f3, 608, rows_out, 19, 2, 38, FVAD_ACT_RELU, 38, 0, 0, 8, st);
+        rc |= gemm(ws.f2, 608, m.fc3_w.p, m.fc3_b.p, ws.f3, 608, rows_out, 19, 2, 38, FVAD_ACT_RELU, 38, 0, 0);
         time_end(ctx);
         time_begin(ctx, "fc4_gemm");
-        rc |= fvad_launch_panel_gemm2(ws.f3, 608, m.fc4_w.p, m.fc4_b.p, ws.gains, kFeatStride, rows_out, 11, 1, 38, FVAD_ACT_SIGMOID, 11, 0, 0, gw, st);
+        rc |= gemm(ws.f3, 608, m.fc4_w.p, m.fc4_b.p, ws.gains, kFeatStride, rows_out, 11, 1, 38, FVAD_ACT_SIGMOID, 11, 0, 0);
         time_end(ctx);
         if (rc) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "no kernel instance for this layer shape");
         FVAD_HIP(ctx, hipGetLastError());
@@ -383,9 +393,11 @@ int fvad_ctx_create(int device, fvad_ctx** out)
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return FVAD_ERR_NO_DEVICE;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FVAD_ERR_NO_DEVICE; // code objects are gfx950-only
     if (hipSetDevice(device) != hipSuccess) return FVAD_ERR_NO_DEVICE;
+    const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     auto* ctx = new (std::nothrow) fvad_ctx();
     if (!ctx) return FVAD_ERR_ALLOC_FAILED;
     ctx->device = device;
+    ctx->n_cu = n_cu;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return FVAD_ERR_HIP; }
 
     // constant tables: one device allocation, sub-ranges 64-float aligned

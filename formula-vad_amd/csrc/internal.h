@@ -76,6 +76,7 @@ struct KernelTime {
 
 struct fvad_ctx {
     int device = 0;
+    int n_cu = 256; // compute units: size of the persistent GEMM grid
     hipStream_t stream = nullptr;
     mutable std::string err;
     // constant tables

@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -52,13 +53,14 @@ __global__ __launch_bounds__(WAVES * 64) void panel_gemm_kernel(
 
     // Row mapping: when row_map_T > 0 the kernel's compact row index i addresses only rows
     // skip..T-1 of every T-row sequence of A (used to run fc2..fc4 on rows 4..53 only).
-    long row = (long)(blockIdx.x * WAVES + wave) * 16 + m;
-    long a_row = row;
+    const unsigned row = (blockIdx.x * WAVES + wave) * 16 + m;
+    unsigned a_row = row;
     if (row_map_T > 0) {
-        const int per = row_map_T - row_map_skip;
-        a_row = (row / per) * row_map_T + row_map_skip + (row % per);
+        const unsigned per = (unsigned)(row_map_T - row_map_skip);
+        const unsigned qd = row / per;
+        a_row = qd * (unsigned)row_map_T + (unsigned)row_map_skip + (row - qd * per);
     }
-    const float* a_ptr = A + a_row * (long)lda + 4 * q;
+    const float* a_ptr = A + (size_t)a_row * (size_t)lda + 4 * q;
     const float* w_src = Wfrag + (size_t)nblk * S_steps * (NT * 256);
 
     f32x4 acc[NT];
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(WAVES * 64) void panel_gemm_kernel(
         __syncthreads();
     }
 
-    float* c_ptr = C + row * (long)ldc + nblk * (NT * 16) + 4 * q;
+    float* c_ptr = C + (size_t)row * (size_t)ldc + nblk * (NT * 16) + 4 * q;
     const float* b_ptr = bias + nblk * (NT * 16) + 4 * q;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -180,20 +182,23 @@ __global__ __launch_bounds__(WAVES * 64) void panel_gemm2_kernel(
     const int wave = tid >> 6;
     const int m = lane & 15;
     const int q = lane >> 4;
-    const int nblk = blockIdx.x % n_blocks;
-    const long panel = blockIdx.x / n_blocks;
+    // all index arithmetic in 32 bits (rows < 2^31): 64-bit integer division is a several-hundred-
+    // instruction software routine on the GPU and this runs once per workgroup
+    const unsigned nblk = blockIdx.x % (unsigned)n_blocks;
+    const unsigned panel = blockIdx.x / (unsigned)n_blocks;
 
     const float* a_ptr[RT];
-    long c_row[RT];
+    unsigned c_row[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        const long row = ((panel * WAVES + wave) * RT + rt) * 16 + m;
-        long a_row = row;
+        const unsigned row = ((panel * WAVES + wave) * RT + rt) * 16 + m;
+        unsigned a_row = row;
         if (row_map_T > 0) {
-            const int per = row_map_T - row_map_skip;
-            a_row = (row / per) * row_map_T + row_map_skip + (row % per);
+            const unsigned per = (unsigned)(row_map_T - row_map_skip);
+            const unsigned qd = row / per;
+            a_row = qd * (unsigned)row_map_T + (unsigned)row_map_skip + (row - qd * per);
         }
-        a_ptr[rt] = A + a_row * (long)lda + 4 * q;
+        a_ptr[rt] = A + (size_t)a_row * (size_t)lda + 4 * q;
         c_row[rt] = row;
     }
     const float* w_src = Wfrag + (size_t)nblk * S_steps * (NT * 256);
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(WAVES * 64) void panel_gemm2_kernel(
                 } else if (ACT == FVAD_ACT_SIGMOID) {
                     v.x = act_sigmoid(v.x); v.y = act_sigmoid(v.y); v.z = act_sigmoid(v.z); v.w = act_sigmoid(v.w);
                 }
-                *reinterpret_cast<f32x4*>(C + c_row[rt] * (long)ldc + nblk * (NT * 16) + 4 * q + 16 * t) = v;
+                *reinterpret_cast<f32x4*>(C + (size_t)c_row[rt] * (size_t)ldc + nblk * (NT * 16) + 4 * q + 16 * t) = v;
             }
         }
     }
@@ -290,6 +295,242 @@ int fvad_launch_panel_gemm2(const float* A, int lda, const float* Wfrag, const f
     CASE2(11, FVAD_ACT_SIGMOID, 6, 8)
     CASE2(11, FVAD_ACT_SIGMOID, 6, 12)
 #undef CASE2
+    return -1;
+}
+
+// ------------------------------------------------------------------ panel GEMM, v3 (persistent)
+// Device timestamps (s_memtime) of panel_gemm2 showed where its missing ~20 % went:
+//   * the compiler guards every ds_read behind s_waitcnt vmcnt(0) while an LDS-DMA is in flight (it
+//     cannot prove the DMA targets the *other* slab buffer), so the first super-step of each phase
+//     stalled for the whole next-slab DMA and the first super-step after an epilogue stalled until
+//     all 30 accumulator stores were acknowledged by memory;
+//   * all NT fragment reads of a super-step were issued together and waited for with lgkmcnt(0),
+//     which leaves a wavefront that runs alone on its SIMD (the two wavefronts of a SIMD are not
+//     arbitrated fairly, one finishes a phase ~25 % early) at ~70 % of the MFMA rate.
+// This kernel therefore
+//   * is persistent: a workgroup walks items blockIdx.x, +gridDim.x, ... as one flat sequence of
+//     phases, so the next item's first slab, first activations and bias block are in flight during
+//     the current item's last phase;
+//   * reads fragment blocks with inline ds_read_b128 + explicit lgkmcnt waits, one super-step ahead:
+//     the read of tile t for step s+1 is issued right after the MFMAs of tile t in step s, so every
+//     wait is lgkmcnt(NT-1) on data requested ~NT MFMA groups earlier; the compiler no longer sees
+//     LDS reads that could alias the DMA;
+//   * loads the activations of the next item's first two super-steps before the epilogue stores
+//     (vmcnt retires in order on gfx9: a load issued after the stores cannot be waited for without
+//     waiting for the stores too), so the stores have two super-steps to drain in the background.
+template <int T, int N> struct StaticFor {
+    template <class F> static __device__ __forceinline__ void run(F&& f) {
+        f(std::integral_constant<int, T>{});
+        StaticFor<T + 1, N>::run(f);
+    }
+};
+template <int N> struct StaticFor<N, N> {
+    template <class F> static __device__ __forceinline__ void run(F&&) {}
+};
+
+template <int OFF> __device__ __forceinline__ void lds_read_b128(f32x4& dst, unsigned addr)
+{
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void lds_wait(f32x4& dst)
+{
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(dst) : "n"(N));
+}
+
+template <int NT, int RT, int ACT, int SP, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void panel_gemm3_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ Wfrag,
+    const float* __restrict__ bias, float* __restrict__ C, int ldc, int S_steps, int n_blocks,
+    int n_valid_tiles, int row_map_T, int row_map_skip, unsigned n_items)
+{
+    __shared__ __attribute__((aligned(16))) float slab[2][NT * SP * 256];
+    __shared__ __attribute__((aligned(16))) float sbias[2][NT * 16];
+    typedef __attribute__((address_space(3))) float lds_float;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: DMA addresses stay in SGPRs
+    const int m = lane & 15;
+    const int q = lane >> 4;
+    const int P = (S_steps + SP - 1) / SP;
+    constexpr int WAITN = (NT - 1 < 15) ? NT - 1 : 15; // lgkmcnt is a 4-bit field
+
+    auto a_pointer = [&](unsigned item, int rt) -> const float* {
+        const unsigned panel = item / (unsigned)n_blocks;
+        const unsigned row = ((panel * WAVES + wave) * RT + rt) * 16 + m;
+        unsigned a_row = row;
+        if (row_map_T > 0) {
+            const unsigned per = (unsigned)(row_map_T - row_map_skip);
+            const unsigned qd = row / per;
+            a_row = qd * (unsigned)row_map_T + (unsigned)row_map_skip + (row - qd * per);
+        }
+        return A + (size_t)a_row * (size_t)lda + 4 * q;
+    };
+    // every wavefront issues the same, compile-time number of DMA instructions per phase (surplus
+    // ones repeat the last block), which lets the compiler count them in its vmcnt bookkeeping
+    auto issue = [&](unsigned item, int p, float* dst) {
+        const int nblk = (int)(item % (unsigned)n_blocks);
+        const int s0 = p * SP;
+        const int cnt = (S_steps - s0 < SP) ? (S_steps - s0) : SP;
+        const float* src = Wfrag + ((size_t)nblk * S_steps + s0) * (NT * 256);
+        const int nb = NT * cnt;
+        constexpr int PER = (NT * SP + WAVES - 1) / WAVES;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int b = wave + i * WAVES;
+            b = b < nb ? b : nb - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + b * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(dst + b * 256), 16, 0, 0);
+        }
+    };
+    auto stage_bias = [&](unsigned item, float* dst) {
+        const int nblk = (int)(item % (unsigned)n_blocks);
+        if (tid < NT * 4) reinterpret_cast<f32x4*>(dst)[tid] = reinterpret_cast<const f32x4*>(bias + nblk * (NT * 16))[tid];
+    };
+
+    unsigned item = blockIdx.x;
+    if (item >= n_items) return;
+    const unsigned slab_addr[2] = {(unsigned)(uintptr_t)(lds_float*)slab[0] + (unsigned)lane * 16u,
+                                   (unsigned)(uintptr_t)(lds_float*)slab[1] + (unsigned)lane * 16u};
+    typedef const __attribute__((address_space(1))) f32x4* gptr4; // keep these global_load, not flat_load
+    const float* a_ptr[RT];
+    f32x4 a0[RT], apre[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        a_ptr[rt] = a_pointer(item, rt);
+        a0[rt] = *(gptr4)(a_ptr[rt]);
+        apre[rt] = *(gptr4)(a_ptr[rt] + 16);
+    }
+    issue(item, 0, slab[0]);
+    stage_bias(item, sbias[0]);
+    __syncthreads();
+    int buf = 0, bbuf = 0;
+
+    for (; item < n_items; item += gridDim.x) {
+        const unsigned next_item = item + gridDim.x;
+        const bool has_next = next_item < n_items;
+        // accumulators start from the bias: the epilogue competes with the SIMD partner's MFMAs for
+        // VALU issue slots, so it should be little more than the stores
+        f32x4 acc[RT][NT];
+        {
+            const f32x4* bl = reinterpret_cast<const f32x4*>(sbias[bbuf]) + q;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 b4 = bl[4 * t];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][t] = b4;
+            }
+        }
+        const float* a_nextitem[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a_nextitem[rt] = has_next ? a_pointer(next_item, rt) : a_ptr[rt];
+
+        for (int p = 0; p < P; ++p) {
+            const int s0 = p * SP;
+            const int cnt = (S_steps - s0 < SP) ? (S_steps - s0) : SP;
+            if (p + 1 < P) issue(item, p + 1, slab[buf ^ 1]);
+            else if (has_next) { issue(next_item, 0, slab[buf ^ 1]); stage_bias(next_item, sbias[bbuf ^ 1]); }
+
+            unsigned rd = slab_addr[buf];
+            f32x4 w[NT];
+            StaticFor<0, NT>::run([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                lds_read_b128<t * 1024>(w[t], rd);
+            });
+            for (int s = 0; s < cnt; ++s) {
+                const int sg = s0 + s;
+                f32x4 a1[RT];
+                if (sg == 0) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) a1[rt] = apre[rt]; // requested before the previous epilogue
+                } else {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        a1[rt] = *(gptr4)((sg + 1 < S_steps) ? a_ptr[rt] + 16 * (sg + 1) : a_nextitem[rt]);
+                }
+                auto mfmas = [&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w[t].x, a0[rt].x, acc[rt][t]);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w[t].y, a0[rt].y, acc[rt][t]);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w[t].z, a0[rt].z, acc[rt][t]);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w[t].w, a0[rt].w, acc[rt][t]);
+                };
+                // The read of tile t for the next super-step follows tile t's MFMAs, so every wait below
+                // sees exactly NT-1 younger reads in flight.  In the last step of a phase the next data
+                // is not in LDS yet (other buffer, after the barrier): read this step's tile again so the
+                // count stays uniform; the post-barrier reads overwrite w[].
+                const unsigned rdn = (s + 1 < cnt) ? rd : rd - NT * 1024;
+                StaticFor<0, NT>::run([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    lds_wait<WAITN>(w[t]);
+                    mfmas(tc);
+                    lds_read_b128<(NT + t) * 1024>(w[t], rdn);
+                });
+                rd += NT * 1024;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a0[rt] = a1[rt];
+            }
+            __syncthreads(); // next phase's weights (and bias block) landed; this buffer is free again
+            buf ^= 1;
+        }
+
+        // epilogue of this item; the next item's first slab is already in LDS
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) apre[rt] = *(gptr4)(a_nextitem[rt] + 16);
+        const int nblk = (int)(item % (unsigned)n_blocks);
+        const unsigned panel = item / (unsigned)n_blocks;
+        float* c_ptr[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const unsigned row = ((panel * WAVES + wave) * RT + rt) * 16 + m;
+            c_ptr[rt] = C + (size_t)row * (size_t)ldc + nblk * (NT * 16) + 4 * q;
+        }
+        const int valid_t = n_valid_tiles - nblk * NT;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t < valid_t) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    f32x4 v = acc[rt][t];
+                    if (ACT == FVAD_ACT_RELU) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    } else if (ACT == FVAD_ACT_SIGMOID) {
+                        v.x = act_sigmoid(v.x); v.y = act_sigmoid(v.y); v.z = act_sigmoid(v.z); v.w = act_sigmoid(v.w);
+                    }
+                    *reinterpret_cast<f32x4*>(c_ptr[rt] + 16 * t) = v;
+                }
+            }
+        }
+        bbuf ^= 1;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a_ptr[rt] = a_nextitem[rt];
+    }
+}
+
+// rows must be a multiple of 256; grid = one persistent workgroup per CU.  Returns -1 when there is no
+// instance for (nt, act): the caller falls back to panel_gemm2.
+int fvad_launch_panel_gemm3(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
+                            int ldc, long rows, int nt, int n_blocks, int S_steps, int act,
+                            int n_valid_tiles, int map_T, int map_skip, int n_wg, hipStream_t stream)
+{
+    if (rows % 256) return -1;
+    const unsigned n_items = (unsigned)((rows / 256) * n_blocks);
+    const unsigned grid = n_items < (unsigned)n_wg ? n_items : (unsigned)n_wg;
+#define CASE3(NT_, ACT_, SP_)                                                                         \
+    if (nt == NT_ && act == ACT_) {                                                                   \
+        hipLaunchKernelGGL((panel_gemm3_kernel<NT_, 2, ACT_, SP_, 8>), dim3(grid), dim3(512), 0, stream, \
+                           A, lda, Wfrag, bias, C, ldc, S_steps, n_blocks, n_valid_tiles, map_T,      \
+                           map_skip, n_items);                                                        \
+        return 0;                                                                                     \
+    }
+    // no 19-tile (fc2/fc3) instance: 152 accumulator + 76 fragment registers do not fit 256 VGPRs
+    CASE3(15, FVAD_ACT_NONE, 5)
+    CASE3(11, FVAD_ACT_SIGMOID, 6)
+#undef CASE3
     return -1;
 }
 
