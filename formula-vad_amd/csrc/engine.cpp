@@ -107,6 +107,12 @@ int upload_model(fvad_ctx* ctx)
         pack_panel(wf.data(), 1200, 161, 5, 15, 11, f);
         if ((rc = upload(ctx, m.gi1f_w, f))) return rc;
         if ((rc = upload(ctx, m.gi1f_b, bf))) return rc;
+        // gru_rec3_kernel adds only the n-gate recurrent bias itself: for z and r, Wb + Rb is one constant
+        for (int o = 0; o < 2 * H; ++o) bf[o] += w.gru1_b[3 * H + o];
+        if ((rc = upload(ctx, m.gi1f_bzr, bf))) return rc;
+        std::vector<float> b2(w.gru2_b.begin(), w.gru2_b.begin() + 3 * H);
+        for (int o = 0; o < 2 * H; ++o) b2[o] += w.gru2_b[3 * H + o];
+        if ((rc = upload(ctx, m.gi2_bzr, b2))) return rc;
     }
     // fc2: 400 -> 600 (N padded to 608 = 2 blocks of 19 tiles)
     pack_panel(w.fc2_w.data(), 600, 400, 2, 19, 25, f);
@@ -178,23 +184,57 @@ void time_end(fvad_ctx* ctx)
     hipEventRecord(ctx->times.back().e1, ctx->stream);
 }
 
-// Large batches: the LDS-DMA kernel with 128 (or 64) sequences per workgroup; small batches keep
+// Large batches: the LDS-DMA kernels with 192 / 128 / 64 sequences per workgroup; small batches keep
 // one wavefront (16 sequences) per workgroup so that more CUs take part.
-static int launch_gru(fvad_ctx* ctx, const float* gi, const DevBuf& r_v1, const DevBuf& r_v2, const float* bR,
+struct GruChoice {
+    int version; // 1: gru_rec, 2: gru_rec2, 3: gru_rec3 (expects the z/r recurrent biases folded into gi)
+    int waves;
+};
+
+// Measured cycles per (time step, unit tile) of one workgroup on MI355X; a launch costs
+// ceil(workgroups / CUs) rounds of that.  The workgroup shapes trade sequences per CU against
+// wavefronts per SIMD: 192 sequences (12 waves), 128 (8) or 64 (4).
+static double gru_cost(long n_pad, int waves, int n_cu)
+{
+    const double per_tile = waves == 12 ? 32.3e3 : waves == 8 ? 23.4e3 : 13.0e3;
+    const long wgs = n_pad / (16 * waves);
+    return (double)((wgs + n_cu - 1) / n_cu) * per_tile;
+}
+
+// Batch padding: the 12-wave recurrence needs a multiple of 192 sequences and the GEMM row panels a
+// multiple of 256 rows (of 54 and of 50 rows per sequence), i.e. 384 sequences; the 8- and 4-wave
+// shapes need 128.  Pick whichever padding gives the cheaper recurrence.
+static long padded_batch(const fvad_ctx* ctx, long n)
+{
+    const long a = (n + 383) / 384 * 384, b = (n + 127) / 128 * 128;
+    if (getenv("FVAD_GRU_KERNEL") || a == b) return a;
+    const double cost_a = std::min(gru_cost(a, 12, ctx->n_cu), std::min(gru_cost(a, 8, ctx->n_cu), gru_cost(a, 4, ctx->n_cu)));
+    const double cost_b = std::min(gru_cost(b, 8, ctx->n_cu), gru_cost(b, 4, ctx->n_cu));
+    return cost_b < cost_a ? b : a;
+}
+
+static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, bool allow_v3)
+{
+    const char* force = getenv("FVAD_GRU_KERNEL"); // tuning aid: "v1w4", "v2w8", "v3w12", ...
+    if (force) {
+        GruChoice c{force[1] - '0', atoi(force + 3)};
+        if (c.version == 3 && !allow_v3) c.version = 2;
+        return c;
+    }
+    if (n_pad / 64 < 64) return {1, 1};
+    int best = 4;
+    if (gru_cost(n_pad, 8, ctx->n_cu) < gru_cost(n_pad, best, ctx->n_cu)) best = 8;
+    if (n_pad % 192 == 0 && gru_cost(n_pad, 12, ctx->n_cu) < gru_cost(n_pad, best, ctx->n_cu)) best = 12;
+    return {allow_v3 ? 3 : 2, best};
+}
+
+static int launch_gru(fvad_ctx* ctx, GruChoice c, const float* gi, const DevBuf& r_v1, const DevBuf& r_v2, const float* bR,
                       float* hout, long n_pad, int T)
 {
-    const char* force = getenv("FVAD_GRU_KERNEL"); // tuning aid: "v1w4", "v2w8", ...
-    if (force) {
-        const int w = atoi(force + 3);
-        const int real_w = (w == 13) ? 12 : (w == 9) ? 8 : w;
-        if (n_pad % (16 * real_w)) return -1;
-        if (force[1] == '2') return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, w, ctx->stream);
-        return fvad_launch_gru_rec(gi, r_v1.p, bR, hout, n_pad, T, w, ctx->stream);
-    }
-    if (n_pad / 192 >= 256) return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, 12, ctx->stream);
-    if (n_pad / 128 >= 256) return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, 8, ctx->stream);
-    if (n_pad / 64 >= 64) return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, 4, ctx->stream);
-    return fvad_launch_gru_rec(gi, r_v1.p, bR, hout, n_pad, T, 1, ctx->stream);
+    if (c.waves <= 0 || n_pad % (16 * c.waves)) return -1;
+    if (c.version == 3) return fvad_launch_gru_rec3(gi, r_v2.p, bR, hout, n_pad, T, c.waves, ctx->stream);
+    if (c.version == 2) return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, c.waves, ctx->stream);
+    return fvad_launch_gru_rec(gi, r_v1.p, bR, hout, n_pad, T, c.waves, ctx->stream);
 }
 
 int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
@@ -223,9 +263,11 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
             return fvad_launch_panel_gemm2(A, lda, W, b, Cc, ldc, r, nt, nblk, S, act, valid, mT, mskip, gw, st);
         };
         const bool fold = !(force && strstr(force, "nofold"));
+        const GruChoice gc = pick_gru(ctx, n_pad, fold);
+        const bool bzr = gc.version == 3;
         if (fold) {
             time_begin(ctx, "gru1_in_gemm_fc1folded");
-            rc |= gemm(ws.feat, kFeatStride, m.gi1f_w.p, m.gi1f_b.p, ws.gi, 1200, rows, 15, 5, 11, FVAD_ACT_NONE, 75, 0, 0);
+            rc |= gemm(ws.feat, kFeatStride, m.gi1f_w.p, bzr ? m.gi1f_bzr.p : m.gi1f_b.p, ws.gi, 1200, rows, 15, 5, 11, FVAD_ACT_NONE, 75, 0, 0);
             time_end(ctx);
         } else {
             time_begin(ctx, "fc1_gemm");
@@ -236,13 +278,13 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
             time_end(ctx);
         }
         time_begin(ctx, "gru1_rec");
-        rc |= launch_gru(ctx, ws.gi, m.r1, m.r1v2, m.br1.p, ws.h1, n_pad, T);
+        rc |= launch_gru(ctx, gc, ws.gi, m.r1, m.r1v2, m.br1.p, ws.h1, n_pad, T);
         time_end(ctx);
         time_begin(ctx, "gru2_in_gemm");
-        rc |= gemm(ws.h1, 400, m.gi2v2_w.p, m.gi2_b.p, ws.gi, 1200, rows, 15, 5, 25, FVAD_ACT_NONE, 75, 0, 0);
+        rc |= gemm(ws.h1, 400, m.gi2v2_w.p, bzr ? m.gi2_bzr.p : m.gi2_b.p, ws.gi, 1200, rows, 15, 5, 25, FVAD_ACT_NONE, 75, 0, 0);
         time_end(ctx);
         time_begin(ctx, "gru2_rec");
-        rc |= launch_gru(ctx, ws.gi, m.r2, m.r2v2, m.br2.p, ws.h2, n_pad, T);
+        rc |= launch_gru(ctx, gc, ws.gi, m.r2, m.r2v2, m.br2.p, ws.h2, n_pad, T);
         time_end(ctx);
         time_begin(ctx, "fc2_gemm");
         rc |= gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, 38, skip ? T : 0, skip);
@@ -264,13 +306,14 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     rc |= fvad_launch_panel_gemm(ws.a1, 400, m.gi1_w.p, m.gi1_b.p, ws.gi, 1200, rows, 25, 3, 25, FVAD_ACT_NONE, 0, 0, st);
     time_end(ctx);
     time_begin(ctx, "gru1_rec");
-    rc |= launch_gru(ctx, ws.gi, m.r1, m.r1v2, m.br1.p, ws.h1, n_pad, T);
+    const GruChoice gcs = pick_gru(ctx, n_pad, false);
+    rc |= launch_gru(ctx, gcs, ws.gi, m.r1, m.r1v2, m.br1.p, ws.h1, n_pad, T);
     time_end(ctx);
     time_begin(ctx, "gru2_in_gemm");
     rc |= fvad_launch_panel_gemm(ws.h1, 400, m.gi2_w.p, m.gi2_b.p, ws.gi, 1200, rows, 25, 3, 25, FVAD_ACT_NONE, 0, 0, st);
     time_end(ctx);
     time_begin(ctx, "gru2_rec");
-    rc |= launch_gru(ctx, ws.gi, m.r2, m.r2v2, m.br2.p, ws.h2, n_pad, T);
+    rc |= launch_gru(ctx, gcs, ws.gi, m.r2, m.r2v2, m.br2.p, ws.h2, n_pad, T);
     time_end(ctx);
     time_begin(ctx, "fc2_gemm");
     rc |= fvad_launch_panel_gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, skip ? T : 0, skip, st);
@@ -332,7 +375,7 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks)
         time_begin(ctx, "stft320_logpow");
         fvad_launch_stft(ws.descs, (int)n, ctx->tb, ws.feat, ws.spec, ctx->stream);
         time_end(ctx);
-        const long n_pad = ((n + 383) / 384) * 384;
+        const long n_pad = padded_batch(ctx, n);
         rc = run_nn(ctx, n_pad, kRowsPerChunk, kWarmupRows);
         if (rc) return rc;
         time_begin(ctx, "istft320_ola_up3");
@@ -449,7 +492,7 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     if (ws.h_fft_jobs) hipHostFree(ws.h_fft_jobs);
     DeviceModel& m = ctx->dm;
     DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.gi1_w, &m.gi1_b, &m.r1, &m.br1, &m.gi2_w, &m.gi2_b, &m.r2, &m.br2,
-                      &m.fc2_w, &m.fc2_b, &m.fc3_w, &m.fc3_b, &m.fc4_w, &m.fc4_b, &m.r1v2, &m.r2v2, &m.gi1f_w, &m.gi1f_b, &m.gi1v2_w, &m.gi2v2_w};
+                      &m.fc2_w, &m.fc2_b, &m.fc3_w, &m.fc3_b, &m.fc4_w, &m.fc4_b, &m.r1v2, &m.r2v2, &m.gi1f_w, &m.gi1f_b, &m.gi1v2_w, &m.gi2v2_w, &m.gi1f_bzr, &m.gi2_bzr};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (ctx->d_tables) hipFree(ctx->d_tables);
     for (auto& kt : ctx->times) { hipEventDestroy(kt.e0); hipEventDestroy(kt.e1); }
@@ -550,7 +593,7 @@ int fvad_nsnet2_forward(fvad_ctx* ctx, const float* features, size_t n_seq, size
     int rc = ensure_workspace(ctx, (long)n_seq, (int)T);
     if (rc) return rc;
     Workspace& ws = ctx->ws;
-    const long n_pad = (((long)n_seq + 383) / 384) * 384;
+    const long n_pad = padded_batch(ctx, (long)n_seq);
     // rows are [n_seq*T][161] on the host, [.][176] on the device
     FVAD_HIP(ctx, hipMemsetAsync(ws.feat, 0, (size_t)n_pad * T * kFeatStride * sizeof(float), ctx->stream));
     FVAD_HIP(ctx, hipMemcpy2DAsync(ws.feat, kFeatStride * sizeof(float), features, kNBins * sizeof(float),

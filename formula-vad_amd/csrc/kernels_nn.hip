@@ -817,6 +817,171 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec2_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------ GRU recurrence, v3
+// gru_rec2_kernel with the two stalls its device timeline showed removed (same cure as panel_gemm3):
+//   * fragment reads are inline ds_read_b128 with explicit lgkmcnt waits, two super-steps of (z, r, n)
+//     blocks in flight, so the compiler no longer puts s_waitcnt vmcnt(0) (= "next slab's DMA has
+//     landed") in front of the first LDS read of every unit tile;
+//   * gi already contains Wb + Rb for the z and r gates (folded on the host), only the n gate's Rb is
+//     added here: two loads and eight registers less per unit tile;
+//   * the end-of-tile barrier waits with vmcnt(1): everything up to the slab DMA, but not the h store
+//     issued just before it (__syncthreads() would wait for that store's acknowledgement too).
+// wave must be wave-uniform (SGPR): the DMA then addresses global memory as scalar base + lane * 16
+template <int WAVES>
+__device__ __forceinline__ void gru3_issue_slab(const float* __restrict__ src, float* lds_dst, int wave, unsigned lane16)
+{
+    asm volatile("" : "+v"(lane16)); // keep the lane offset a 32-bit VGPR instead of a hoisted 64-bit address
+#pragma unroll
+    for (int b = wave; b < 3 * GRU_J; b += WAVES) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)((const __attribute__((address_space(1))) char*)src + b * 1024 + lane16),
+            (__attribute__((address_space(3))) void*)(lds_dst + b * 256), 16, 0, 0);
+    }
+}
+
+template <int WAVES, int D>
+__global__ __launch_bounds__(WAVES * 64) void gru_rec3_kernel(const float* __restrict__ gi,
+                                                              const float* __restrict__ R2frag,
+                                                              const float* __restrict__ bR,
+                                                              float* hout, int T)
+{
+    __shared__ __attribute__((aligned(16))) float slab[2][GRU2_SLAB];
+    typedef __attribute__((address_space(3))) float lds_float;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15;
+    const int q = lane >> 4;
+    // Addresses are a scalar base (workgroup, wavefront, t, J) plus one 32-bit per-lane byte offset per
+    // array, so that the loads take the saddr + voffset form and the 100 registers of h_{t-1} leave room
+    // for three wavefronts per SIMD.
+    typedef const __attribute__((address_space(1))) char* gbytes;
+    const size_t seq0 = (size_t)(blockIdx.x * WAVES + wave) * 16;
+    gbytes gi_w = (gbytes)(gi + seq0 * T * (3 * GRU_H));
+    __attribute__((address_space(1))) char* h_w = (__attribute__((address_space(1))) char*)(hout + seq0 * T * GRU_H);
+    gbytes bR_b = (gbytes)bR;
+    const unsigned gi_off = ((unsigned)m * (unsigned)T * (3 * GRU_H) + 4u * q) * 4u;
+    const unsigned h_off = ((unsigned)m * (unsigned)T * GRU_H + 4u * q) * 4u;
+    const unsigned b_off = 16u * q;
+    // the empty asm keeps the compiler from folding the lane offset into a hoisted 64-bit VGPR base
+    auto ld4 = [](gbytes base, unsigned off) {
+        asm volatile("" : "+v"(off));
+        return *(const __attribute__((address_space(1))) f32x4*)(base + off);
+    };
+    const unsigned slab_addr[2] = {(unsigned)(uintptr_t)(lds_float*)slab[0] + (unsigned)lane * 16u,
+                                   (unsigned)(uintptr_t)(lds_float*)slab[1] + (unsigned)lane * 16u};
+
+    gru3_issue_slab<WAVES>(R2frag, slab[0], wave, (unsigned)lane * 16u);
+
+    // ---- t = 0: h_{-1} = 0, so R h + Rb = Rb
+    for (int J = 0; J < GRU_J; ++J) {
+        const f32x4 giz = ld4(gi_w + 64 * J, gi_off);
+        const f32x4 gir = ld4(gi_w + 64 * J + 4 * GRU_H, gi_off);
+        const f32x4 gin = ld4(gi_w + 64 * J + 8 * GRU_H, gi_off);
+        const f32x4 bn = ld4(bR_b + 64 * J + 8 * GRU_H, b_off);
+        f32x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float z = fast_sigmoid(giz[r]);
+            const float rr = fast_sigmoid(gir[r]);
+            const float n = fast_tanh(gin[r] + rr * bn[r]);
+            h[r] = (1.0f - z) * n + z * 0.0f;
+        }
+        *(__attribute__((address_space(1))) f32x4*)(h_w + 64 * J + h_off) = h;
+    }
+    __syncthreads(); // drains the LDS-DMA (vmcnt) and publishes slab 0
+    int buf = 0;
+
+    for (int t = 1; t < T; ++t) {
+        gbytes gi_t = gi_w + (size_t)t * (12 * GRU_H);
+        gbytes h_prev = (gbytes)h_w + (size_t)(t - 1) * (4 * GRU_H);
+        __attribute__((address_space(1))) char* h_out = h_w + (size_t)t * (4 * GRU_H);
+
+        f32x4 hreg[GRU_J];
+#pragma unroll
+        for (int S = 0; S < GRU_J; ++S) hreg[S] = ld4(h_prev + 64 * S, h_off);
+        // Consume h_{t-1} here, once per step: otherwise the compiler's wait for these loads sits in front
+        // of the first MFMA of every unit tile as s_waitcnt vmcnt(0), i.e. behind that tile's slab DMA.
+#pragma unroll
+        for (int S = 0; S < GRU_J; ++S) asm volatile("" : "+v"(hreg[S]));
+
+        for (int J = 0; J < GRU_J; ++J) {
+            const int nJ = (J + 1 == GRU_J) ? 0 : J + 1;
+            gru3_issue_slab<WAVES>(R2frag + (size_t)nJ * GRU2_SLAB, slab[buf ^ 1], wave, (unsigned)lane * 16u);
+
+            // one base per gate: the ds_read offset field is 16 bits and the n-gate blocks start at 50 KB
+            const unsigned rdz = slab_addr[buf], rdr = rdz + GRU_J * 1024, rdn = rdz + 2 * GRU_J * 1024;
+            // ring of D super-steps: slot S % D holds the z, r, n fragment blocks of super-step S
+            f32x4 wz[D], wr[D], wn[D];
+            StaticFor<0, D>::run([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                lds_read_b128<S * 1024>(wz[S], rdz);
+                lds_read_b128<S * 1024>(wr[S], rdr);
+                lds_read_b128<S * 1024>(wn[S], rdn);
+            });
+
+            f32x4 az = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 ar = az, an = az;
+            auto super_step = [&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                constexpr int k = S % D;
+                // younger reads allowed in flight: those of super-steps S+1 .. S+D-1 (fewer near the end)
+                constexpr int ahead = (GRU_J - 1 - S < D - 1) ? GRU_J - 1 - S : D - 1;
+                constexpr int younger = (3 * ahead < 13) ? 3 * ahead : 13; // lgkmcnt is a 4-bit field
+                lds_wait<younger + 2>(wz[k]);
+                const f32x4 hv = hreg[S];
+                az = MFMA16(wz[k].x, hv.x, az);
+                lds_wait<younger + 1>(wr[k]);
+                ar = MFMA16(wr[k].x, hv.x, ar);
+                lds_wait<younger>(wn[k]);
+                an = MFMA16(wn[k].x, hv.x, an);
+                az = MFMA16(wz[k].y, hv.y, az);
+                ar = MFMA16(wr[k].y, hv.y, ar);
+                an = MFMA16(wn[k].y, hv.y, an);
+                az = MFMA16(wz[k].z, hv.z, az);
+                ar = MFMA16(wr[k].z, hv.z, ar);
+                an = MFMA16(wn[k].z, hv.z, an);
+                az = MFMA16(wz[k].w, hv.w, az);
+                ar = MFMA16(wr[k].w, hv.w, ar);
+                an = MFMA16(wn[k].w, hv.w, an);
+                if (S + D < GRU_J) {
+                    lds_read_b128<(S + D) * 1024>(wz[k], rdz);
+                    lds_read_b128<(S + D) * 1024>(wr[k], rdr);
+                    lds_read_b128<(S + D) * 1024>(wn[k], rdn);
+                }
+            };
+            // The gate operands are requested late in the tile (their registers are live only for the
+            // last super-steps) but still several thousand cycles before the gate math needs them.
+            constexpr int LOAD_AT = 18;
+            StaticFor<0, LOAD_AT>::run(super_step);
+            const f32x4 giz = ld4(gi_t + 64 * J, gi_off);
+            const f32x4 gir = ld4(gi_t + 64 * J + 4 * GRU_H, gi_off);
+            const f32x4 gin = ld4(gi_t + 64 * J + 8 * GRU_H, gi_off);
+            const f32x4 hp = ld4(h_prev + 64 * J, h_off);
+            const f32x4 bn = ld4(bR_b + 64 * J + 8 * GRU_H, b_off);
+            StaticFor<LOAD_AT, GRU_J>::run(super_step);
+            f32x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = fast_sigmoid(giz[r] + az[r]);
+                const float rr = fast_sigmoid(gir[r] + ar[r]);
+                const float n = fast_tanh(gin[r] + rr * (an[r] + bn[r]));
+                h[r] = (1.0f - z) * n + z * hp[r];
+            }
+            {
+                unsigned o = h_off;
+                asm volatile("" : "+v"(o));
+                *(__attribute__((address_space(1))) f32x4*)(h_out + 64 * J + o) = h;
+            }
+            // next slab landed (everything older than the h store has retired) and everyone is done
+            // reading this one (all ds_reads were waited for above)
+            asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+            buf ^= 1;
+        }
+    }
+}
+
 int fvad_launch_gru_rec2(const float* gi, const float* R2frag, const float* bR, float* hout,
                          long n_seq_pad, int T, int waves, hipStream_t stream)
 {
@@ -826,6 +991,21 @@ int fvad_launch_gru_rec2(const float* gi, const float* R2frag, const float* bR, 
         hipLaunchKernelGGL((gru_rec2_kernel<8>), dim3((unsigned)(n_seq_pad / 128)), dim3(512), 0, stream, gi, R2frag, bR, hout, T);
     } else if (waves == 4) {
         hipLaunchKernelGGL((gru_rec2_kernel<4>), dim3((unsigned)(n_seq_pad / 64)), dim3(256), 0, stream, gi, R2frag, bR, hout, T);
+    } else {
+        return -1;
+    }
+    return 0;
+}
+
+int fvad_launch_gru_rec3(const float* gi, const float* R2frag, const float* bR, float* hout,
+                         long n_seq_pad, int T, int waves, hipStream_t stream)
+{
+    if (waves == 12) {
+        hipLaunchKernelGGL((gru_rec3_kernel<12, 2>), dim3((unsigned)(n_seq_pad / 192)), dim3(768), 0, stream, gi, R2frag, bR, hout, T);
+    } else if (waves == 8) {
+        hipLaunchKernelGGL((gru_rec3_kernel<8, 2>), dim3((unsigned)(n_seq_pad / 128)), dim3(512), 0, stream, gi, R2frag, bR, hout, T);
+    } else if (waves == 4) {
+        hipLaunchKernelGGL((gru_rec3_kernel<4, 2>), dim3((unsigned)(n_seq_pad / 64)), dim3(256), 0, stream, gi, R2frag, bR, hout, T);
     } else {
         return -1;
     }
