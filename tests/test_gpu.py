@@ -194,6 +194,27 @@ def test_nsnet2_forward_matches_oracle(fv, gpu_ctx, weights7):
     assert np.array_equal(g, g_rev[::-1])
 
 
+@pytest.mark.parametrize("env", [
+    {}, {"FVAD_GRU_KERNEL": "v3w12"}, {"FVAD_GRU_KERNEL": "v3w8"}, {"FVAD_GRU_KERNEL": "v3w4"},
+    {"FVAD_GRU_KERNEL": "v2w12"}, {"FVAD_GRU_KERNEL": "v2w8"}, {"FVAD_GEMM_KERNEL": "v2"},
+    {"FVAD_GEMM_KERNEL": "v2nofold"}, {"FVAD_GEMM_KERNEL": "v1"},
+], ids=lambda e: "-".join(e.values()) or "default")
+def test_nsnet2_large_batch_kernels_match_oracle(fv, gpu_ctx, weights7, env, monkeypatch):
+    # 2100 sequences take the large-batch path (LDS-DMA GEMMs, persistent GEMM, multi-wave recurrence);
+    # every kernel variant the engine can pick for other batch sizes is forced in turn and checked
+    # against the oracle on a sample of sequences spread over the batch (first, last, padding edge)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(11)
+    f = rng.uniform(-11, 2, (2100, 54, 161)).astype(np.float32)
+    f[::7, :2] = 0.0
+    g = gpu_ctx.nsnet2_forward(f)
+    pick = [0, 1, 15, 16, 127, 128, 191, 192, 1023, 1500, 2047, 2048, 2098, 2099]
+    ref = np.stack([orc.nsnet2_forward(weights7, f[i]) for i in pick])
+    assert_rel(g[pick], ref, 1e-4, floor=1e-2, what=f"gains large batch {env}")
+    assert g.min() >= 0 and g.max() <= 1
+
+
 def test_get_weights_roundtrip(fv, gpu_ctx, weights7):
     got = gpu_ctx.weights()
     for k in fv.WEIGHT_NAMES:
