@@ -117,7 +117,7 @@ def pmc_traffic(chunks_per_launch):
         if d["chunks_per_launch"] != min(chunks_per_launch, 49152):
             return None
         for k, v in d["kernels"].items():
-            if k.startswith("gru_rec2_kernel"):
+            if k.startswith("gru_rec3_kernel") or k.startswith("gru_rec2_kernel"):
                 return v["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -296,7 +296,7 @@ def main():
                        "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
             "audio_seconds_per_s": value / 100.0,
             "device_only_frames_per_s": total_frames / dev_elapsed,
-            "roofline": {"bound": "mfma", "kernel": "gru_rec_kernel (fp32 v_mfma_f32_16x16x4_f32)",
+            "roofline": {"bound": "mfma", "kernel": "gru_rec3_kernel<12, 2> (fp32 v_mfma_f32_16x16x4_f32)",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(lanes * n_chunks),
                          "launch_ms": gru_ms, "flop_per_launch": gru_flop},

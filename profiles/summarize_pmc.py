@@ -1,5 +1,6 @@
 """Per-kernel HBM traffic from the rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
-runs of `bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra`, 32768 chunks per launch).
+runs of `bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra`; usage:
+summarize_pmc.py <tag> <chunks_per_launch>, e.g. `r01b 49152`).
 Counter units are KiB.  Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on
 gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads, WRITE_SIZE is exact
 for 16 B/lane stores -> hbm_bytes = 2 * FETCH_SIZE + WRITE_SIZE.  Access shapes here are float4
@@ -12,6 +13,7 @@ import sys
 
 here = os.path.dirname(os.path.abspath(__file__))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+chunks = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 out = {}
 for name, key in (("fetch_size", "fetch_kib"), ("write_size", "write_kib")):
     agg = collections.defaultdict(list)
@@ -23,6 +25,6 @@ for name, key in (("fetch_size", "fetch_kib"), ("write_size", "write_kib")):
         out.setdefault(k, {})[key] = sum(v) / len(v)
 for k, v in out.items():
     v["hbm_bytes_per_launch"] = (2 * v.get("fetch_kib", 0) + v.get("write_kib", 0)) * 1024
-json.dump({"chunks_per_launch": 32768, "kernels": out}, open(os.path.join(here, f"{tag}_pmc_summary.json"), "w"), indent=1)
+json.dump({"chunks_per_launch": chunks, "kernels": out}, open(os.path.join(here, f"{tag}_pmc_summary.json"), "w"), indent=1)
 for k, v in out.items():
     print(f"{k:45s} {v['hbm_bytes_per_launch'] / 1e9:7.2f} GB/launch")
