@@ -122,6 +122,14 @@ int upload_model(fvad_ctx* ctx)
     pack_panel(w.fc3_w.data(), 600, 600, 2, 19, 38, f);
     if ((rc = upload(ctx, m.fc3_w, f))) return rc;
     if ((rc = upload(ctx, m.fc3_b, padded(w.fc3_b.data(), 600, 608)))) return rc;
+    // the same two layers as 3 blocks of 13 tiles (39 tiles, the 39th is padding and never stored):
+    // 104 accumulator + 52 fragment registers fit the persistent kernel, 19-tile blocks do not
+    pack_panel(w.fc2_w.data(), 600, 400, 3, 13, 25, f);
+    if ((rc = upload(ctx, m.fc2v3_w, f))) return rc;
+    if ((rc = upload(ctx, m.fc2v3_b, padded(w.fc2_b.data(), 600, 624)))) return rc;
+    pack_panel(w.fc3_w.data(), 600, 600, 3, 13, 38, f);
+    if ((rc = upload(ctx, m.fc3v3_w, f))) return rc;
+    if ((rc = upload(ctx, m.fc3v3_b, padded(w.fc3_b.data(), 600, 624)))) return rc;
     // fc4: 600 -> 161 (N padded to 176 = 11 tiles)
     pack_panel(w.fc4_w.data(), 161, 600, 1, 11, 38, f);
     if ((rc = upload(ctx, m.fc4_w, f))) return rc;
@@ -287,10 +295,13 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
         rc |= launch_gru(ctx, gc, ws.gi, m.r2, m.r2v2, m.br2.p, ws.h2, n_pad, T);
         time_end(ctx);
         time_begin(ctx, "fc2_gemm");
-        rc |= gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, 38, skip ? T : 0, skip);
+        const bool fc13 = allow_v3 && !(force && strstr(force, "fc19"));
+        if (fc13) rc |= gemm(ws.h2, 400, m.fc2v3_w.p, m.fc2v3_b.p, ws.f2, 608, rows_out, 13, 3, 25, FVAD_ACT_RELU, 38, skip ? T : 0, skip);
+        else rc |= gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, 38, skip ? T : 0, skip);
         time_end(ctx);
         time_begin(ctx, "fc3_gemm");
-        rc |= gemm(ws.f2, 608, m.fc3_w.p, m.fc3_b.p, ws.f3, 608, rows_out, 19, 2, 38, FVAD_ACT_RELU, 38, 0, 0);
+        if (fc13) rc |= gemm(ws.f2, 608, m.fc3v3_w.p, m.fc3v3_b.p, ws.f3, 608, rows_out, 13, 3, 38, FVAD_ACT_RELU, 38, 0, 0);
+        else rc |= gemm(ws.f2, 608, m.fc3_w.p, m.fc3_b.p, ws.f3, 608, rows_out, 19, 2, 38, FVAD_ACT_RELU, 38, 0, 0);
         time_end(ctx);
         time_begin(ctx, "fc4_gemm");
         rc |= gemm(ws.f3, 608, m.fc4_w.p, m.fc4_b.p, ws.gains, kFeatStride, rows_out, 11, 1, 38, FVAD_ACT_SIGMOID, 11, 0, 0);
@@ -492,7 +503,7 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     if (ws.h_fft_jobs) hipHostFree(ws.h_fft_jobs);
     DeviceModel& m = ctx->dm;
     DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.gi1_w, &m.gi1_b, &m.r1, &m.br1, &m.gi2_w, &m.gi2_b, &m.r2, &m.br2,
-                      &m.fc2_w, &m.fc2_b, &m.fc3_w, &m.fc3_b, &m.fc4_w, &m.fc4_b, &m.r1v2, &m.r2v2, &m.gi1f_w, &m.gi1f_b, &m.gi1v2_w, &m.gi2v2_w, &m.gi1f_bzr, &m.gi2_bzr};
+                      &m.fc2_w, &m.fc2_b, &m.fc3_w, &m.fc3_b, &m.fc4_w, &m.fc4_b, &m.r1v2, &m.r2v2, &m.gi1f_w, &m.gi1f_b, &m.gi1v2_w, &m.gi2v2_w, &m.gi1f_bzr, &m.gi2_bzr, &m.fc2v3_w, &m.fc3v3_w, &m.fc2v3_b, &m.fc3v3_b};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (ctx->d_tables) hipFree(ctx->d_tables);
     for (auto& kt : ctx->times) { hipEventDestroy(kt.e0); hipEventDestroy(kt.e1); }

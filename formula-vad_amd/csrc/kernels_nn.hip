@@ -527,8 +527,10 @@ int fvad_launch_panel_gemm3(const float* A, int lda, const float* Wfrag, const f
                            map_skip, n_items);                                                        \
         return 0;                                                                                     \
     }
-    // no 19-tile (fc2/fc3) instance: 152 accumulator + 76 fragment registers do not fit 256 VGPRs
+    // no 19-tile instance: 152 accumulator + 76 fragment registers do not fit 256 VGPRs; fc2/fc3 use
+    // three 13-tile column blocks here
     CASE3(15, FVAD_ACT_NONE, 5)
+    CASE3(13, FVAD_ACT_RELU, 5)
     CASE3(11, FVAD_ACT_SIGMOID, 6)
 #undef CASE3
     return -1;
