@@ -168,6 +168,12 @@ def main():
     results = {}
     host_ms = []
 
+    frame_start = np.arange(n_frames_fft) * 1024
+    frame_chunk = frame_start // CHUNK
+    frame_chunk_end = (frame_start + 1023) // CHUNK
+    w0 = (np.minimum((frame_chunk + 1) * CHUNK, frame_start + 1024) - frame_start).astype(np.float32)
+    w1 = np.float32(1024) - w0
+
     def host_stage(step, slot):
         """band sums + chunk RMS -> per-frame volume ratio -> VAD state machine -> segments"""
         t_h0 = time.perf_counter()
@@ -175,15 +181,11 @@ def main():
         rms = h_rms[slot]
         # mono: ratio = min/max of one channel = 1 (0 for digital silence), BufferedVolumeAnalyzer.zig:48-69
         ratio_chunk = np.where(rms > 0, np.where(rms < 1, 1.0, 1.0 / np.maximum(rms, 1e-30)), 0.0).astype(np.float32)
-        frame_chunk = (np.arange(n_frames_fft) * 1024) // CHUNK
-        frame_chunk_end = (np.arange(n_frames_fft) * 1024 + 1023) // CHUNK
-        w0 = np.minimum((frame_chunk + 1) * CHUNK, np.arange(n_frames_fft) * 1024 + 1024) - np.arange(n_frames_fft) * 1024
-        w0 = w0.astype(np.float32)
-        w1 = np.float32(1024) - w0
-        ratios = []
-        for lane in range(lanes):
-            r0, r1 = ratio_chunk[lane][frame_chunk], ratio_chunk[lane][frame_chunk_end]
-            ratios.append(((r0 * w0 + np.where(w1 > 0, r1 * w1, np.float32(0))) / (w0 + w1)).astype(np.float32))
+        # per-frame metadata = sample-weighted mean of the (at most two) chunks a 1024-sample frame spans,
+        # VADMetadata.zig:36-66; all lanes at once
+        r0, r1 = ratio_chunk[:, frame_chunk], ratio_chunk[:, frame_chunk_end]
+        ratio_all = ((r0 * w0 + np.where(w1 > 0, r1 * w1, np.float32(0))) / (w0 + w1)).astype(np.float32)
+        ratios = [ratio_all[lane] for lane in range(lanes)]
         ms = [fv.VadMachine() for _ in range(lanes)]
         t_h1 = time.perf_counter()
         fv.vad_run_many(ms, [band[lane][:, None] for lane in range(lanes)], ratios, n_threads=vad_threads)
