@@ -195,50 +195,56 @@ void time_end(fvad_ctx* ctx)
 // Large batches: the LDS-DMA kernels with 192 / 128 / 64 sequences per workgroup; small batches keep
 // one wavefront (16 sequences) per workgroup so that more CUs take part.
 struct GruChoice {
-    int version; // 1: gru_rec, 2: gru_rec2, 3: gru_rec3 (expects the z/r recurrent biases folded into gi)
+    int version; // 1: gru_rec, 2: gru_rec2, 3: gru_rec3 (expects the z/r recurrent biases folded into gi),
+                 // 4: gru_lat (16 sequences per workgroup, tiles split over 8 waves)
     int waves;
 };
 
-// Measured cycles per (time step, unit tile) of one workgroup on MI355X; a launch costs
+// Measured cycles per time step of one workgroup on MI355X; a launch costs
 // ceil(workgroups / CUs) rounds of that.  The workgroup shapes trade sequences per CU against
-// wavefronts per SIMD: 192 sequences (12 waves), 128 (8) or 64 (4).
+// wavefronts per SIMD: 192 sequences (12 waves), 128 (8), 64 (4), or the low-latency shape (waves = 0
+// here): 16 sequences with the unit tiles of a step split over 8 waves.
 static double gru_cost(long n_pad, int waves, int n_cu)
 {
-    const double per_tile = waves == 12 ? 32.3e3 : waves == 8 ? 23.4e3 : 13.0e3;
-    const long wgs = n_pad / (16 * waves);
-    return (double)((wgs + n_cu - 1) / n_cu) * per_tile;
+    const double per_step = waves == 12 ? 25 * 32.3e3 : waves == 8 ? 25 * 23.4e3 : waves == 4 ? 25 * 13.0e3 : 120e3;
+    const long wgs = n_pad / (waves ? 16 * waves : 16);
+    return (double)((wgs + n_cu - 1) / n_cu) * per_step;
 }
 
 // Batch padding: the 12-wave recurrence needs a multiple of 192 sequences and the GEMM row panels a
-// multiple of 256 rows (of 54 and of 50 rows per sequence), i.e. 384 sequences; the 8- and 4-wave
-// shapes need 128.  Pick whichever padding gives the cheaper recurrence.
+// multiple of 256 rows (of 54 and of 50 rows per sequence), i.e. 384 sequences; the other shapes need
+// 128.  Pick whichever padding gives the cheaper recurrence.
 static long padded_batch(const fvad_ctx* ctx, long n)
 {
     const long a = (n + 383) / 384 * 384, b = (n + 127) / 128 * 128;
     if (getenv("FVAD_GRU_KERNEL") || a == b) return a;
-    const double cost_a = std::min(gru_cost(a, 12, ctx->n_cu), std::min(gru_cost(a, 8, ctx->n_cu), gru_cost(a, 4, ctx->n_cu)));
-    const double cost_b = std::min(gru_cost(b, 8, ctx->n_cu), gru_cost(b, 4, ctx->n_cu));
-    return cost_b < cost_a ? b : a;
+    const int cu = ctx->n_cu;
+    const double cost_a = std::min(std::min(gru_cost(a, 12, cu), gru_cost(a, 8, cu)), std::min(gru_cost(a, 4, cu), gru_cost(a, 0, cu)));
+    const double cost_b = std::min(gru_cost(b, 8, cu), std::min(gru_cost(b, 4, cu), gru_cost(b, 0, cu)));
+    return cost_b <= cost_a ? b : a;
 }
 
 static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, bool allow_v3)
 {
-    const char* force = getenv("FVAD_GRU_KERNEL"); // tuning aid: "v1w4", "v2w8", "v3w12", ...
+    const char* force = getenv("FVAD_GRU_KERNEL"); // tuning aid: "v1w1", "v2w8", "v3w12", "v4w8", ...
     if (force) {
         GruChoice c{force[1] - '0', atoi(force + 3)};
         if (c.version == 3 && !allow_v3) c.version = 2;
         return c;
     }
-    if (n_pad / 64 < 64) return {1, 1};
-    int best = 4;
-    if (gru_cost(n_pad, 8, ctx->n_cu) < gru_cost(n_pad, best, ctx->n_cu)) best = 8;
-    if (n_pad % 192 == 0 && gru_cost(n_pad, 12, ctx->n_cu) < gru_cost(n_pad, best, ctx->n_cu)) best = 12;
+    const int cu = ctx->n_cu;
+    int best = 0; // low-latency shape
+    if (n_pad % 64 == 0 && gru_cost(n_pad, 4, cu) < gru_cost(n_pad, best, cu)) best = 4;
+    if (n_pad % 128 == 0 && gru_cost(n_pad, 8, cu) < gru_cost(n_pad, best, cu)) best = 8;
+    if (n_pad % 192 == 0 && gru_cost(n_pad, 12, cu) < gru_cost(n_pad, best, cu)) best = 12;
+    if (best == 0) return {4, 8};
     return {allow_v3 ? 3 : 2, best};
 }
 
 static int launch_gru(fvad_ctx* ctx, GruChoice c, const float* gi, const DevBuf& r_v1, const DevBuf& r_v2, const float* bR,
                       float* hout, long n_pad, int T)
 {
+    if (c.version == 4) return fvad_launch_gru_lat(gi, r_v2.p, bR, hout, n_pad, T, ctx->stream);
     if (c.waves <= 0 || n_pad % (16 * c.waves)) return -1;
     if (c.version == 3) return fvad_launch_gru_rec3(gi, r_v2.p, bR, hout, n_pad, T, c.waves, ctx->stream);
     if (c.version == 2) return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, c.waves, ctx->stream);

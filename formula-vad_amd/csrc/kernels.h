@@ -72,6 +72,8 @@ int fvad_launch_gru_rec(const float* gi, const float* Rfrag, const float* bR, fl
                         long n_seq_pad, int T, int waves, hipStream_t stream);
 int fvad_launch_gru_rec2(const float* gi, const float* R2frag, const float* bR, float* hout,
                          long n_seq_pad, int T, int waves, hipStream_t stream);
+int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, float* hout,
+                        long n_seq_pad, int T, hipStream_t stream);
 int fvad_launch_gru_rec3(const float* gi, const float* R2frag, const float* bR, float* hout,
                          long n_seq_pad, int T, int waves, hipStream_t stream);
 

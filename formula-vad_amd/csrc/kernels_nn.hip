@@ -984,6 +984,148 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec3_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------ GRU recurrence, low latency
+// For small batches (a push of a few 0.5 s chunks) the recurrence is a latency problem: 53 dependent
+// steps.  Here one workgroup owns 16 sequences and its 8 wavefronts split the 25 unit tiles of a
+// step between them (wave w: tiles w, w+8, w+16, and 24 for wave 0), so all four SIMDs of the CU work
+// on the same step: ~7 tiles x 300 MFMAs per SIMD per step instead of 25 tiles on one SIMD.
+//   * nothing is shared between the waves except h, so weight fragments go straight from L2 into
+//     VGPRs (coalesced 1 KB blocks of R2frag) through a ring of five super-steps that runs across tile
+//     boundaries (25 % 5 == 0 keeps the slot of every (tile, super-step) static);
+//   * h_t is exchanged through LDS in operand layout hs[S][lane] (the float4 a lane writes for unit
+//     tile J is the float4 the same lane index reads as super-step S = J), double-buffered, one
+//     barrier per step.
+// Same bias convention as gru_rec_kernel (gi holds Wx + Wb; Rb is added here).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __restrict__ gi,
+                                                             const float* __restrict__ R2frag,
+                                                             const float* __restrict__ bR,
+                                                             float* hout, int T)
+{
+    __shared__ __attribute__((aligned(16))) float hs[2][GRU_J * 256];
+    typedef const __attribute__((address_space(1))) f32x4* gptr4;
+    constexpr int D = 5;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15;
+    const int q = lane >> 4;
+    const size_t seq = (size_t)blockIdx.x * 16 + m;
+    const float* gi_seq = gi + seq * T * (3 * GRU_H) + 4 * q;
+    float* h_seq = hout + seq * T * GRU_H + 4 * q;
+    const float* bR_q = bR + 4 * q;
+
+    // ---- t = 0: h_{-1} = 0, so R h + Rb = Rb
+    for (int J = wave; J < GRU_J; J += WAVES) {
+        const f32x4 giz = *reinterpret_cast<const f32x4*>(gi_seq + 16 * J);
+        const f32x4 gir = *reinterpret_cast<const f32x4*>(gi_seq + GRU_H + 16 * J);
+        const f32x4 gin = *reinterpret_cast<const f32x4*>(gi_seq + 2 * GRU_H + 16 * J);
+        const f32x4 bz = *reinterpret_cast<const f32x4*>(bR_q + 16 * J);
+        const f32x4 br = *reinterpret_cast<const f32x4*>(bR_q + GRU_H + 16 * J);
+        const f32x4 bn = *reinterpret_cast<const f32x4*>(bR_q + 2 * GRU_H + 16 * J);
+        f32x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float z = fast_sigmoid(giz[r] + bz[r]);
+            const float rr = fast_sigmoid(gir[r] + br[r]);
+            const float n = fast_tanh(gin[r] + rr * bn[r]);
+            h[r] = (1.0f - z) * n + z * 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(h_seq + 16 * J) = h;
+        reinterpret_cast<f32x4*>(hs[0])[J * 64 + lane] = h;
+    }
+    __syncthreads();
+    int cur = 0;
+
+    // fragment pointer of (tile J, gate g, super-step S): R2frag[J][g][S][lane][4]
+    auto frag = [&](int J, int g, int S) -> gptr4 {
+        return (gptr4)(R2frag + (size_t)J * GRU2_SLAB + (size_t)(g * GRU_J + S) * 256 + lane * 4);
+    };
+
+    for (int t = 1; t < T; ++t) {
+        const float* gi_t = gi_seq + (size_t)t * (3 * GRU_H);
+        float* h_out = h_seq + (size_t)t * GRU_H;
+        const f32x4* hcur = reinterpret_cast<const f32x4*>(hs[cur]) + lane;
+        f32x4* hnxt = reinterpret_cast<f32x4*>(hs[cur ^ 1]) + lane;
+
+        f32x4 hreg[GRU_J];
+#pragma unroll
+        for (int S = 0; S < GRU_J; ++S) hreg[S] = hcur[S * 64];
+
+        f32x4 wz[D], wr[D], wn[D];
+#pragma unroll
+        for (int S = 0; S < D; ++S) {
+            wz[S] = *frag(wave, 0, S);
+            wr[S] = *frag(wave, 1, S);
+            wn[S] = *frag(wave, 2, S);
+        }
+        for (int J = wave; J < GRU_J; J += WAVES) {
+            const int Jn = (J + WAVES < GRU_J) ? J + WAVES : J; // next tile of this wave (or a harmless re-read)
+            f32x4 az = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 ar = az, an = az;
+            f32x4 giz, gir, gin, hp, bz, br, bn;
+#pragma unroll
+            for (int S = 0; S < GRU_J; ++S) {
+                const int k = S % D;
+                const f32x4 hv = hreg[S];
+                az = MFMA16(wz[k].x, hv.x, az);
+                ar = MFMA16(wr[k].x, hv.x, ar);
+                an = MFMA16(wn[k].x, hv.x, an);
+                az = MFMA16(wz[k].y, hv.y, az);
+                ar = MFMA16(wr[k].y, hv.y, ar);
+                an = MFMA16(wn[k].y, hv.y, an);
+                az = MFMA16(wz[k].z, hv.z, az);
+                ar = MFMA16(wr[k].z, hv.z, ar);
+                an = MFMA16(wn[k].z, hv.z, an);
+                az = MFMA16(wz[k].w, hv.w, az);
+                ar = MFMA16(wr[k].w, hv.w, ar);
+                an = MFMA16(wn[k].w, hv.w, an);
+                // refill the slot with the super-step D ahead; past the end of this tile that is the
+                // next tile's super-step S + D - 25
+                if (S + D < GRU_J) {
+                    wz[k] = *frag(J, 0, S + D);
+                    wr[k] = *frag(J, 1, S + D);
+                    wn[k] = *frag(J, 2, S + D);
+                } else {
+                    wz[k] = *frag(Jn, 0, S + D - GRU_J);
+                    wr[k] = *frag(Jn, 1, S + D - GRU_J);
+                    wn[k] = *frag(Jn, 2, S + D - GRU_J);
+                }
+                if (S == 15) {
+                    giz = *reinterpret_cast<const f32x4*>(gi_t + 16 * J);
+                    gir = *reinterpret_cast<const f32x4*>(gi_t + GRU_H + 16 * J);
+                    gin = *reinterpret_cast<const f32x4*>(gi_t + 2 * GRU_H + 16 * J);
+                    bz = *reinterpret_cast<const f32x4*>(bR_q + 16 * J);
+                    br = *reinterpret_cast<const f32x4*>(bR_q + GRU_H + 16 * J);
+                    bn = *reinterpret_cast<const f32x4*>(bR_q + 2 * GRU_H + 16 * J);
+                    hp = hcur[J * 64];
+                }
+            }
+            f32x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = fast_sigmoid(giz[r] + (az[r] + bz[r]));
+                const float rr = fast_sigmoid(gir[r] + (ar[r] + br[r]));
+                const float n = fast_tanh(gin[r] + rr * (an[r] + bn[r]));
+                h[r] = (1.0f - z) * n + z * hp[r];
+            }
+            *reinterpret_cast<f32x4*>(h_out + 16 * J) = h;
+            hnxt[J * 64] = h;
+        }
+        __syncthreads(); // h_t complete in hs[cur ^ 1]; everyone has read hs[cur]
+        cur ^= 1;
+    }
+}
+
+int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, float* hout,
+                        long n_seq_pad, int T, hipStream_t stream)
+{
+    if (n_seq_pad % 16) return -1;
+    hipLaunchKernelGGL((gru_lat_kernel<8>), dim3((unsigned)(n_seq_pad / 16)), dim3(512), 0, stream, gi, R2frag, bR, hout, T);
+    return 0;
+}
+
 int fvad_launch_gru_rec2(const float* gi, const float* R2frag, const float* bR, float* hout,
                          long n_seq_pad, int T, int waves, hipStream_t stream)
 {
