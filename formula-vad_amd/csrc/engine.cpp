@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <thread>
 
 #include "internal.h"
 
@@ -160,7 +162,8 @@ int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
     const size_t rows = (size_t)G * TT;
     int rc;
     FVAD_HIP(ctx, hipMalloc((void**)&ws.descs, (size_t)G * sizeof(ChunkDesc)));
-    FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_descs, (size_t)G * sizeof(ChunkDesc), hipHostMallocDefault));
+    FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_descs, 2 * (size_t)G * sizeof(ChunkDesc), hipHostMallocDefault));
+    for (hipEvent_t& e : ws.desc_ev) if (!e) FVAD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     // zero-filled: padded rows / padded columns are read by the GEMMs and must stay finite
     if ((rc = dev_alloc(ctx, &ws.feat, rows * kFeatStride, true))) return rc;
     if ((rc = dev_alloc(ctx, &ws.spec, (size_t)G * kFramesPerChunk * kNBins * 2, true))) return rc;
@@ -366,7 +369,12 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks)
         // fill one launch, lane-contiguous
         long n = 0;
         std::vector<size_t> touched;
-        ChunkDesc* hd = ws.h_descs;
+        // pinned descriptor table: two slots, so the host can build the next launch while the GPU still
+        // runs this one; a slot is free once its (tiny) upload has been consumed
+        const int slot = ws.desc_slot;
+        ws.desc_slot ^= 1;
+        FVAD_HIP(ctx, hipEventSynchronize(ws.desc_ev[slot]));
+        ChunkDesc* hd = ws.h_descs + (size_t)slot * (size_t)ws.cap_chunks;
         size_t j = job, c = chunk_in_job;
         while (j < jobs.size() && n < cap) {
             LaneJob& lj = jobs[j];
@@ -389,6 +397,7 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks)
         }
         // the stream orders this copy after the previous launch's kernels
         FVAD_HIP(ctx, hipMemcpyAsync(ws.descs, hd, (size_t)n * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
+        FVAD_HIP(ctx, hipEventRecord(ws.desc_ev[slot], ctx->stream));
         time_begin(ctx, "stft320_logpow");
         fvad_launch_stft(ws.descs, (int)n, ctx->tb, ws.feat, ws.spec, ctx->stream);
         time_end(ctx);
@@ -399,8 +408,6 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks)
         fvad_launch_istft(ws.descs, (int)n, ctx->tb, ws.spec, ws.gains, kFramesPerChunk, 0, ctx->stream);
         time_end(ctx);
         for (size_t t : touched) jobs[t].cur ^= 1;
-        // the pinned descriptor table is reused by the next launch
-        FVAD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         job = j;
         chunk_in_job = c;
     }
@@ -505,6 +512,15 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     if (ws.band) hipFree(ws.band);
     if (ws.bins) hipFree(ws.bins);
     if (ws.carries) hipFree(ws.carries);
+    for (Workspace::PinRing* r : {&ws.ring_in, &ws.ring_out}) {
+        if (r->base) hipHostFree(r->base);
+        for (hipEvent_t& e : r->ev) if (e) hipEventDestroy(e);
+    }
+    for (hipEvent_t& e : ws.grp_in) if (e) hipEventDestroy(e);
+    for (hipEvent_t& e : ws.grp_k) if (e) hipEventDestroy(e);
+    if (ws.copy_in) hipStreamDestroy(ws.copy_in);
+    if (ws.copy_out) hipStreamDestroy(ws.copy_out);
+    for (hipEvent_t& e : ws.desc_ev) if (e) hipEventDestroy(e);
     if (ws.fft_jobs) hipFree(ws.fft_jobs);
     if (ws.h_fft_jobs) hipHostFree(ws.h_fft_jobs);
     DeviceModel& m = ctx->dm;
@@ -681,6 +697,104 @@ static int grow(fvad_ctx* ctx, float** p, size_t* cap, size_t need)
     return FVAD_OK;
 }
 
+} // extern "C"
+
+// ---- large host <-> device transfers
+// hipMemcpyAsync from / to pageable memory moves ~20 GB/s up and only ~4-8 GB/s down on this platform.
+// Transfers above a few MB go through a pinned ring instead: worker threads copy user memory <-> pinned
+// slots while the DMA engine moves the other half of the ring, so the rate is the slower of the
+// parallel memcpy and the PCIe DMA rather than their sum.
+namespace {
+constexpr size_t kPinSlotBytes = 8u << 20;
+constexpr int kPinSlots = 16; // per half
+struct CopySeg { void* host; void* dev; size_t bytes; };
+
+int ensure_pin(fvad_ctx* ctx, Workspace::PinRing& ring)
+{
+    if (ring.base) return FVAD_OK;
+    FVAD_HIP(ctx, hipHostMalloc((void**)&ring.base, 2 * kPinSlots * kPinSlotBytes, hipHostMallocDefault));
+    for (hipEvent_t& e : ring.ev) FVAD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return FVAD_OK;
+}
+
+void parallel_memcpy(const std::vector<CopySeg>& blocks, size_t first, size_t n, char* slots, bool to_pinned)
+{
+    static const int n_threads = [] { const char* e = getenv("FVAD_COPY_THREADS"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();
+    auto work = [&](size_t t) {
+        for (size_t i = t; i < n; i += (size_t)n_threads) {
+            const CopySeg& b = blocks[first + i];
+            if (to_pinned) memcpy(slots + i * kPinSlotBytes, b.host, b.bytes);
+            else memcpy(b.host, slots + i * kPinSlotBytes, b.bytes);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads && (size_t)t < n; ++t) th.emplace_back(work, (size_t)t);
+    work(0);
+    for (auto& x : th) x.join();
+}
+
+// host -> device (to_device) or device -> host, ordered on ctx->stream; returns after the last DMA has
+// been enqueued (to_device) or after the data is in user memory (!to_device)
+int staged_copy(fvad_ctx* ctx, const std::vector<CopySeg>& segs, bool to_device, hipStream_t st)
+{
+    Workspace::PinRing& ring = to_device ? ctx->ws.ring_in : ctx->ws.ring_out;
+    size_t total = 0;
+    for (const CopySeg& s : segs) total += s.bytes;
+    if (total < (4u << 20)) {
+        for (const CopySeg& s : segs)
+            if (s.bytes) FVAD_HIP(ctx, to_device ? hipMemcpyAsync(s.dev, s.host, s.bytes, hipMemcpyHostToDevice, st)
+                                                 : hipMemcpyAsync(s.host, s.dev, s.bytes, hipMemcpyDeviceToHost, st));
+        return FVAD_OK;
+    }
+    int rc = ensure_pin(ctx, ring);
+    if (rc) return rc;
+    std::vector<CopySeg> blocks;
+    for (const CopySeg& s : segs) {
+        if (s.bytes < (256u << 10)) { // small pieces (band sums, RMS) would waste ring slots: copy them directly
+            if (s.bytes) FVAD_HIP(ctx, to_device ? hipMemcpyAsync(s.dev, s.host, s.bytes, hipMemcpyHostToDevice, st)
+                                                 : hipMemcpyAsync(s.host, s.dev, s.bytes, hipMemcpyDeviceToHost, st));
+            continue;
+        }
+        for (size_t o = 0; o < s.bytes; o += kPinSlotBytes)
+            blocks.push_back({(char*)s.host + o, (char*)s.dev + o, std::min(kPinSlotBytes, s.bytes - o)});
+    }
+    if (blocks.empty()) return FVAD_OK;
+    const size_t n_waves = (blocks.size() + kPinSlots - 1) / kPinSlots;
+    auto wave_n = [&](size_t w) { return std::min((size_t)kPinSlots, blocks.size() - w * kPinSlots); };
+    auto half = [&](size_t w) { return ring.base + (w & 1) * kPinSlots * kPinSlotBytes; };
+    if (to_device) {
+        for (size_t w = 0; w < n_waves; ++w) {
+            if (w >= 2) FVAD_HIP(ctx, hipEventSynchronize(ring.ev[w & 1])); // this half's previous DMA is done
+            parallel_memcpy(blocks, w * kPinSlots, wave_n(w), half(w), true);
+            for (size_t i = 0; i < wave_n(w); ++i) {
+                const CopySeg& b = blocks[w * kPinSlots + i];
+                FVAD_HIP(ctx, hipMemcpyAsync(b.dev, half(w) + i * kPinSlotBytes, b.bytes, hipMemcpyHostToDevice, st));
+            }
+            FVAD_HIP(ctx, hipEventRecord(ring.ev[w & 1], st));
+        }
+        // the ring may be reused by a later call: its last two halves must have left the host
+        for (size_t w = (n_waves >= 2 ? n_waves - 2 : 0); w < n_waves; ++w) FVAD_HIP(ctx, hipEventSynchronize(ring.ev[w & 1]));
+    } else {
+        for (size_t w = 0; w <= n_waves; ++w) {
+            if (w < n_waves) {
+                for (size_t i = 0; i < wave_n(w); ++i) {
+                    const CopySeg& b = blocks[w * kPinSlots + i];
+                    FVAD_HIP(ctx, hipMemcpyAsync(half(w) + i * kPinSlotBytes, b.dev, b.bytes, hipMemcpyDeviceToHost, st));
+                }
+                FVAD_HIP(ctx, hipEventRecord(ring.ev[w & 1], st));
+            }
+            if (w >= 1) { // drain the previous wave while this one's DMA runs
+                FVAD_HIP(ctx, hipEventSynchronize(ring.ev[(w - 1) & 1]));
+                parallel_memcpy(blocks, (w - 1) * kPinSlots, wave_n(w - 1), half(w - 1), false);
+            }
+        }
+    }
+    return FVAD_OK;
+}
+} // namespace
+
+extern "C" {
+
 int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_engine_opts* opts_in)
 {
     if (!ctx || (n_lanes && !lanes)) return FVAD_ERR_INVALID_ARGUMENT;
@@ -735,6 +849,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
 
     float* d_rms = ws.band + frames_total;
     std::vector<LaneJob> jobs(n_lanes);
+    std::vector<CopySeg> h2d;
     size_t scratch_i = 0;
     for (size_t l = 0; l < n_lanes; ++l) {
         fvad_lane& L = lanes[l];
@@ -742,7 +857,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
         const size_t n_in = L.n_chunks * kChunk48;
         if (opts.on_device) j.d_in = L.pcm;
         else {
-            if (n_in) FVAD_HIP(ctx, hipMemcpyAsync(ws.in + in_off[l], L.pcm, n_in * sizeof(float), hipMemcpyHostToDevice, st));
+            if (n_in) h2d.push_back({(void*)L.pcm, ws.in + in_off[l], n_in * sizeof(float)});
             j.d_in = ws.in + in_off[l];
         }
         // denoised region: [1024-float prefix | chunks]; the not-yet-FFT'd remainder of the previous
@@ -759,37 +874,141 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
             scratch_i += 2;
         }
     }
-    if ((rc = run_chunks(ctx, jobs, opts.max_chunks_per_launch))) return rc;
-
-    // ---- K4 per lane + outputs
-    for (size_t l = 0; l < n_lanes; ++l) {
-        fvad_lane& L = lanes[l];
-        const float* den_start = jobs[l].d_den - n_rem[l];
-        if (L.n_fft_frames) {
-            time_begin(ctx, "fft1024_bandsum");
-            fvad_launch_vadfft(den_start, (long)L.n_fft_frames, ctx->tb, opts.min_bin, opts.max_bin, ws.band + band_off[l],
-                               L.fft_bins ? ws.bins + band_off[l] * kVadBins : nullptr, st);
-            time_end(ctx);
-            FVAD_HIP(ctx, hipMemcpyAsync(L.band_sum, ws.band + band_off[l], L.n_fft_frames * sizeof(float), hipMemcpyDeviceToHost, st));
-            if (L.fft_bins)
-                FVAD_HIP(ctx, hipMemcpyAsync(L.fft_bins, ws.bins + band_off[l] * kVadBins, L.n_fft_frames * kVadBins * sizeof(float), hipMemcpyDeviceToHost, st));
-        }
-        if (L.n_chunks) {
-            FVAD_HIP(ctx, hipMemcpyAsync(L.chunk_rms, d_rms + rms_off[l], L.n_chunks * sizeof(float), hipMemcpyDeviceToHost, st));
-            if (L.denoised)
-                FVAD_HIP(ctx, hipMemcpyAsync(L.denoised, jobs[l].d_den, L.n_chunks * kChunk48 * sizeof(float),
-                                             opts.on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
-        }
-        if (L.state) {
-            const size_t n_den = n_rem[l] + L.n_chunks * kChunk48;
-            const size_t rem = n_den - L.n_fft_frames * kVadFft;
-            if (rem) FVAD_HIP(ctx, hipMemcpyAsync(L.state->den_rem, den_start + L.n_fft_frames * kVadFft, rem * sizeof(float), hipMemcpyDeviceToDevice, st));
-            L.state->n_rem = rem;
-            L.state->cur = jobs[l].cur;
-            L.state->samples_consumed += L.n_chunks * kChunk48;
-            L.state->next_frame_index += L.n_fft_frames * (uint64_t)kVadFft;
+    // ---- lane groups.  With host buffers and enough work the call is pipelined over up to four groups
+    // of lanes: while the GPU runs group g, the host stages group g+1's input into the pinned ring and
+    // drains group g-1's output (copies on their own streams, ordered by events).  Staging pageable
+    // memory moves ~25 GB/s on the host side whatever the method, so hiding it behind compute is what
+    // is left to gain.
+    size_t h2d_bytes = 0;
+    for (const CopySeg& c : h2d) h2d_bytes += c.bytes;
+    int G = 1;
+    if (!opts.on_device && n_lanes >= 8 && h2d_bytes >= (64u << 20) && !getenv("FVAD_NO_PIPELINE")) G = 4;
+    if (G > 1) {
+        if (!ws.copy_in) FVAD_HIP(ctx, hipStreamCreateWithFlags(&ws.copy_in, hipStreamNonBlocking));
+        if (!ws.copy_out) FVAD_HIP(ctx, hipStreamCreateWithFlags(&ws.copy_out, hipStreamNonBlocking));
+        for (int g = 0; g < G; ++g) {
+            if (!ws.grp_in[g]) FVAD_HIP(ctx, hipEventCreateWithFlags(&ws.grp_in[g], hipEventDisableTiming));
+            if (!ws.grp_k[g]) FVAD_HIP(ctx, hipEventCreateWithFlags(&ws.grp_k[g], hipEventDisableTiming));
         }
     }
+    hipStream_t s_in = G > 1 ? ws.copy_in : st, s_out = G > 1 ? ws.copy_out : st;
+    // group boundaries: contiguous lanes, about equal chunk counts
+    std::vector<size_t> gb(G + 1, n_lanes);
+    gb[0] = 0;
+    {
+        size_t acc = 0, g = 1;
+        for (size_t l = 0; l < n_lanes && g < (size_t)G; ++l) {
+            acc += lanes[l].n_chunks;
+            if (acc * G >= chunks_total * g) gb[g++] = l + 1;
+        }
+    }
+    // K4 job table for every lane (pointers are known up front)
+    long max_frames = 0;
+    {
+        if (ws.fft_jobs_cap < n_lanes) {
+            hipStreamSynchronize(st);
+            if (ws.fft_jobs) hipFree(ws.fft_jobs);
+            if (ws.h_fft_jobs) hipHostFree(ws.h_fft_jobs);
+            ws.fft_jobs = nullptr; ws.h_fft_jobs = nullptr; ws.fft_jobs_cap = 0;
+            FVAD_HIP(ctx, hipMalloc((void**)&ws.fft_jobs, n_lanes * sizeof(VadFftJob)));
+            FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_fft_jobs, n_lanes * sizeof(VadFftJob), hipHostMallocDefault));
+            ws.fft_jobs_cap = n_lanes;
+        }
+        for (size_t l = 0; l < n_lanes; ++l) {
+            const fvad_lane& L = lanes[l];
+            ws.h_fft_jobs[l] = {jobs[l].d_den - n_rem[l], ws.band + band_off[l],
+                                L.fft_bins ? ws.bins + band_off[l] * kVadBins : nullptr, (long)L.n_fft_frames};
+            max_frames = std::max(max_frames, (long)L.n_fft_frames);
+        }
+        if (max_frames) FVAD_HIP(ctx, hipMemcpyAsync(ws.fft_jobs, ws.h_fft_jobs, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice, st));
+    }
+
+    auto outputs_of = [&](size_t l0, size_t l1) -> int {
+        std::vector<CopySeg> d2h;
+        for (size_t l = l0; l < l1; ++l) {
+            fvad_lane& L = lanes[l];
+            if (L.n_fft_frames) {
+                d2h.push_back({L.band_sum, ws.band + band_off[l], L.n_fft_frames * sizeof(float)});
+                if (L.fft_bins) d2h.push_back({L.fft_bins, ws.bins + band_off[l] * kVadBins, L.n_fft_frames * kVadBins * sizeof(float)});
+            }
+            if (L.n_chunks) {
+                d2h.push_back({L.chunk_rms, d_rms + rms_off[l], L.n_chunks * sizeof(float)});
+                if (L.denoised && !opts.on_device) d2h.push_back({L.denoised, jobs[l].d_den, L.n_chunks * kChunk48 * sizeof(float)});
+            }
+        }
+        return staged_copy(ctx, d2h, false, s_out);
+    };
+
+    // a second host thread drains group g's outputs (its own pinned ring and stream) while this one stages
+    // group g+1's input: both are memcpy-bound host work
+    std::atomic<int> groups_recorded{0};
+    std::atomic<bool> abort_out{false};
+    int rc_out = FVAD_OK;
+    std::thread out_thread;
+    if (G > 1)
+        out_thread = std::thread([&] {
+            hipSetDevice(ctx->device);
+            for (int g = 0; g < G; ++g) {
+                while (groups_recorded.load(std::memory_order_acquire) <= g) {
+                    if (abort_out.load()) return;
+                    std::this_thread::yield();
+                }
+                if (hipStreamWaitEvent(s_out, ws.grp_k[g], 0) != hipSuccess) { rc_out = FVAD_ERR_HIP; return; }
+                if ((rc_out = outputs_of(gb[g], gb[g + 1]))) return;
+            }
+        });
+    struct Joiner { std::thread& t; std::atomic<bool>& a; ~Joiner() { if (t.joinable()) { a.store(true); t.join(); } } } joiner{out_thread, abort_out};
+
+    for (int g = 0; g < G; ++g) {
+        const size_t l0 = gb[g], l1 = gb[g + 1];
+        // input of this group
+        std::vector<CopySeg> in_g;
+        for (size_t l = l0; l < l1; ++l) {
+            const size_t n_in = lanes[l].n_chunks * kChunk48;
+            if (!opts.on_device && n_in) in_g.push_back({(void*)lanes[l].pcm, ws.in + in_off[l], n_in * sizeof(float)});
+        }
+        if ((rc = staged_copy(ctx, in_g, true, s_in))) return rc;
+        if (G > 1) {
+            FVAD_HIP(ctx, hipEventRecord(ws.grp_in[g], s_in));
+            FVAD_HIP(ctx, hipStreamWaitEvent(st, ws.grp_in[g], 0));
+        }
+        // kernels of this group
+        std::vector<LaneJob> jg(jobs.begin() + l0, jobs.begin() + l1);
+        if ((rc = run_chunks(ctx, jg, opts.max_chunks_per_launch))) return rc;
+        for (size_t l = l0; l < l1; ++l) jobs[l].cur = jg[l - l0].cur;
+        long mf = 0;
+        for (size_t l = l0; l < l1; ++l) mf = std::max(mf, (long)lanes[l].n_fft_frames);
+        if (mf) {
+            time_begin(ctx, "fft1024_bandsum");
+            fvad_launch_vadfft_jobs(ws.fft_jobs + l0, (int)(l1 - l0), mf, ctx->tb, opts.min_bin, opts.max_bin, st);
+            time_end(ctx);
+        }
+        for (size_t l = l0; l < l1; ++l) {
+            fvad_lane& L = lanes[l];
+            const float* den_start = jobs[l].d_den - n_rem[l];
+            if (L.n_chunks && L.denoised && opts.on_device)
+                FVAD_HIP(ctx, hipMemcpyAsync(L.denoised, jobs[l].d_den, L.n_chunks * kChunk48 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            if (L.state) {
+                const size_t n_den = n_rem[l] + L.n_chunks * kChunk48;
+                const size_t rem = n_den - L.n_fft_frames * kVadFft;
+                if (rem) FVAD_HIP(ctx, hipMemcpyAsync(L.state->den_rem, den_start + L.n_fft_frames * kVadFft, rem * sizeof(float), hipMemcpyDeviceToDevice, st));
+                L.state->n_rem = rem;
+                L.state->cur = jobs[l].cur;
+                L.state->samples_consumed += L.n_chunks * kChunk48;
+                L.state->next_frame_index += L.n_fft_frames * (uint64_t)kVadFft;
+            }
+        }
+        if (G > 1) {
+            FVAD_HIP(ctx, hipEventRecord(ws.grp_k[g], st));
+            groups_recorded.store(g + 1, std::memory_order_release);
+        }
+    }
+    if (G > 1) {
+        out_thread.join(); // all groups recorded: the worker runs to completion
+        if (rc_out) return set_err(ctx, rc_out, "device-to-host output copy failed");
+        FVAD_HIP(ctx, hipStreamSynchronize(s_in));
+        FVAD_HIP(ctx, hipStreamSynchronize(s_out));
+    } else if ((rc = outputs_of(0, n_lanes))) return rc;
     FVAD_HIP(ctx, hipStreamSynchronize(st));
     FVAD_HIP(ctx, hipGetLastError());
     return FVAD_OK;

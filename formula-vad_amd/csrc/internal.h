@@ -57,7 +57,9 @@ struct Workspace {
     long cap_chunks = 0; // padded chunk capacity (multiple of 384)
     int T = 0;
     ChunkDesc* descs = nullptr;
-    ChunkDesc* h_descs = nullptr; // pinned
+    ChunkDesc* h_descs = nullptr; // pinned, two slots of cap_chunks descriptors
+    hipEvent_t desc_ev[2] = {nullptr, nullptr}; // slot's upload has left the host
+    int desc_slot = 0;
     float *feat = nullptr, *spec = nullptr, *a1 = nullptr, *gi = nullptr,
           *h1 = nullptr, *h2 = nullptr, *f2 = nullptr, *f3 = nullptr, *gains = nullptr;
     // generic scratch (engine_run staging, denoised audio, band sums)
@@ -67,6 +69,12 @@ struct Workspace {
     float* bins = nullptr; size_t bins_cap = 0;
     LaneCarry* carries = nullptr; size_t carries_cap = 0; // scratch carries (2 per lane)
     VadFftJob* fft_jobs = nullptr; VadFftJob* h_fft_jobs = nullptr; size_t fft_jobs_cap = 0;
+    // pinned staging ring for large host <-> device transfers (two halves of kPinSlots slots)
+    struct PinRing { char* base = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
+    PinRing ring_in, ring_out; // host->device staging / device->host draining (used by different threads)
+    // copy streams + per-group events of the pipelined host-buffer path (fvad_engine_run)
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    hipEvent_t grp_in[8] = {}, grp_k[8] = {};
 };
 
 struct KernelTime {

@@ -340,6 +340,26 @@ def test_engine_batch_consistency_at_scale(fv, gpu_ctx, pkg):
     assert np.all(np.isfinite(ref_a["denoised"]))
 
 
+def test_engine_host_buffer_pipelining_is_invisible(fv, gpu_ctx, pkg, monkeypatch):
+    # above 64 MB of input the host-buffer path runs in four lane groups with staged copies on their own
+    # streams; results must be bit-identical to the single-group path, ragged lanes included
+    rng = np.random.default_rng(3)
+    base, _ = pkg.synth.make_stream(50.0, seed=21)
+    lanes = []
+    for i in range(20):
+        n = int(rng.integers(60, 100)) * 24000 + int(rng.integers(0, 24000))
+        lanes.append(np.roll(base[0], 4801 * i)[:n].copy())
+    assert sum(x.nbytes for x in lanes) > (64 << 20)
+    a = gpu_ctx.engine_run(lanes, want_denoised=True)
+    monkeypatch.setenv("FVAD_NO_PIPELINE", "1")
+    b = gpu_ctx.engine_run(lanes, want_denoised=True)
+    for x, y in zip(a, b):
+        assert x["n_chunks"] == y["n_chunks"] and x["n_fft_frames"] == y["n_fft_frames"]
+        assert np.array_equal(x["denoised"], y["denoised"])
+        assert np.array_equal(x["band_sum"], y["band_sum"]) and np.array_equal(x["chunk_rms"], y["chunk_rms"])
+    assert np.all(np.isfinite(a[0]["denoised"])) and np.abs(a[0]["denoised"]).max() > 0
+
+
 # ------------------------------------------------------------------ B1: AudioPipeline end to end
 @pytest.mark.parametrize("n_channels,seconds,seed", [(1, 90.0, 40), (2, 60.0, 41)])
 def test_pipeline_segments_bit_identical(fv, gpu_ctx, weights7, pkg, n_channels, seconds, seed):
