@@ -184,8 +184,10 @@ __global__ __launch_bounds__(WAVES * 64) void panel_gemm2_kernel(
     const int q = lane >> 4;
     // all index arithmetic in 32 bits (rows < 2^31): 64-bit integer division is a several-hundred-
     // instruction software routine on the GPU and this runs once per workgroup
-    const unsigned nblk = blockIdx.x % (unsigned)n_blocks;
-    const unsigned panel = blockIdx.x / (unsigned)n_blocks;
+    // XCD-major renumbering (see panel_gemm3_kernel): the column blocks of a row panel share one L2
+    const unsigned vb = (gridDim.x % 8u == 0u) ? (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u : blockIdx.x;
+    const unsigned nblk = vb % (unsigned)n_blocks;
+    const unsigned panel = vb / (unsigned)n_blocks;
 
     const float* a_ptr[RT];
     unsigned c_row[RT];
@@ -388,7 +390,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
         if (tid < NT * 4) reinterpret_cast<f32x4*>(dst)[tid] = reinterpret_cast<const f32x4*>(bias + nblk * (NT * 16))[tid];
     };
 
-    unsigned item = blockIdx.x;
+    // XCD-aware start: workgroups are dealt to the 8 XCDs round-robin (blockIdx.x % 8), each with its own
+    // L2.  Renumbering them XCD-major makes the workgroups of one XCD take consecutive items, i.e. the
+    // column blocks of the same row panel, so a panel is fetched from HBM by one L2 instead of five.
+    unsigned item = (gridDim.x % 8u == 0u) ? (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u : blockIdx.x;
     if (item >= n_items) return;
     const unsigned slab_addr[2] = {(unsigned)(uintptr_t)(lds_float*)slab[0] + (unsigned)lane * 16u,
                                    (unsigned)(uintptr_t)(lds_float*)slab[1] + (unsigned)lane * 16u};
