@@ -273,9 +273,10 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
         // the default where it has an instance: the 15- and 11-tile column blocks.  The 19-tile blocks
         // of fc2/fc3 leave it no room for its fragment ring in 256 VGPRs and stay on panel_gemm2.
         const bool allow_v3 = !(force && strstr(force, "v2"));
+        // K is the true reduction length (S super-steps of 16 cover it, zero-padded)
         auto gemm = [&](const float* A, int lda, const float* W, const float* b, float* Cc, int ldc, long r, int nt,
-                        int nblk, int S, int act, int valid, int mT, int mskip) {
-            if (allow_v3 && fvad_launch_panel_gemm3(A, lda, W, b, Cc, ldc, r, nt, nblk, S, act, valid, mT, mskip, ctx->n_cu, st) == 0)
+                        int nblk, int S, int K, int act, int valid, int mT, int mskip) {
+            if (allow_v3 && fvad_launch_panel_gemm3(A, lda, W, b, Cc, ldc, r, nt, nblk, S, K, act, valid, mT, mskip, ctx->n_cu, st) == 0)
                 return 0;
             return fvad_launch_panel_gemm2(A, lda, W, b, Cc, ldc, r, nt, nblk, S, act, valid, mT, mskip, gw, st);
         };
@@ -284,36 +285,36 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
         const bool bzr = gc.version == 3;
         if (fold) {
             time_begin(ctx, "gru1_in_gemm_fc1folded");
-            rc |= gemm(ws.feat, kFeatStride, m.gi1f_w.p, bzr ? m.gi1f_bzr.p : m.gi1f_b.p, ws.gi, 1200, rows, 15, 5, 11, FVAD_ACT_NONE, 75, 0, 0);
+            rc |= gemm(ws.feat, kFeatStride, m.gi1f_w.p, bzr ? m.gi1f_bzr.p : m.gi1f_b.p, ws.gi, 1200, rows, 15, 5, 11, 161, FVAD_ACT_NONE, 75, 0, 0);
             time_end(ctx);
         } else {
             time_begin(ctx, "fc1_gemm");
             rc |= fvad_launch_panel_gemm(ws.feat, kFeatStride, m.fc1_w.p, m.fc1_b.p, ws.a1, 400, rows, 25, 1, 11, FVAD_ACT_NONE, 0, 0, st);
             time_end(ctx);
             time_begin(ctx, "gru1_in_gemm");
-            rc |= gemm(ws.a1, 400, m.gi1v2_w.p, m.gi1_b.p, ws.gi, 1200, rows, 15, 5, 25, FVAD_ACT_NONE, 75, 0, 0);
+            rc |= gemm(ws.a1, 400, m.gi1v2_w.p, m.gi1_b.p, ws.gi, 1200, rows, 15, 5, 25, 400, FVAD_ACT_NONE, 75, 0, 0);
             time_end(ctx);
         }
         time_begin(ctx, "gru1_rec");
         rc |= launch_gru(ctx, gc, ws.gi, m.r1, m.r1v2, m.br1.p, ws.h1, n_pad, T);
         time_end(ctx);
         time_begin(ctx, "gru2_in_gemm");
-        rc |= gemm(ws.h1, 400, m.gi2v2_w.p, bzr ? m.gi2_bzr.p : m.gi2_b.p, ws.gi, 1200, rows, 15, 5, 25, FVAD_ACT_NONE, 75, 0, 0);
+        rc |= gemm(ws.h1, 400, m.gi2v2_w.p, bzr ? m.gi2_bzr.p : m.gi2_b.p, ws.gi, 1200, rows, 15, 5, 25, 400, FVAD_ACT_NONE, 75, 0, 0);
         time_end(ctx);
         time_begin(ctx, "gru2_rec");
         rc |= launch_gru(ctx, gc, ws.gi, m.r2, m.r2v2, m.br2.p, ws.h2, n_pad, T);
         time_end(ctx);
         time_begin(ctx, "fc2_gemm");
         const bool fc13 = allow_v3 && !(force && strstr(force, "fc19"));
-        if (fc13) rc |= gemm(ws.h2, 400, m.fc2v3_w.p, m.fc2v3_b.p, ws.f2, 608, rows_out, 13, 3, 25, FVAD_ACT_RELU, 38, skip ? T : 0, skip);
-        else rc |= gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, 38, skip ? T : 0, skip);
+        if (fc13) rc |= gemm(ws.h2, 400, m.fc2v3_w.p, m.fc2v3_b.p, ws.f2, 608, rows_out, 13, 3, 25, 400, FVAD_ACT_RELU, 38, skip ? T : 0, skip);
+        else rc |= gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, 400, FVAD_ACT_RELU, 38, skip ? T : 0, skip);
         time_end(ctx);
         time_begin(ctx, "fc3_gemm");
-        if (fc13) rc |= gemm(ws.f2, 608, m.fc3v3_w.p, m.fc3v3_b.p, ws.f3, 608, rows_out, 13, 3, 38, FVAD_ACT_RELU, 38, 0, 0);
-        else rc |= gemm(ws.f2, 608, m.fc3_w.p, m.fc3_b.p, ws.f3, 608, rows_out, 19, 2, 38, FVAD_ACT_RELU, 38, 0, 0);
+        if (fc13) rc |= gemm(ws.f2, 608, m.fc3v3_w.p, m.fc3v3_b.p, ws.f3, 608, rows_out, 13, 3, 38, 600, FVAD_ACT_RELU, 38, 0, 0);
+        else rc |= gemm(ws.f2, 608, m.fc3_w.p, m.fc3_b.p, ws.f3, 608, rows_out, 19, 2, 38, 600, FVAD_ACT_RELU, 38, 0, 0);
         time_end(ctx);
         time_begin(ctx, "fc4_gemm");
-        rc |= gemm(ws.f3, 608, m.fc4_w.p, m.fc4_b.p, ws.gains, kFeatStride, rows_out, 11, 1, 38, FVAD_ACT_SIGMOID, 11, 0, 0);
+        rc |= gemm(ws.f3, 608, m.fc4_w.p, m.fc4_b.p, ws.gains, kFeatStride, rows_out, 11, 1, 38, 600, FVAD_ACT_SIGMOID, 11, 0, 0);
         time_end(ctx);
         if (rc) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "no kernel instance for this layer shape");
         FVAD_HIP(ctx, hipGetLastError());

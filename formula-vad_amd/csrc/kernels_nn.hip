@@ -343,7 +343,7 @@ template <int NT, int RT, int ACT, int SP, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void panel_gemm3_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ Wfrag,
     const float* __restrict__ bias, float* __restrict__ C, int ldc, int S_steps, int n_blocks,
-    int n_valid_tiles, int row_map_T, int row_map_skip, unsigned n_items)
+    int n_valid_tiles, int row_map_T, int row_map_skip, unsigned n_items, int tail_r)
 {
     __shared__ __attribute__((aligned(16))) float slab[2][NT * SP * 256];
     __shared__ __attribute__((aligned(16))) float sbias[2][NT * 16];
@@ -453,16 +453,25 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
                     for (int rt = 0; rt < RT; ++rt)
                         a1[rt] = *(gptr4)((sg + 1 < S_steps) ? a_ptr[rt] + 16 * (sg + 1) : a_nextitem[rt]);
                 }
+                // MFMA r of a super-step reduces over k = 16 sg + 4q + r: when K is not a multiple of 16 the
+                // last super-step's higher r are all padding (K = 161: only r = 0 carries k = 160)
+                const int nr = (sg + 1 < S_steps) ? 4 : tail_r;
                 auto mfmas = [&](auto tc) {
                     constexpr int t = decltype(tc)::value;
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w[t].x, a0[rt].x, acc[rt][t]);
+                    if (nr > 1) {
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w[t].y, a0[rt].y, acc[rt][t]);
+                        for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w[t].y, a0[rt].y, acc[rt][t]);
+                    }
+                    if (nr > 2) {
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w[t].z, a0[rt].z, acc[rt][t]);
+                        for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w[t].z, a0[rt].z, acc[rt][t]);
+                    }
+                    if (nr > 3) {
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w[t].w, a0[rt].w, acc[rt][t]);
+                        for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w[t].w, a0[rt].w, acc[rt][t]);
+                    }
                 };
                 // The read of tile t for the next super-step follows tile t's MFMAs, so every wait below
                 // sees exactly NT-1 younger reads in flight.  In the last step of a phase the next data
@@ -519,17 +528,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
 // rows must be a multiple of 256; grid = one persistent workgroup per CU.  Returns -1 when there is no
 // instance for (nt, act): the caller falls back to panel_gemm2.
 int fvad_launch_panel_gemm3(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
-                            int ldc, long rows, int nt, int n_blocks, int S_steps, int act,
+                            int ldc, long rows, int nt, int n_blocks, int S_steps, int K, int act,
                             int n_valid_tiles, int map_T, int map_skip, int n_wg, hipStream_t stream)
 {
     if (rows % 256) return -1;
+    const int n_last = K - 16 * (S_steps - 1); // valid k in the last super-step
+    const int tail_r = n_last >= 4 ? 4 : (n_last < 1 ? 4 : n_last);
     const unsigned n_items = (unsigned)((rows / 256) * n_blocks);
     const unsigned grid = n_items < (unsigned)n_wg ? n_items : (unsigned)n_wg;
 #define CASE3(NT_, ACT_, SP_)                                                                         \
     if (nt == NT_ && act == ACT_) {                                                                   \
         hipLaunchKernelGGL((panel_gemm3_kernel<NT_, 2, ACT_, SP_, 8>), dim3(grid), dim3(512), 0, stream, \
                            A, lda, Wfrag, bias, C, ldc, S_steps, n_blocks, n_valid_tiles, map_T,      \
-                           map_skip, n_items);                                                        \
+                           map_skip, n_items, tail_r);                                                \
         return 0;                                                                                     \
     }
     // no 19-tile instance: 152 accumulator + 76 fragment registers do not fit 256 VGPRs; fc2/fc3 use
