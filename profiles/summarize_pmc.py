@@ -25,6 +25,24 @@ for name, key in (("fetch_size", "fetch_kib"), ("write_size", "write_kib")):
         out.setdefault(k, {})[key] = sum(v) / len(v)
 for k, v in out.items():
     v["hbm_bytes_per_launch"] = (2 * v.get("fetch_kib", 0) + v.get("write_kib", 0)) * 1024
+    v["hbm_bytes_per_launch_raw_counters"] = (v.get("fetch_kib", 0) + v.get("write_kib", 0)) * 1024
+# MFMA busy fraction and clock from the third pass, when present (GRBM_GUI_ACTIVE is summed over the 8
+# XCDs; SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs)
+mf = os.path.join(here, f"{tag}_pmc_mfma_busy.csv")
+if os.path.exists(mf):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(mf)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[k]["ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k, v in agg.items():
+        if "rocclr" in k or k not in out:
+            continue
+        mean = lambda x: sum(x) / len(x)
+        gui = mean(v["GRBM_GUI_ACTIVE"]) / 8
+        out[k]["clock_GHz"] = gui / mean(v["ns"])
+        out[k]["mfma_busy_frac"] = mean(v["SQ_VALU_MFMA_BUSY_CYCLES"]) / (gui * 1024)
 json.dump({"chunks_per_launch": chunks, "kernels": out}, open(os.path.join(here, f"{tag}_pmc_summary.json"), "w"), indent=1)
 for k, v in out.items():
-    print(f"{k:45s} {v['hbm_bytes_per_launch'] / 1e9:7.2f} GB/launch")
+    print(f"{k:45s} {v['hbm_bytes_per_launch'] / 1e9:7.2f} GB/launch corrected, {v['hbm_bytes_per_launch_raw_counters'] / 1e9:7.2f} raw, "
+          f"mfma busy {v.get('mfma_busy_frac', 0):.3f}, clock {v.get('clock_GHz', 0):.2f} GHz")
