@@ -197,6 +197,7 @@ SIGNATURES = {
     "fvad_vad_segment_count": (sz, [vp]),
     "fvad_vad_segments": (C.c_int, [vp, C.POINTER(SpeechSegment), sz, C.POINTER(sz)]),
     "fvad_vad_audit_get": (C.c_int, [vp, C.POINTER(VadAudit)]),
+    "fvad_vad_lazy_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "fvad_vad_run_many": (C.c_int, [C.POINTER(vp), sz, C.POINTER(c_float_p),
                                     C.POINTER(c_float_p), C.POINTER(sz), sz,
                                     C.POINTER(C.c_uint64), sz, C.c_int]),
@@ -632,6 +633,12 @@ class VadMachine:
         a = VadAudit()
         check(lib().fvad_vad_audit_get(self.h, C.byref(a)), "audit")
         return a.min_rel_threshold_margin, a.min_abs_ratio_margin, a.n_frames
+
+    def lazy_stats(self):
+        """(exact evaluations of the long-term chain, pushes absorbed lazily)"""
+        e, p = C.c_uint64(), C.c_uint64()
+        check(lib().fvad_vad_lazy_stats(self.h, C.byref(e), C.byref(p)), "lazy_stats")
+        return e.value, p.value
 
     def close(self):
         if self.h:

@@ -8,6 +8,7 @@
 // supplies the per-frame band sums and per-chunk RMS values that feed it.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -139,6 +140,8 @@ VadMachine::VadMachine(const fvad_vad_config& c, size_t sample_rate_, size_t n_c
     audit.min_rel_threshold_margin = INFINITY;
     audit.min_abs_ratio_margin = INFINITY;
     audit.n_frames = 0;
+    const char* eager = getenv("FVAD_VAD_EAGER");
+    lt_lazy = !(eager && eager[0] == '1');
 }
 
 uint64_t VadMachine::offset_start(uint64_t vad_from) const // :312-317
@@ -220,13 +223,107 @@ fvad_vad_result VadMachine::finish_step(uint64_t index, bool threshold_met, bool
     return result;
 }
 
+// ---- lazily exact long-term average
+// The long-term average feeds exactly one thing: the comparison `short_term > long_term * factor`
+// (VADMachine.zig:169-171; plus this build's margin audit).  Re-running the reference's chain of `len`
+// dependent f64 adds on every push (RollingAverage.zig:45-56) makes a stream cost ~4.5 us per frame and a
+// two-hour stream three seconds, however many cores there are.  Instead the machine keeps
+//   lt_approx = the chain's last exact value, updated as fl(fl(lt_approx + q_new) - q_old) per push,
+//   lt_err    = a running bound on the rounding error of those updates,
+//   lt_abs    = (approximately) sum |q_i|,
+// and bounds the distance to what the chain would return *now*:
+//   |lt_approx - chain| <= gamma_N sum|q_i|(anchor) + lt_err + gamma_N sum|q_i|(now)
+// (gamma_N = N u / (1 - N u), u = 2^-53: the chain's error against the real-number sum when lt_approx was
+// anchored on it, the updates' rounding, the chain's own error now).
+// decide() evaluates the comparison with the threshold interval this gives; only if `short_term` falls
+// inside the interval, or the frame could lower the audit's minimum margin, is the chain run for real
+// (long_term_exact: the reference's additions in the reference's order).  Every decision and every
+// audited number is therefore the one the eager evaluation produces; the tests compare whole runs
+// bit for bit with the oracle.
+static constexpr double kU = 1.1102230246251565e-16; // 2^-53
+
+void VadMachine::long_term_exact()
+{
+    RollingAverage& a = long_term;
+    const double* qq = a.q.data();
+    double acc = 0.0, pref = 0.0, abs_sum = 0.0;
+    for (size_t i = 0; i < a.len; ++i) {
+        if (i == a.write_idx) pref = acc;
+        acc += qq[i]; // == a += data[i] * scalar (RollingAverage.zig:50-53), products cached in q
+        abs_sum += std::fabs(qq[i]);
+    }
+    a.last_avg = acc;
+    a.has_last_avg = true;
+    a.pref = (a.write_idx == 0) ? 0.0 : pref;
+    lt_approx = acc;
+    lt_abs = abs_sum;
+    lt_abs_anchor = abs_sum;
+    lt_anchored = true;
+    lt_err = 0.0;
+    lt_stale = false;
+    lt_updates = 0;
+    ++lt_exact_evals;
+}
+
+void VadMachine::long_term_push(float mv) // RollingAverage.push for the long-term ring
+{
+    RollingAverage& a = long_term;
+    if (!a.steady || !lt_lazy) { // ring not full yet (or eager mode): the reference's path as is
+        const bool was_steady = a.steady;
+        a.push(mv);
+        if (lt_lazy && !was_steady && a.steady) long_term_exact();
+        return;
+    }
+    if (!lt_anchored) long_term_exact(); // first lazy push: anchor on the chain's current value
+    const size_t w = a.write_idx;
+    const double qn = (double)mv * a.scalar, qo = a.q[w];
+    a.data[w] = (double)mv;
+    a.q[w] = qn;
+    a.write_idx = (w + 1) % a.len;
+    const double s1 = lt_approx + qn, s2 = s1 - qo;
+    lt_err += 2.0 * kU * (std::fabs(s1) + std::fabs(s2)); // each rounding <= u |result|; doubled
+    lt_abs += std::fabs(qn) - std::fabs(qo);
+    lt_approx = s2;
+    lt_stale = true;
+    a.has_last_avg = true;
+    ++lt_lazy_pushes;
+    if (++lt_updates >= 4096) long_term_exact(); // keep the bound tight
+}
+
 bool VadMachine::decide(double short_term_avg, double ratio_avg, double* threshold_out)
 {
+    const double f = (double)cfg.speech_threshold_factor;
+    if (long_term.steady && lt_stale && threshold_out) long_term_exact();
+    if (long_term.steady && lt_stale) {
+        const double n = (double)long_term.len;
+        const double gamma = n * kU / (1.0 - n * kU);
+        // lt_abs is itself updated in floating point: widen it by its own drift
+        const double abs_now = std::fabs(lt_abs) * (1.0 + 1e-9) + 8192.0 * 2.0 * kU * (std::fabs(lt_abs) + lt_abs_anchor);
+        const double delta = lt_err + 2.0 * gamma * (abs_now + lt_abs_anchor);
+        double t0 = (lt_approx - delta) * f, t1 = (lt_approx + delta) * f;
+        if (t0 > t1) std::swap(t0, t1);
+        const double lo = t0 - std::fabs(t0) * 4.0 * kU - 1e-300, hi = t1 + std::fabs(t1) * 4.0 * kU + 1e-300;
+        const bool sure_true = short_term_avg > hi, sure_false = short_term_avg <= lo;
+        bool need_exact = !(sure_true || sure_false);
+        if (!need_exact && hi > 0) {
+            // smallest relative margin |st - thr| / thr any threshold in [lo, hi] could give
+            const double gap = sure_true ? short_term_avg - hi : lo - short_term_avg;
+            const double m_lb = gap / (sure_true ? hi : std::max(lo, hi));
+            if (!(m_lb * (1.0 - 1e-9) > audit.min_rel_threshold_margin)) need_exact = true;
+        }
+        if (!need_exact) {
+            const double rm = std::fabs(ratio_avg - (double)cfg.channel_vol_ratio_threshold);
+            if (rm < audit.min_abs_ratio_margin) audit.min_abs_ratio_margin = rm;
+            audit.n_frames++;
+            return sure_true && ratio_avg > (double)cfg.channel_vol_ratio_threshold;
+        }
+        long_term_exact();
+    }
     double base; // :169  last_avg orelse initial_long_term_avg orelse short_term
     if (long_term.has_last_avg) base = long_term.last_avg;
     else if (cfg.has_initial_long_term_avg) base = cfg.initial_long_term_avg;
     else base = short_term_avg;
-    const double threshold = base * (double)cfg.speech_threshold_factor; // :170
+    const double threshold = base * f; // :170
     const bool met = short_term_avg > threshold && ratio_avg > (double)cfg.channel_vol_ratio_threshold; // :171
     // margin audit: how close was this frame to flipping?
     if (threshold > 0) {
@@ -258,128 +355,19 @@ fvad_vad_result VadMachine::run(uint64_t index, const float* channel_volumes, bo
     const double st = short_term.push(mv);                       // :166
     const double cr = ch_ratio.push(has_ratio ? ratio : 0);      // :167
     const bool met = decide(st, cr, nullptr);
-    if (!met) long_term.push(mv);                                // :176-178
+    if (!met) long_term_push(mv);                                // :176-178
     return finish_step(index, met, has_ratio, ratio);
 }
 
-// ------------------------------------------------------------------ many streams in lock-step
-// The long-term average is an 8437-term dependent f64 chain per frame per stream
-// (RollingAverage.zig:45-56) -- latency-bound when done one stream at a time.  Here up to LANES
-// streams advance together and the chain is evaluated for all of them at once from a
-// structure-of-arrays copy of their rings: data[i][lane].  Every lane still adds its own terms in
-// index order, so each stream's result is bit-identical to VadMachine::run.
-namespace {
-// 16 streams per group: the ring contents are kept as the f32 values that were pushed
-// (data[i] is always an exact f32, RollingAverage.zig:35), structure-of-arrays [len][16] = 540 KB,
-// which stays L2-resident; each row is widened, multiplied by 1/len and added to 16 independent
-// f64 accumulators -- four AVX2 (two AVX-512) dependent chains, enough to cover the add latency.
-constexpr int LANES = 16;
-
-struct Group {
-    std::vector<VadMachine*> m;            // <= LANES machines with identical, full long-term rings
-    std::vector<float> soa;                // [len][LANES]
-    size_t len = 0;
-};
-
-// avg_l = sum_i data_l[i] * scalar, i ascending, for every lane at once: per lane exactly the
-// reference's loop (RollingAverage.zig:45-56: mul, then add, no contraction).
-__attribute__((target_clones("avx512f", "avx2", "default")))
-void group_resum(const float* d, size_t len, double scalar, double* out)
-{
-    double acc[LANES];
-    for (int l = 0; l < LANES; ++l) acc[l] = 0.0;
-    for (size_t i = 0; i < len; ++i) {
-        const float* row = d + i * LANES;
-        for (int l = 0; l < LANES; ++l) acc[l] += (double)row[l] * scalar;
-    }
-    for (int l = 0; l < LANES; ++l) out[l] = acc[l];
-}
-} // namespace
-
+// ------------------------------------------------------------------ many streams
+// Streams are independent (one pipeline per file, simulator.zig:225-231); with the lazily exact
+// long-term average a frame costs ~0.1 us, so the streams are simply dealt to threads.
 void run_many(VadMachine* const* vads, size_t n_streams, const float* const* band,
               const float* const* ratio, const size_t* n_frames, size_t n_channels,
               const uint64_t* first_index, size_t fft_size, int n_threads)
 {
     if (n_threads < 1) n_threads = 1;
-    // partition streams into groups of <= LANES machines with equal, already full long-term rings
-    std::vector<Group> groups;
-    std::vector<std::vector<size_t>> group_sid;
-    std::vector<size_t> scalar_streams;
-    {
-        std::vector<bool> used(n_streams, false);
-        for (size_t i = 0; i < n_streams; ++i) {
-            if (used[i]) continue;
-            used[i] = true;
-            RollingAverage& a = vads[i]->long_term;
-            if (a.written_count != a.len) { scalar_streams.push_back(i); continue; }
-            std::vector<size_t> idx{i};
-            for (size_t j = i + 1; j < n_streams && idx.size() < (size_t)LANES; ++j) {
-                const RollingAverage& b = vads[j]->long_term;
-                if (!used[j] && b.len == a.len && b.written_count == b.len) { idx.push_back(j); used[j] = true; }
-            }
-            if (idx.size() < 2) { scalar_streams.push_back(i); continue; }
-            Group g;
-            g.len = a.len;
-            g.soa.assign(g.len * LANES, 0.0f);
-            for (size_t l = 0; l < idx.size(); ++l) {
-                RollingAverage& ra = vads[idx[l]]->long_term;
-                g.m.push_back(vads[idx[l]]);
-                for (size_t k = 0; k < g.len; ++k) g.soa[k * LANES + l] = (float)ra.data[k];
-                ra.steady = false; // q / pref are rebuilt when the group is done
-            }
-            groups.push_back(std::move(g));
-            group_sid.push_back(idx);
-        }
-    }
-
-    auto run_group = [&](size_t gi) {
-        Group& g = groups[gi];
-        const size_t L = g.m.size();
-        size_t sid[LANES]; size_t nf[LANES]; size_t max_f = 0;
-        for (size_t l = 0; l < L; ++l) { sid[l] = group_sid[gi][l]; nf[l] = n_frames[sid[l]]; max_f = std::max(max_f, nf[l]); }
-        const double scalar = 1.0 / (double)g.len;
-        for (size_t k = 0; k < max_f; ++k) {
-            bool pushed[LANES] = {false};
-            bool met[LANES] = {false};
-            float mv[LANES] = {0};
-            bool any = false;
-            for (size_t l = 0; l < L; ++l) {
-                if (k >= nf[l]) continue;
-                VadMachine* m = g.m[l];
-                const size_t s = sid[l];
-                mv[l] = m->min_volume(band[s] + k * n_channels);
-                const float r = ratio[s][k];
-                const bool has_ratio = !std::isnan(r);
-                const double st = m->short_term.push(mv[l]);
-                const double cr = m->ch_ratio.push(has_ratio ? r : 0);
-                met[l] = m->decide(st, cr, nullptr);
-                if (!met[l]) {
-                    // RollingAverage.push without the re-sum (done for the whole group below)
-                    RollingAverage& ra = m->long_term;
-                    ra.data[ra.write_idx] = (double)mv[l];
-                    g.soa[ra.write_idx * LANES + l] = mv[l];
-                    ra.write_idx = (ra.write_idx + 1) % ra.len;
-                    pushed[l] = true;
-                    any = true;
-                }
-            }
-            if (any) {
-                double out[LANES];
-                group_resum(g.soa.data(), g.len, scalar, out);
-                for (size_t l = 0; l < L; ++l)
-                    if (pushed[l]) { g.m[l]->long_term.last_avg = out[l]; g.m[l]->long_term.has_last_avg = true; }
-            }
-            for (size_t l = 0; l < L; ++l) {
-                if (k >= nf[l]) continue;
-                const size_t s = sid[l];
-                const float r = ratio[s][k];
-                const bool has_ratio = !std::isnan(r);
-                g.m[l]->finish_step(first_index[s] + (uint64_t)k * fft_size, met[l], has_ratio, r);
-            }
-        }
-        for (size_t l = 0; l < L; ++l) g.m[l]->long_term.enter_steady();
-    };
-    auto run_scalar = [&](size_t s) {
+    auto run_stream = [&](size_t s) {
         VadMachine* m = vads[s];
         for (size_t k = 0; k < n_frames[s]; ++k) {
             const float r = ratio[s][k];
@@ -387,24 +375,19 @@ void run_many(VadMachine* const* vads, size_t n_streams, const float* const* ban
             m->run(first_index[s] + (uint64_t)k * fft_size, band[s] + k * n_channels, has_ratio, r);
         }
     };
-
-    // work items: groups then scalar streams, spread over threads
-    const size_t n_items = groups.size() + scalar_streams.size();
-    if (n_threads == 1 || n_items <= 1) {
-        for (size_t gi = 0; gi < groups.size(); ++gi) run_group(gi);
-        for (size_t s : scalar_streams) run_scalar(s);
+    if (n_threads == 1 || n_streams <= 1) {
+        for (size_t s = 0; s < n_streams; ++s) run_stream(s);
         return;
     }
     std::vector<std::thread> th;
     std::atomic<size_t> next{0};
-    const int nt = (int)std::min<size_t>((size_t)n_threads, n_items);
+    const int nt = (int)std::min<size_t>((size_t)n_threads, n_streams);
     for (int t = 0; t < nt; ++t)
         th.emplace_back([&]() {
             for (;;) {
                 const size_t i = next.fetch_add(1);
-                if (i >= n_items) break;
-                if (i < groups.size()) run_group(i);
-                else run_scalar(scalar_streams[i - groups.size()]);
+                if (i >= n_streams) break;
+                run_stream(i);
             }
         });
     for (auto& t : th) t.join();
@@ -453,6 +436,14 @@ int fvad_vad_segments(const fvad_vad* v, fvad_speech_segment* out, size_t cap, s
     if (*n) memcpy(out, v->m.segments.data(), *n * sizeof(fvad_speech_segment));
     return FVAD_OK;
 }
+int fvad_vad_lazy_stats(const fvad_vad* v, uint64_t* exact_evaluations, uint64_t* lazy_pushes)
+{
+    if (!v) return FVAD_ERR_INVALID_ARGUMENT;
+    if (exact_evaluations) *exact_evaluations = v->m.lt_exact_evals;
+    if (lazy_pushes) *lazy_pushes = v->m.lt_lazy_pushes;
+    return FVAD_OK;
+}
+
 int fvad_vad_audit_get(const fvad_vad* v, fvad_vad_audit* out)
 {
     if (!v || !out) return FVAD_ERR_INVALID_ARGUMENT;

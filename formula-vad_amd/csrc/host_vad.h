@@ -52,9 +52,20 @@ struct VadMachine {                // src/AudioPipeline/VADMachine.zig
     std::vector<fvad_speech_segment> segments;
     fvad_vad_audit audit;
 
+    // Lazily exact long-term average (see host_vad.cpp): between exact evaluations of the reference's
+    // 8437-term chain the machine carries an incrementally updated value and a rigorous bound on its
+    // distance from what the chain would give; the chain is run only when that bound cannot settle a
+    // comparison.  long_term.last_avg is current only while !lt_stale.
+    double lt_approx = 0, lt_err = 0, lt_abs = 0, lt_abs_anchor = 0;
+    bool lt_stale = false, lt_anchored = false;
+    bool lt_lazy = true; // FVAD_VAD_EAGER=1 in the environment: run the chain on every push (testing aid)
+    unsigned lt_updates = 0;
+    uint64_t lt_exact_evals = 0, lt_lazy_pushes = 0; // statistics
+    void long_term_push(float mv);
+    void long_term_exact();
+
     VadMachine(const fvad_vad_config& c, size_t sample_rate, size_t n_channels, size_t fft_size);
     fvad_vad_result run(uint64_t index, const float* channel_volumes, bool has_ratio, float ratio);
-    // pieces of run(), used by the lock-step multi-stream driver
     float min_volume(const float* channel_volumes) const;
     bool decide(double short_term_avg, double ratio_avg, double* threshold_out);
     fvad_vad_result finish_step(uint64_t index, bool threshold_met, bool has_ratio, float ratio);

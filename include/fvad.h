@@ -264,6 +264,10 @@ int fvad_vad_run(fvad_vad *v, uint64_t index, const float *channel_volumes, int 
 size_t fvad_vad_segment_count(const fvad_vad *v);
 int fvad_vad_segments(const fvad_vad *v, fvad_speech_segment *out, size_t cap, size_t *n);
 int fvad_vad_audit_get(const fvad_vad *v, fvad_vad_audit *out);
+/* How often the long-term average's full chain (RollingAverage.zig:45-56) had to be run: this build
+ * evaluates it lazily, only when a bound on the incrementally carried value cannot settle the threshold
+ * comparison (results are identical either way; see host_vad.cpp). */
+int fvad_vad_lazy_stats(const fvad_vad *v, uint64_t *exact_evaluations, uint64_t *lazy_pushes);
 /* Many independent streams at once, bit-identical to fvad_vad_run per stream: streams are
  * advanced in lock-step with the f64 re-summation vectorised ACROSS streams (same index order
  * within each).  band[s] points at [n_frames[s]][n_channels] f32, ratio[s] at [n_frames[s]].

@@ -138,6 +138,41 @@ def test_vad_machine_identical_to_oracle(fv, n_channels):
     assert ev == ev_o and m2.segments() == segs_o
 
 
+def test_vad_lazy_long_term_average_equals_eager(fv, monkeypatch):
+    # The long-term chain (8437 dependent f64 adds) is evaluated lazily: only when a rigorous bound on the
+    # incrementally carried value cannot settle `short_term > threshold` or could lower the audited minimum
+    # margin.  Events, segments and the audit must equal the eager evaluation bit for bit, on a long script
+    # whose level wanders through four decades (so that anchor-time and current magnitudes differ) and on
+    # one that hugs the threshold.
+    rng = np.random.default_rng(77)
+    n = 40000
+    level = 10 ** (np.cumsum(rng.normal(0, 0.02, n)) % 4 - 4)
+    band = (level * rng.uniform(0.5, 1.5, n)).astype(np.float32)[:, None]
+    burst = np.zeros(n, bool)
+    for s in rng.integers(0, n - 400, 120):
+        burst[s:s + int(rng.integers(5, 300))] = True
+    band[burst] *= np.float32(30)
+    # frames that sit within a hair of 10 x the running level: the comparison is nearly tied
+    near = rng.random(n) < 0.05
+    band[near, 0] = (level[near] * 10 * (1 + rng.normal(0, 1e-7, near.sum()))).astype(np.float32)
+    ratio = rng.uniform(0.3, 1.0, n).astype(np.float32)
+
+    def run():
+        m = fv.VadMachine(n_channels=1)
+        ev = [m.run(1024 * k, band[k], float(ratio[k])) for k in range(n)]
+        out = (ev, m.segments(), m.audit(), m.lazy_stats())
+        m.close()
+        return out
+
+    ev_l, seg_l, audit_l, (exact_l, lazy_l) = run()
+    monkeypatch.setenv("FVAD_VAD_EAGER", "1")
+    ev_e, seg_e, audit_e, (exact_e, lazy_e) = run()
+    assert ev_l == ev_e and seg_l == seg_e and len(seg_e) >= 5
+    assert audit_l == audit_e
+    assert lazy_e == 0 and lazy_l > 10000
+    assert exact_l < lazy_l / 20, (exact_l, lazy_l)     # the chain ran for a few percent of the pushes at most
+
+
 def test_vad_run_many_bit_identical_to_scalar(fv):
     # lock-step multi-stream driver (f64 re-sum vectorised across streams) == per-stream runs
     rng = np.random.default_rng(20)
