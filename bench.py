@@ -334,9 +334,10 @@ def main():
                               "vad_run_many": float(np.mean([h[1] for h in host_ms])),
                               "collect": float(np.mean([h[2] for h in host_ms]))},
         }
-        if not args.no_cpu_baseline:
+        # the CPU baseline and the side measurements belong to the single-GPU run only
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg, fv, weights, min(os.cpu_count() or 1, 16))
-        if not args.no_extra:
+        if not args.no_extra and world == 1:
             out["extra"] = side_measurements(pkg, fv, ctx, torch, dev)
         print(json.dumps(out))
     if world > 1:
