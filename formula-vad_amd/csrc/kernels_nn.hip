@@ -497,25 +497,44 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int rt = 0; rt < RT; ++rt) apre[rt] = *(gptr4)(a_nextitem[rt] + 16);
         const int nblk = (int)(item % (unsigned)n_blocks);
         const unsigned panel = item / (unsigned)n_blocks;
+        // The store path merges adjacent lanes only: in the MFMA layout (lane = m + 16 q) adjacent lanes
+        // are different rows and a float4 store becomes 64 separate 16-byte requests (18 B/clk per CU,
+        // tools/store_rate.hip).  A 16x4 lane transpose through the LDS crossbar (ds_bpermute, no LDS
+        // memory) makes lane 4m + q hold row m's 16 bytes at column 4q, so four adjacent lanes write
+        // 64 contiguous bytes and the same bytes drain at 50 B/clk.
+        const int bp_addr = ((lane >> 2) + 16 * (lane & 3)) * 4; // this lane's data comes from lane m + 16 q
         float* c_ptr[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const unsigned row = ((panel * WAVES + wave) * RT + rt) * 16 + m;
-            c_ptr[rt] = C + (size_t)row * (size_t)ldc + nblk * (NT * 16) + 4 * q;
+            const unsigned row = ((panel * WAVES + wave) * RT + rt) * 16 + (unsigned)(lane >> 2);
+            c_ptr[rt] = C + (size_t)row * (size_t)ldc + nblk * (NT * 16) + 4 * (lane & 3);
         }
         const int valid_t = n_valid_tiles - nblk * NT;
+        auto emit = [&](int t, int rt) {
+            f32x4 v = acc[rt][t];
+            if (ACT == FVAD_ACT_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            } else if (ACT == FVAD_ACT_SIGMOID) {
+                v.x = act_sigmoid(v.x); v.y = act_sigmoid(v.y); v.z = act_sigmoid(v.z); v.w = act_sigmoid(v.w);
+            }
+            f32x4 o;
+            o.x = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[0])));
+            o.y = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[1])));
+            o.z = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[2])));
+            o.w = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[3])));
+            *reinterpret_cast<f32x4*>(c_ptr[rt] + 16 * t) = o;
+        };
+        if (valid_t >= NT) { // every tile is stored: no per-tile branches, the permutes of many tiles overlap
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t < valid_t) {
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    f32x4 v = acc[rt][t];
-                    if (ACT == FVAD_ACT_RELU) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    } else if (ACT == FVAD_ACT_SIGMOID) {
-                        v.x = act_sigmoid(v.x); v.y = act_sigmoid(v.y); v.z = act_sigmoid(v.z); v.w = act_sigmoid(v.w);
-                    }
-                    *reinterpret_cast<f32x4*>(c_ptr[rt] + 16 * t) = v;
+                for (int rt = 0; rt < RT; ++rt) emit(t, rt);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t < valid_t) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) emit(t, rt);
                 }
             }
         }

@@ -3,6 +3,9 @@
 //   shape 0: 16 rows x 64 B per instruction (lane (m,q) -> row m, bytes 16q..)      <- the MFMA layout
 //   shape 1:  4 rows x 256 B
 //   shape 2:  1 row  x 1 KB (fully contiguous)
+//   shape 3:  8 rows x 128 B, consecutive lanes on different rows (what a row_shr:8 DPP exchange gives)
+//   shape 4:  8 rows x 128 B, 8 consecutive lanes per row
+//   shape 5: 16 rows x 64 B, 4 consecutive lanes per row (shape 0's bytes after a 16x4 lane transpose)
 // Build: hipcc --offload-arch=gfx950 -O3 store_rate.hip -o store_rate
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -15,6 +18,9 @@ __global__ __launch_bounds__(512) void store_kernel(float* C, int iters, size_t 
     size_t off;
     if (SHAPE == 0) off = (size_t)(lane & 15) * 1200 + 4 * (lane >> 4);
     else if (SHAPE == 1) off = (size_t)(lane >> 4) * 1200 + 4 * (lane & 15);
+    else if (SHAPE == 5) off = (size_t)(lane >> 2) * 1200 + 4 * (lane & 3);
+    else if (SHAPE == 4) off = (size_t)(lane >> 3) * 1200 + 4 * (lane & 7);
+    else if (SHAPE == 3) off = (size_t)(lane & 7) * 1200 + 16 * ((lane >> 3) & 1) + 4 * (lane >> 4);
     else off = 4 * lane;
     float* base = C + (size_t)blockIdx.x * wg_stride + (size_t)wave * 16 * 1200 + off;
     const f32x4 v = {1.f, 2.f, 3.f, (float)lane};
@@ -22,8 +28,9 @@ __global__ __launch_bounds__(512) void store_kernel(float* C, int iters, size_t 
         float* p = base + (size_t)it * (128 * 1200);
 #pragma unroll
         for (int t = 0; t < 15; ++t) {
-            if (SHAPE == 0) *reinterpret_cast<f32x4*>(p + 16 * t) = v;
+            if (SHAPE == 0 || SHAPE == 5) *reinterpret_cast<f32x4*>(p + 16 * t) = v;
             else if (SHAPE == 1) *reinterpret_cast<f32x4*>(p + 64 * (t % 4) + (size_t)(t / 4) * 4 * 1200) = v;
+            else if (SHAPE == 3 || SHAPE == 4) *reinterpret_cast<f32x4*>(p + 32 * (t / 2) + (size_t)(t % 2) * 8 * 1200) = v;
             else *reinterpret_cast<f32x4*>(p + 256 * (t % 4) + (size_t)(t / 4) * 1200) = v;
         }
     }
@@ -60,6 +67,10 @@ int main(int argc, char** argv)
     // few active CUs: HBM is not the limit, this is the per-CU store path
     for (int g : {8, 32, 64}) {
         run<0>(C, iters, wg_stride, 8, g);
+        run<1>(C, iters, wg_stride, 8, g);
+        run<3>(C, iters, wg_stride, 8, g);
+        run<4>(C, iters, wg_stride, 8, g);
+        run<5>(C, iters, wg_stride, 8, g);
         run<2>(C, iters, wg_stride, 8, g);
     }
     return 0;
