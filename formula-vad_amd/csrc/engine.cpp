@@ -68,16 +68,12 @@ int upload_model(fvad_ctx* ctx)
     pack_panel(w.gru1_w.data(), 1200, 400, 3, 25, 25, f);
     if ((rc = upload(ctx, m.gi1_w, f))) return rc;
     if ((rc = upload(ctx, m.gi1_b, std::vector<float>(w.gru1_b.begin(), w.gru1_b.begin() + 3 * H)))) return rc;
-    pack_gru_r(w.gru1_r.data(), H, f);
-    if ((rc = upload(ctx, m.r1, f))) return rc;
     if ((rc = upload(ctx, m.br1, std::vector<float>(w.gru1_b.begin() + 3 * H, w.gru1_b.end())))) return rc;
     pack_gru_r2(w.gru1_r.data(), H, f);
     if ((rc = upload(ctx, m.r1v2, f))) return rc;
     pack_panel(w.gru2_w.data(), 1200, 400, 3, 25, 25, f);
     if ((rc = upload(ctx, m.gi2_w, f))) return rc;
     if ((rc = upload(ctx, m.gi2_b, std::vector<float>(w.gru2_b.begin(), w.gru2_b.begin() + 3 * H)))) return rc;
-    pack_gru_r(w.gru2_r.data(), H, f);
-    if ((rc = upload(ctx, m.r2, f))) return rc;
     if ((rc = upload(ctx, m.br2, std::vector<float>(w.gru2_b.begin() + 3 * H, w.gru2_b.end())))) return rc;
     pack_gru_r2(w.gru2_r.data(), H, f);
     if ((rc = upload(ctx, m.r2v2, f))) return rc;
@@ -198,7 +194,7 @@ void time_end(fvad_ctx* ctx)
 // Large batches: the LDS-DMA kernels with 192 / 128 / 64 sequences per workgroup; small batches keep
 // one wavefront (16 sequences) per workgroup so that more CUs take part.
 struct GruChoice {
-    int version; // 1: gru_rec, 2: gru_rec2, 3: gru_rec3 (expects the z/r recurrent biases folded into gi),
+    int version; // 2: gru_rec2, 3: gru_rec3 (expects the z/r recurrent biases folded into gi),
                  // 4: gru_lat (16 sequences per workgroup, tiles split over 8 waves)
     int waves;
 };
@@ -229,7 +225,7 @@ static long padded_batch(const fvad_ctx* ctx, long n)
 
 static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, bool allow_v3)
 {
-    const char* force = getenv("FVAD_GRU_KERNEL"); // tuning aid: "v1w1", "v2w8", "v3w12", "v4w8", ...
+    const char* force = getenv("FVAD_GRU_KERNEL"); // tuning aid: "v2w8", "v3w12", "v4w8", ...
     if (force) {
         GruChoice c{force[1] - '0', atoi(force + 3)};
         if (c.version == 3 && !allow_v3) c.version = 2;
@@ -244,14 +240,14 @@ static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, bool allow_v3)
     return {allow_v3 ? 3 : 2, best};
 }
 
-static int launch_gru(fvad_ctx* ctx, GruChoice c, const float* gi, const DevBuf& r_v1, const DevBuf& r_v2, const float* bR,
+static int launch_gru(fvad_ctx* ctx, GruChoice c, const float* gi, const DevBuf& r_v2, const float* bR,
                       float* hout, long n_pad, int T)
 {
     if (c.version == 4) return fvad_launch_gru_lat(gi, r_v2.p, bR, hout, n_pad, T, ctx->stream);
     if (c.waves <= 0 || n_pad % (16 * c.waves)) return -1;
     if (c.version == 3) return fvad_launch_gru_rec3(gi, r_v2.p, bR, hout, n_pad, T, c.waves, ctx->stream);
     if (c.version == 2) return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, c.waves, ctx->stream);
-    return fvad_launch_gru_rec(gi, r_v1.p, bR, hout, n_pad, T, c.waves, ctx->stream);
+    return -1;
 }
 
 int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
@@ -296,13 +292,13 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
             time_end(ctx);
         }
         time_begin(ctx, "gru1_rec");
-        rc |= launch_gru(ctx, gc, ws.gi, m.r1, m.r1v2, m.br1.p, ws.h1, n_pad, T);
+        rc |= launch_gru(ctx, gc, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T);
         time_end(ctx);
         time_begin(ctx, "gru2_in_gemm");
         rc |= gemm(ws.h1, 400, m.gi2v2_w.p, bzr ? m.gi2_bzr.p : m.gi2_b.p, ws.gi, 1200, rows, 15, 5, 25, 400, FVAD_ACT_NONE, 75, 0, 0);
         time_end(ctx);
         time_begin(ctx, "gru2_rec");
-        rc |= launch_gru(ctx, gc, ws.gi, m.r2, m.r2v2, m.br2.p, ws.h2, n_pad, T);
+        rc |= launch_gru(ctx, gc, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T);
         time_end(ctx);
         time_begin(ctx, "fc2_gemm");
         const bool fc13 = allow_v3 && !(force && strstr(force, "fc19"));
@@ -328,13 +324,13 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     time_end(ctx);
     time_begin(ctx, "gru1_rec");
     const GruChoice gcs = pick_gru(ctx, n_pad, false);
-    rc |= launch_gru(ctx, gcs, ws.gi, m.r1, m.r1v2, m.br1.p, ws.h1, n_pad, T);
+    rc |= launch_gru(ctx, gcs, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T);
     time_end(ctx);
     time_begin(ctx, "gru2_in_gemm");
     rc |= fvad_launch_panel_gemm(ws.h1, 400, m.gi2_w.p, m.gi2_b.p, ws.gi, 1200, rows, 25, 3, 25, FVAD_ACT_NONE, 0, 0, st);
     time_end(ctx);
     time_begin(ctx, "gru2_rec");
-    rc |= launch_gru(ctx, gcs, ws.gi, m.r2, m.r2v2, m.br2.p, ws.h2, n_pad, T);
+    rc |= launch_gru(ctx, gcs, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T);
     time_end(ctx);
     time_begin(ctx, "fc2_gemm");
     rc |= fvad_launch_panel_gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, skip ? T : 0, skip, st);
@@ -525,7 +521,7 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     if (ws.fft_jobs) hipFree(ws.fft_jobs);
     if (ws.h_fft_jobs) hipHostFree(ws.h_fft_jobs);
     DeviceModel& m = ctx->dm;
-    DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.gi1_w, &m.gi1_b, &m.r1, &m.br1, &m.gi2_w, &m.gi2_b, &m.r2, &m.br2,
+    DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.gi1_w, &m.gi1_b, &m.br1, &m.gi2_w, &m.gi2_b, &m.br2,
                       &m.fc2_w, &m.fc2_b, &m.fc3_w, &m.fc3_b, &m.fc4_w, &m.fc4_b, &m.r1v2, &m.r2v2, &m.gi1f_w, &m.gi1f_b, &m.gi1v2_w, &m.gi2v2_w, &m.gi1f_bzr, &m.gi2_bzr, &m.fc2v3_w, &m.fc3v3_w, &m.fc2v3_b, &m.fc3v3_b};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (ctx->d_tables) hipFree(ctx->d_tables);

@@ -36,7 +36,6 @@ int read_onnx_nsnet2(const char* path, HostWeights& w, std::string& err);
 
 // fragment-major packing for the MFMA kernels (see kernels_nn.hip)
 void pack_panel(const float* W, int N, int K, int n_blocks, int NT, int S, std::vector<float>& out);
-void pack_gru_r(const float* R, int H, std::vector<float>& out);
 void pack_gru_r2(const float* R, int H, std::vector<float>& out);
 
 // ------------------------------------------------------------------ device model
@@ -46,7 +45,7 @@ struct DevBuf {
 };
 
 struct DeviceModel {
-    DevBuf fc1_w, fc1_b, gi1_w, gi1_b, r1, br1, gi2_w, gi2_b, r2, br2, fc2_w, fc2_b, fc3_w, fc3_b,
+    DevBuf fc1_w, fc1_b, gi1_w, gi1_b, br1, gi2_w, gi2_b, br2, fc2_w, fc2_b, fc3_w, fc3_b,
         fc4_w, fc4_b, r1v2, r2v2, gi1f_w, gi1f_b, gi1v2_w, gi2v2_w,
         fc2v3_w, fc3v3_w, fc2v3_b, fc3v3_b, // fc2/fc3 as 3 column blocks of 13 tiles for panel_gemm3
         gi1f_bzr, gi2_bzr; // input-projection biases with the recurrent z/r biases folded in (gru_rec3)

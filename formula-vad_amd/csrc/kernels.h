@@ -68,8 +68,6 @@ int fvad_launch_panel_gemm2(const float* A, int lda, const float* Wfrag, const f
 int fvad_launch_panel_gemm3(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
                             int ldc, long rows, int nt, int n_blocks, int S_steps, int K, int act,
                             int n_valid_tiles, int map_T, int map_skip, int n_wg, hipStream_t stream);
-int fvad_launch_gru_rec(const float* gi, const float* Rfrag, const float* bR, float* hout,
-                        long n_seq_pad, int T, int waves, hipStream_t stream);
 int fvad_launch_gru_rec2(const float* gi, const float* R2frag, const float* bR, float* hout,
                          long n_seq_pad, int T, int waves, hipStream_t stream);
 int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, float* hout,

@@ -573,157 +573,19 @@ int fvad_launch_panel_gemm3(const float* A, int lda, const float* Wfrag, const f
 
 // ------------------------------------------------------------------ GRU recurrence
 // h_t = GRU(gi_t, h_{t-1}) for T steps, 16 sequences per wavefront.
-//   gi   [n_seq_pad * T][3H]   = x_t W^T + Wb   (from panel_gemm), gate order z,r,h
-//   Rfrag[H/16 J][5 s5][3 g][5 Sin][64][4]      recurrent weights, fragment blocks
+//   gi   [n_seq_pad * T][3H]   = x_t W^T + Wb   (from the panel GEMMs), gate order z,r,h
+//   R2frag [25 J][3 g][25 S][64][4]             recurrent weights as 1 KB fragment blocks
 //   bR   [3H]
 //   hout [n_seq_pad * T][H]
-// Specialised for H = 400 (25 unit tiles, 25 super-steps = 5 slabs of 5).
-//
-// h_{t-1} stays in registers as the 25 activation float4s (100 VGPRs).  Each workgroup streams
-// the whole R (1.92 MB, L2-resident) through LDS once per step in 125 slabs of 15 KB
-// (3 gates x 5 super-steps of one unit tile), double-buffered; the waves of the workgroup share
-// every slab.  New h values are written straight to hout in the layout the lane itself re-reads
-// as next step's operand, so the only cross-lane traffic in the recurrence is the MFMA itself.
+// Specialised for H = 400 (25 unit tiles of 16 units, 25 super-steps of 16).  h_{t-1} stays in
+// registers as the 25 activation float4s (100 VGPRs); new h values are written straight to hout in the
+// layout the lane itself re-reads as next step's operand, so the only cross-lane traffic in the
+// recurrence is the MFMA itself.
 constexpr int GRU_H = 400;
 constexpr int GRU_J = GRU_H / 16;     // 25 unit tiles
-constexpr int GRU_S5 = 5;             // slabs per tile
-constexpr int GRU_SIN = 5;            // super-steps per slab
-constexpr int GRU_SLAB = 3 * GRU_SIN * 256; // floats per slab (15 KB)
-
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void gru_rec_kernel(const float* __restrict__ gi,
-                                                             const float* __restrict__ Rfrag,
-                                                             const float* __restrict__ bR,
-                                                             float* hout, int T)
-{
-    __shared__ __attribute__((aligned(16))) float slab[2][GRU_SLAB];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int m = lane & 15;
-    const int q = lane >> 4;
-    const long seq = (long)(blockIdx.x * WAVES + wave) * 16 + m;
-
-    const float* gi_seq = gi + seq * T * (3 * GRU_H) + 4 * q;
-    float* h_seq = hout + seq * T * GRU_H + 4 * q;
-    const float* bR_q = bR + 4 * q;
-
-    constexpr int SLAB_F4 = GRU_SLAB / 4; // 960 float4
-    constexpr int PER_T = (SLAB_F4 + WAVES * 64 - 1) / (WAVES * 64);
-
-    // ---- t = 0: h_{-1} = 0, so R h + Rb = Rb
-    for (int J = 0; J < GRU_J; ++J) {
-        const f32x4 giz = *reinterpret_cast<const f32x4*>(gi_seq + 16 * J);
-        const f32x4 gir = *reinterpret_cast<const f32x4*>(gi_seq + GRU_H + 16 * J);
-        const f32x4 gin = *reinterpret_cast<const f32x4*>(gi_seq + 2 * GRU_H + 16 * J);
-        const f32x4 bz = *reinterpret_cast<const f32x4*>(bR_q + 16 * J);
-        const f32x4 br = *reinterpret_cast<const f32x4*>(bR_q + GRU_H + 16 * J);
-        const f32x4 bn = *reinterpret_cast<const f32x4*>(bR_q + 2 * GRU_H + 16 * J);
-        f32x4 h;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float z = act_sigmoid(giz[r] + bz[r]);
-            const float rr = act_sigmoid(gir[r] + br[r]);
-            const float n = tanhf(gin[r] + rr * bn[r]);
-            h[r] = (1.0f - z) * n + z * 0.0f;
-        }
-        *reinterpret_cast<f32x4*>(h_seq + 16 * J) = h;
-    }
-
-    // ---- t >= 1
-    // prologue: slab 0 -> LDS buffer 0
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(Rfrag);
-#pragma unroll
-        for (int i = 0; i < PER_T; ++i) {
-            const int idx = tid + i * WAVES * 64;
-            if (idx < SLAB_F4) reinterpret_cast<f32x4*>(slab[0])[idx] = src[idx];
-        }
-    }
-    __syncthreads();
-    int buf = 0;
-
-    for (int t = 1; t < T; ++t) {
-        const float* gi_t = gi_seq + (long)t * (3 * GRU_H);
-        const float* h_prev = h_seq + (long)(t - 1) * GRU_H;
-        float* h_out = h_seq + (long)t * GRU_H;
-
-        // this lane's own h_{t-1}, as the activation operand of all 25 super-steps
-        f32x4 hreg[GRU_J];
-#pragma unroll
-        for (int S = 0; S < GRU_J; ++S) hreg[S] = *reinterpret_cast<const f32x4*>(h_prev + 16 * S);
-
-        for (int J = 0; J < GRU_J; ++J) {
-            // epilogue operands, issued early so they land during the MFMA phase
-            const f32x4 giz = *reinterpret_cast<const f32x4*>(gi_t + 16 * J);
-            const f32x4 gir = *reinterpret_cast<const f32x4*>(gi_t + GRU_H + 16 * J);
-            const f32x4 gin = *reinterpret_cast<const f32x4*>(gi_t + 2 * GRU_H + 16 * J);
-            const f32x4 hp = *reinterpret_cast<const f32x4*>(h_prev + 16 * J);
-            const f32x4 bz = *reinterpret_cast<const f32x4*>(bR_q + 16 * J);
-            const f32x4 br = *reinterpret_cast<const f32x4*>(bR_q + GRU_H + 16 * J);
-            const f32x4 bn = *reinterpret_cast<const f32x4*>(bR_q + 2 * GRU_H + 16 * J);
-
-            f32x4 az = (f32x4){0.f, 0.f, 0.f, 0.f};
-            f32x4 ar = az, an = az;
-
-#pragma unroll
-            for (int s5 = 0; s5 < GRU_S5; ++s5) {
-                // next slab in the (periodic) sequence
-                int nslab = J * GRU_S5 + s5 + 1;
-                if (nslab == GRU_J * GRU_S5) nslab = 0;
-                const f32x4* src = reinterpret_cast<const f32x4*>(Rfrag + (size_t)nslab * GRU_SLAB);
-                f32x4 stage[PER_T];
-#pragma unroll
-                for (int i = 0; i < PER_T; ++i) {
-                    const int idx = tid + i * WAVES * 64;
-                    if (idx < SLAB_F4) stage[i] = src[idx];
-                }
-                const f32x4* wl = reinterpret_cast<const f32x4*>(slab[buf]) + lane;
-#pragma unroll
-                for (int si = 0; si < GRU_SIN; ++si) {
-                    const f32x4 hv = hreg[s5 * GRU_SIN + si];
-                    const f32x4 wz = wl[(0 * GRU_SIN + si) * 64];
-                    const f32x4 wr = wl[(1 * GRU_SIN + si) * 64];
-                    const f32x4 wn = wl[(2 * GRU_SIN + si) * 64];
-                    az = MFMA16(wz.x, hv.x, az);
-                    ar = MFMA16(wr.x, hv.x, ar);
-                    an = MFMA16(wn.x, hv.x, an);
-                    az = MFMA16(wz.y, hv.y, az);
-                    ar = MFMA16(wr.y, hv.y, ar);
-                    an = MFMA16(wn.y, hv.y, an);
-                    az = MFMA16(wz.z, hv.z, az);
-                    ar = MFMA16(wr.z, hv.z, ar);
-                    an = MFMA16(wn.z, hv.z, an);
-                    az = MFMA16(wz.w, hv.w, az);
-                    ar = MFMA16(wr.w, hv.w, ar);
-                    an = MFMA16(wn.w, hv.w, an);
-                }
-#pragma unroll
-                for (int i = 0; i < PER_T; ++i) {
-                    const int idx = tid + i * WAVES * 64;
-                    if (idx < SLAB_F4) reinterpret_cast<f32x4*>(slab[buf ^ 1])[idx] = stage[i];
-                }
-                buf ^= 1;
-                __syncthreads();
-            }
-
-            f32x4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float z = act_sigmoid(giz[r] + (az[r] + bz[r]));
-                const float rr = act_sigmoid(gir[r] + (ar[r] + br[r]));
-                const float n = tanhf(gin[r] + rr * (an[r] + bn[r]));
-                h[r] = (1.0f - z) * n + z * hp[r];
-            }
-            *reinterpret_cast<f32x4*>(h_out + 16 * J) = h;
-        }
-    }
-}
-
 
 // ------------------------------------------------------------------ GRU recurrence, v2
-// Same math and operand convention as gru_rec_kernel, restructured for the MFMA pipe:
+// Large batches: every weight slab is shared by the wavefronts of a workgroup through LDS:
 //   * 8 wavefronts (128 sequences) per workgroup = 2 waves per SIMD, so one wave's LDS / global /
 //     epilogue latency is covered by the other wave's MFMAs;
 //   * the whole weight slab of one unit tile (3 gates x 25 super-steps = 75 KB) is staged per
@@ -1030,7 +892,7 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec3_kernel(const float* __res
 //   * h_t is exchanged through LDS in operand layout hs[S][lane] (the float4 a lane writes for unit
 //     tile J is the float4 the same lane index reads as super-step S = J), double-buffered, one
 //     barrier per step.
-// Same bias convention as gru_rec_kernel (gi holds Wx + Wb; Rb is added here).
+// gi holds Wx + Wb; Rb is added here (the convention of gru_rec2_kernel).
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __restrict__ gi,
                                                              const float* __restrict__ R2frag,
@@ -1191,15 +1053,3 @@ int fvad_launch_gru_rec3(const float* gi, const float* R2frag, const float* bR, 
     return 0;
 }
 
-// small-batch variant: one wavefront (16 sequences) per workgroup; n_seq_pad multiple of 16
-int fvad_launch_gru_rec(const float* gi, const float* Rfrag, const float* bR, float* hout,
-                        long n_seq_pad, int T, int waves, hipStream_t stream)
-{
-    if (waves == 1) {
-        hipLaunchKernelGGL((gru_rec_kernel<1>), dim3((unsigned)(n_seq_pad / 16)), dim3(64), 0,
-                           stream, gi, Rfrag, bR, hout, T);
-    } else {
-        return -1;
-    }
-    return 0;
-}

@@ -191,23 +191,6 @@ void pack_panel(const float* W, int N, int K, int n_blocks, int NT, int S, std::
                     }
 }
 
-void pack_gru_r(const float* R, int H, std::vector<float>& out)
-{
-    const int J = H / 16; // 25
-    out.assign((size_t)J * 5 * 3 * 5 * 256, 0.0f);
-    for (int j = 0; j < J; ++j)
-        for (int s5 = 0; s5 < 5; ++s5)
-            for (int g = 0; g < 3; ++g)
-                for (int si = 0; si < 5; ++si)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int r = 0; r < 4; ++r) {
-                            const int n = g * H + 16 * j + (lane & 15);
-                            const int k = 16 * (5 * s5 + si) + 4 * (lane >> 4) + r;
-                            out[((((size_t)j * 5 + s5) * 3 + g) * 5 + si) * 256 + lane * 4 + r] =
-                                R[(size_t)n * H + k];
-                        }
-}
-
 // v2 layout: one contiguous 75 KB slab per unit tile: [J][g][S][64][4]
 void pack_gru_r2(const float* R, int H, std::vector<float>& out)
 {
