@@ -5,6 +5,7 @@
 //   mode 2: + workgroup barrier every 5 steps
 //   mode 3: + LDS-DMA of a 75 KB slab every 5 steps (double buffered)
 //   mode 4: + one global float4 activation load per step per row tile (rows L2-resident)
+//   mode 14: like 4, but the first activation load of a phase is issued before that phase's slab DMA
 //   mode 5: + accumulator stores (245 KB per workgroup) every 5 phases to fresh HBM rows, accumulators reset
 //   mode 7/8: like 5 but each store instruction covers 8 rows x 128 B / 4 rows x 256 B instead of 16 rows x 64 B
 //             (timing only: the values land in the wrong places)
@@ -46,6 +47,13 @@ __global__ __launch_bounds__(512) void loop_kernel(const float* __restrict__ W, 
     f32x4 a0[2] = {*(gptr4)a_ptr[0], *(gptr4)a_ptr[1]};
     int buf = 0;
     for (int p = 0; p < phases; ++p) {
+        f32x4 a1pre[2];
+        if (MODE == 14) {
+            // the first step's activation load goes out before the slab DMA, so that waiting for it at the end
+            // of that step (vmcnt retires in order) does not also wait for the DMA
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) a1pre[rt] = *(gptr4)(a_ptr[rt] + 16 * ((p * SP + 1) % 25));
+        }
         if (MODE >= 3) {
             const float* src = W;
             float* dst = slab[buf ^ 1];
@@ -64,9 +72,12 @@ __global__ __launch_bounds__(512) void loop_kernel(const float* __restrict__ W, 
 #pragma unroll
             for (int t = 0; t < NT; ++t) w[t] = (f32x4){1.f + t, 0.5f, 0.25f, 2.f};
         }
-        for (int s = 0; s < SP; ++s) {
+        auto do_step = [&](int s, auto pre) {
             f32x4 a1[2];
-            if (MODE >= 4 && !(MODE >= 9 && (p % 5) == 0 && s < MODE - 8)) {
+            if (decltype(pre)::value) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) a1[rt] = a1pre[rt];
+            } else if (MODE >= 4 && !(MODE >= 9 && MODE < 14 && (p % 5) == 0 && s < MODE - 8)) {
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) a1[rt] = *(gptr4)(a_ptr[rt] + 16 * ((p * SP + s + 1) % 25));
             } else {
@@ -90,10 +101,16 @@ __global__ __launch_bounds__(512) void loop_kernel(const float* __restrict__ W, 
             rd += NT * 1024;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) a0[rt] = a1[rt];
+        };
+        if (MODE == 14) {
+            do_step(0, std::true_type{});
+            for (int s = 1; s < SP; ++s) do_step(s, std::false_type{});
+        } else {
+            for (int s = 0; s < SP; ++s) do_step(s, std::false_type{});
         }
         if (MODE >= 2) __syncthreads();
         if (MODE >= 3) buf ^= 1;
-        if (MODE >= 5 && p % 5 == 4) {
+        if (MODE >= 5 && MODE != 14 && p % 5 == 4) {
             const size_t item = (size_t)(p / 5) * 256 + blockIdx.x;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
@@ -162,6 +179,7 @@ int main(int argc, char** argv)
     run<2>(W, A, out, phases);
     run<3>(W, A, out, phases);
     run<4>(W, A, out, phases);
+    run<14>(W, A, out, phases);
     {
         const size_t items = (size_t)(phases / 5 + 1);
         float *C, *A2;
