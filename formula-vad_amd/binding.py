@@ -196,6 +196,8 @@ SIGNATURES = {
                                C.POINTER(VadResult)]),
     "fvad_vad_segment_count": (sz, [vp]),
     "fvad_vad_segments": (C.c_int, [vp, C.POINTER(SpeechSegment), sz, C.POINTER(sz)]),
+    "fvad_host_alloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
+    "fvad_host_free": (None, [vp, vp]),
     "fvad_vad_audit_get": (C.c_int, [vp, C.POINTER(VadAudit)]),
     "fvad_vad_lazy_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "fvad_vad_run_many": (C.c_int, [C.POINTER(vp), sz, C.POINTER(c_float_p),
@@ -404,6 +406,19 @@ class Context:
                         "band_sum": band[:nf].copy(), "chunk_rms": rms[:nc].copy(),
                         "denoised": den, "fft_bins": None if bins is None else bins[:nf].copy()})
         return out
+
+    def host_alloc(self, n_floats):
+        """page-locked float32 buffer (fvad_host_alloc) as a numpy array; release with host_free(arr)"""
+        p = vp()
+        self._ck(lib().fvad_host_alloc(self.h, int(n_floats) * 4, C.byref(p)), "fvad_host_alloc")
+        arr = np.ctypeslib.as_array(C.cast(p, c_float_p), shape=(int(n_floats),))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = self._pinned.pop(arr.ctypes.data)
+        lib().fvad_host_free(self.h, p)
 
     def lane_state(self):
         s = vp()

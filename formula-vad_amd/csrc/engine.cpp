@@ -540,6 +540,22 @@ int fvad_ctx_synchronize(fvad_ctx* ctx)
 }
 void* fvad_ctx_stream(fvad_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+int fvad_host_alloc(fvad_ctx* ctx, size_t bytes, void** out)
+{
+    if (!ctx || !out || bytes == 0) return FVAD_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    hipSetDevice(ctx->device);
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) { *out = nullptr; return set_err(ctx, FVAD_ERR_ALLOC_FAILED, "hipHostMalloc failed"); }
+    return FVAD_OK;
+}
+
+void fvad_host_free(fvad_ctx* ctx, void* p)
+{
+    if (!ctx || !p) return;
+    hipSetDevice(ctx->device);
+    hipHostFree(p);
+}
+
 int fvad_ctx_copy_to_host(fvad_ctx* ctx, void* dst_host, const void* src_device, size_t bytes)
 {
     if (!ctx || (bytes && (!dst_host || !src_device))) return FVAD_ERR_INVALID_ARGUMENT;
@@ -743,11 +759,17 @@ int staged_copy(fvad_ctx* ctx, const std::vector<CopySeg>& segs, bool to_device,
                                                  : hipMemcpyAsync(s.host, s.dev, s.bytes, hipMemcpyDeviceToHost, st));
         return FVAD_OK;
     }
-    int rc = ensure_pin(ctx, ring);
-    if (rc) return rc;
     std::vector<CopySeg> blocks;
     for (const CopySeg& s : segs) {
-        if (s.bytes < (256u << 10)) { // small pieces (band sums, RMS) would waste ring slots: copy them directly
+        bool direct = s.bytes < (256u << 10); // small pieces (band sums, RMS) would waste ring slots
+        if (!direct) {
+            // page-locked user memory (fvad_host_alloc, hipHostMalloc, hipHostRegister): the DMA engine reads
+            // or writes it in place
+            hipPointerAttribute_t attr;
+            if (hipPointerGetAttributes(&attr, s.host) == hipSuccess && attr.type == hipMemoryTypeHost) direct = true;
+            else (void)hipGetLastError(); // an unknown (pageable) pointer is reported as an error: clear it
+        }
+        if (direct) {
             if (s.bytes) FVAD_HIP(ctx, to_device ? hipMemcpyAsync(s.dev, s.host, s.bytes, hipMemcpyHostToDevice, st)
                                                  : hipMemcpyAsync(s.host, s.dev, s.bytes, hipMemcpyDeviceToHost, st));
             continue;
@@ -756,6 +778,8 @@ int staged_copy(fvad_ctx* ctx, const std::vector<CopySeg>& segs, bool to_device,
             blocks.push_back({(char*)s.host + o, (char*)s.dev + o, std::min(kPinSlotBytes, s.bytes - o)});
     }
     if (blocks.empty()) return FVAD_OK;
+    int rc = ensure_pin(ctx, ring);
+    if (rc) return rc;
     const size_t n_waves = (blocks.size() + kPinSlots - 1) / kPinSlots;
     auto wave_n = [&](size_t w) { return std::min((size_t)kPinSlots, blocks.size() - w * kPinSlots); };
     auto half = [&](size_t w) { return ring.base + (w & 1) * kPinSlots * kPinSlotBytes; };

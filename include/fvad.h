@@ -81,6 +81,13 @@ void *fvad_ctx_stream(fvad_ctx *ctx);
 /* hipMemcpyAsync(device -> host) on the context's stream: ordered after everything queued so
  * far; the bytes are valid after fvad_ctx_synchronize. */
 int fvad_ctx_copy_to_host(fvad_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+/* Page-locked host memory for audio buffers handed to fvad_engine_run / fvad_pipeline_push_samples.
+ * Optional: any host pointer is accepted, but pageable memory has to be staged through pinned rings
+ * (the host side of that moves ~25-45 GB/s), while buffers from this allocator are copied by the DMA
+ * engine directly (57 GB/s measured).  The allocator replaces the std.mem.Allocator the reference
+ * injects for its sample buffers (AudioPipeline.zig:40-44).  Free with fvad_host_free. */
+int fvad_host_alloc(fvad_ctx *ctx, size_t bytes, void **out);
+void fvad_host_free(fvad_ctx *ctx, void *p);
 
 /* ------------------------------------------------------------------ NSNet2 model
  * Replaces onnx.OnnxInstance.init(allocator, .{ .model_path = ... }) (NSNet2.zig:53-61): the

@@ -359,6 +359,19 @@ def test_engine_host_buffer_pipelining_is_invisible(fv, gpu_ctx, pkg, monkeypatc
     assert np.all(np.isfinite(a[0]["denoised"])) and np.abs(a[0]["denoised"]).max() > 0
 
 
+def test_engine_accepts_page_locked_buffers(fv, gpu_ctx, pkg):
+    # buffers from fvad_host_alloc are DMA'd in place instead of being staged: same results
+    pcm, _ = pkg.synth.make_stream(30.0, seed=5)
+    x = pcm[0][: 60 * 24000]
+    pinned = gpu_ctx.host_alloc(x.shape[0])
+    pinned[:] = x
+    a = gpu_ctx.engine_run([x.copy()] * 3, want_denoised=True)
+    b = gpu_ctx.engine_run([pinned] * 3, want_denoised=True)
+    for u, v in zip(a, b):
+        assert np.array_equal(u["denoised"], v["denoised"]) and np.array_equal(u["band_sum"], v["band_sum"])
+    gpu_ctx.host_free(pinned)
+
+
 # ------------------------------------------------------------------ B1: AudioPipeline end to end
 @pytest.mark.parametrize("n_channels,seconds,seed", [(1, 90.0, 40), (2, 60.0, 41)])
 def test_pipeline_segments_bit_identical(fv, gpu_ctx, weights7, pkg, n_channels, seconds, seed):
