@@ -1043,6 +1043,7 @@ int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes
     if (opts_in) opts = *opts_in; else fvad_engine_opts_default(&opts);
     if (!ctx->dm.loaded) return set_err(ctx, FVAD_ERR_NO_MODEL, "NSNet2 weights not loaded");
     if (lane_stride % 4) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "lane_stride must be a multiple of 4 floats");
+    if (((uintptr_t)d_pcm | (uintptr_t)d_denoised) % 16) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "device audio buffers must be 16-byte aligned");
     hipSetDevice(ctx->device);
     Workspace& ws = ctx->ws;
     hipStream_t st = ctx->stream;

@@ -478,34 +478,37 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
     }
     __syncthreads();
 
-    // overlap-add (NSNet2.zig:336): d[160 f + j] = y_{f-1}[160 + j] + y_f[j], in place into oa
-    for (int i = tid; i < kFramesPerChunk * kNHop; i += 256) {
-        const int f = i / kNHop, j = i - f * kNHop;
-        oa[f + 2][j] = ob[f + 1][j] + oa[f + 2][j];
-    }
-    __syncthreads();
+    // overlap-add (NSNet2.zig:336), d[160 f + j] = y_{f-1}[160 + j] + y_f[j], is folded into the
+    // upsampling loop below (each value is formed once, as ob + oa, where it is consumed)
+    auto ola = [&](int mdec) { // decimated output sample mdec of this chunk, 0 <= mdec < 8160
+        const int f = mdec / kNHop, j = mdec - f * kNHop;
+        return ob[f + 1][j] + oa[f + 2][j];
+    };
     if (d.last) {
         for (int j = tid; j < kNHop; j += 256) d.carry_out->ola_tail[j] = ob[kFramesPerChunk + 1][j];
-        if (tid == 0) d.carry_out->last_sample = oa[kFramesPerChunk + 1][kNHop - 1];
+        if (tid == 0) d.carry_out->last_sample = ola(kFramesPerChunk * kNHop - 1);
     }
 
-    // x3 upsample (resample.zig:32-79): out[3m+2] = d[m]; out[3m+j] = lerp(d[m-1], d[m], (j+1)/3)
-    const float* dd = &oa[2][0];
+    // x3 upsample (resample.zig:32-79): out[3m+2] = d[m]; out[3m+j] = lerp(d[m-1], d[m], (j+1)/3).
+    // Each thread turns 4 decimated samples into 12 outputs = three float4 stores (d.den is 16-byte
+    // aligned: chunk regions are 64-float aligned and 24000 % 4 == 0).
     const float frac1 = 1.0f / 3.0f, frac2 = 2.0f / 3.0f;
-    float* out = d.den;
+    f32x4* out4 = reinterpret_cast<f32x4*>(d.den);
     const float dm1 = s_dm1;
-    for (int s = tid; s < kChunk48; s += 256) {
-        const int mm = s / 3;
-        const int r = s - 3 * mm;
-        const float cur = dd[mm];
-        float o;
-        if (r == 2) {
-            o = cur;
-        } else {
-            const float prev = mm > 0 ? dd[mm - 1] : dm1;
-            o = __builtin_fmaf(cur - prev, r == 0 ? frac1 : frac2, prev); // std.math.lerp = mulAdd
-        }
-        out[s] = o;
+    for (int w = tid; w < kFramesPerChunk * kNHop / 4; w += 256) {
+        const int m0 = 4 * w;
+        const int f = m0 / kNHop, j = m0 - f * kNHop; // 160 % 4 == 0: a float4 never straddles two frames
+        const f32x4 c = *reinterpret_cast<const f32x4*>(&ob[f + 1][j]) + *reinterpret_cast<const f32x4*>(&oa[f + 2][j]);
+        const float pv = m0 > 0 ? ola(m0 - 1) : dm1;
+        // std.math.lerp = mulAdd: (b - a) * t + a, fused
+        const f32x4 o0 = {__builtin_fmaf(c.x - pv, frac1, pv), __builtin_fmaf(c.x - pv, frac2, pv), c.x,
+                          __builtin_fmaf(c.y - c.x, frac1, c.x)};
+        const f32x4 o1 = {__builtin_fmaf(c.y - c.x, frac2, c.x), c.y, __builtin_fmaf(c.z - c.y, frac1, c.y),
+                          __builtin_fmaf(c.z - c.y, frac2, c.y)};
+        const f32x4 o2 = {c.z, __builtin_fmaf(c.w - c.z, frac1, c.z), __builtin_fmaf(c.w - c.z, frac2, c.z), c.w};
+        out4[3 * w] = o0;
+        out4[3 * w + 1] = o1;
+        out4[3 * w + 2] = o2;
     }
 }
 
