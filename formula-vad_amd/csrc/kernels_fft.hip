@@ -329,8 +329,10 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
                 frow[kn] = fnk;
                 if (fl2 >= kWarmupRows) {
                     float* srow = spec_g + (size_t)(fl2 - kWarmupRows) * kNBins * 2;
-                    if (k != 80) { srow[2 * k] = xk.r; srow[2 * k + 1] = xk.i; }
-                    srow[2 * kn] = xnk.r; srow[2 * kn + 1] = xnk.i;
+                    // one 8-byte store per bin (rows start 8-byte aligned: 161 * 2 floats per row)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    if (k != 80) *reinterpret_cast<f32x2*>(srow + 2 * k) = (f32x2){xk.r, xk.i};
+                    *reinterpret_cast<f32x2*>(srow + 2 * kn) = (f32x2){xnk.r, xnk.i};
                 }
                 if (d.last && fl2 >= kFramesPerChunk) {
                     float* ft = d.carry_out->feat_tail + (fl2 - kFramesPerChunk) * kNBins;
@@ -402,8 +404,11 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
                 const float* srow = spec + ((size_t)gg * kFramesPerChunk + f) * kNBins * 2;
                 const float* grow = gains + ((size_t)gg * g_rows + g_row0 + f) * kFeatStride;
                 const int kn = 160 - k;
-                itm[u].sk_r = srow[2 * k]; itm[u].sk_i = srow[2 * k + 1];
-                itm[u].snk_r = srow[2 * kn]; itm[u].snk_i = srow[2 * kn + 1];
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 a = *reinterpret_cast<const f32x2*>(srow + 2 * k);
+                const f32x2 b = *reinterpret_cast<const f32x2*>(srow + 2 * kn);
+                itm[u].sk_r = a.x; itm[u].sk_i = a.y;
+                itm[u].snk_r = b.x; itm[u].snk_i = b.y;
                 itm[u].gk = grow[k]; itm[u].gnk = grow[kn];
             }
         }
