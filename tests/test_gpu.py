@@ -372,6 +372,41 @@ def test_engine_accepts_page_locked_buffers(fv, gpu_ctx, pkg):
     gpu_ctx.host_free(pinned)
 
 
+def test_two_contexts_on_two_threads(fv, weights7, pkg):
+    # contexts are thread-confined like the reference's one-pipeline-per-thread model
+    # (simulator.zig:225-231): two of them driven concurrently give what each gives alone
+    import threading
+    streams = [pkg.synth.make_stream(12.0, seed=60 + i)[0][0][: 24 * 24000].copy() for i in range(2)]
+    solo = []
+    for x in streams:
+        c = fv.Context(0)
+        c.load_weights(weights7)
+        solo.append(c.engine_run([x] * 4, want_denoised=True)[0])
+        c.close()
+    got = [None, None]
+    errs = []
+
+    def work(i):
+        try:
+            c = fv.Context(0)
+            c.load_weights(weights7)
+            for _ in range(3):
+                got[i] = c.engine_run([streams[i]] * 4, want_denoised=True)[0]
+            c.close()
+        except Exception as e:  # surfaced below
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert np.array_equal(got[i]["denoised"], solo[i]["denoised"])
+        assert np.array_equal(got[i]["band_sum"], solo[i]["band_sum"])
+
+
 # ------------------------------------------------------------------ B1: AudioPipeline end to end
 @pytest.mark.parametrize("n_channels,seconds,seed", [(1, 90.0, 40), (2, 60.0, 41)])
 def test_pipeline_segments_bit_identical(fv, gpu_ctx, weights7, pkg, n_channels, seconds, seed):
