@@ -122,6 +122,42 @@ __device__ __forceinline__ void lane_tw_load(LaneTw<R, L>& tw, const float* tabl
     }
 }
 
+// value of lane (l ^ H).  __shfl_xor compiles to ds_bpermute_b32, which goes through the LDS pipe; the DIF
+// butterflies only need fixed xor patterns, and those exist as VALU data movement: quad permutes and
+// row rotates as DPP modifiers (H = 1, 2, 4, 8), gfx950's v_permlane16/32_swap for the row- and
+// half-crossing strides.
+template <int H> __device__ __forceinline__ float lane_xor(float v, int lane)
+{
+    const int x = __float_as_int(v);
+    int r;
+    if constexpr (H == 1) r = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+    else if constexpr (H == 2) r = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    else if constexpr (H == 4) {
+        r = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);                 // row_shl:4 into banks 0, 2
+        r = __builtin_amdgcn_update_dpp(r, x, 0x114, 0xF, 0xA, false);                 // row_shr:4 into banks 1, 3
+    } else if constexpr (H == 8) r = __builtin_amdgcn_mov_dpp(x, 0x128, 0xF, 0xF, true); // row_ror:8
+    else if constexpr (H == 16) {
+        const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+        r = (int)((lane & 16) ? sw[0] : sw[1]);
+    } else {
+        static_assert(H == 32, "lane_xor: stride");
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+        r = (int)((lane & 32) ? sw[0] : sw[1]);
+    }
+    return __int_as_float(r);
+}
+__device__ __forceinline__ float lane_xor_dyn(float v, int h, int lane) // h is a constant after unrolling
+{
+    switch (h) {
+    case 1: return lane_xor<1>(v, lane);
+    case 2: return lane_xor<2>(v, lane);
+    case 4: return lane_xor<4>(v, lane);
+    case 8: return lane_xor<8>(v, lane);
+    case 16: return lane_xor<16>(v, lane);
+    default: return lane_xor<32>(v, lane);
+    }
+}
+
 // v[j] = z[p + L j] in, v[k1] = Z[k1 + R * bitrev_L(p)] out.
 template <int R, int L, bool INV>
 __device__ __forceinline__ void wave_fft(cpx (&v)[R], const LaneTw<R, L>& tw, int p)
@@ -137,8 +173,8 @@ __device__ __forceinline__ void wave_fft(cpx (&v)[R], const LaneTw<R, L>& tw, in
         for (int k1 = 0; k1 < R; ++k1) {
             const cpx mine = v[k1];
             cpx other;
-            other.r = __shfl_xor(mine.r, h, 64);
-            other.i = __shfl_xor(mine.i, h, 64);
+            other.r = lane_xor_dyn(mine.r, h, p); // bit h of p is bit h of the lane index for every h < L
+            other.i = lane_xor_dyn(mine.i, h, p);
             // lower lane: a + b ; upper lane: (a_low - a_high) * w = (other - mine) * w
             const cpx t = upper ? csub(other, mine) : cadd(mine, other);
             v[k1] = cmul(t, tw.stage[s]);
