@@ -122,7 +122,7 @@ def cpu_model():
     return "unknown"
 
 
-def pmc_traffic(chunks_per_launch):
+def pmc_traffic(chunks_per_launch, raw=False):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_summary.json; counters cannot be read from inside the benchmark), or None when
     the profile was taken at a different launch size."""
@@ -133,7 +133,7 @@ def pmc_traffic(chunks_per_launch):
             return None
         for k, v in d["kernels"].items():
             if k.startswith("gru_rec3_kernel") or k.startswith("gru_rec2_kernel"):
-                return v["hbm_bytes_per_launch"]
+                return v["hbm_bytes_per_launch"] if not raw else v.get("hbm_bytes_per_launch_raw_counters")
     except Exception:
         pass
     return None
@@ -316,6 +316,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gru_rec3_kernel<12, 2> (fp32 v_mfma_f32_16x16x4_f32)",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(lanes * n_chunks),
+                         # FETCH_SIZE + WRITE_SIZE without the guide's x2 fetch correction: for this kernel's 64-byte
+                         # row segments the uncorrected sum equals the algorithmic 21.2 GB
+                         "traffic_uncorrected_counters": pmc_traffic(lanes * n_chunks, raw=True),
+                         "algorithmic_hbm_bytes_per_launch": lanes * n_chunks * (54 * 1200 * 4 + 2 * 54 * 400 * 4),
                          "launch_ms": gru_ms, "flop_per_launch": gru_flop},
             "roofline_pipeline": {
                 "nsnet2_executed_tflops": lanes * n_chunks * NSNET2_EXECUTED_FLOP_PER_CHUNK / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
