@@ -333,9 +333,14 @@ int read_onnx_nsnet2(const char* path, HostWeights& hw, std::string& err)
 
     std::map<std::string, Tensor> inits;
     std::vector<Node> nodes;
+    std::vector<std::string> graph_inputs; // GraphProto.input = 11 -> ValueInfoProto.name = 1
     while (graph.next(f, w, sub, v)) {
         if (w != 2) continue;
-        if (f == 5) { std::string name; Tensor t; if (!parse_tensor(sub, name, t)) { err = "bad TensorProto"; return FVAD_ERR_MODEL_FORMAT; } inits[name] = std::move(t); }
+        if (f == 11) {
+            Cursor vi = sub; uint32_t vf, vw; Cursor vs{nullptr, nullptr}; uint64_t vv;
+            while (vi.next(vf, vw, vs, vv))
+                if (vf == 1 && vw == 2) graph_inputs.emplace_back((const char*)vs.p, (size_t)(vs.end - vs.p));
+        } else if (f == 5) { std::string name; Tensor t; if (!parse_tensor(sub, name, t)) { err = "bad TensorProto"; return FVAD_ERR_MODEL_FORMAT; } inits[name] = std::move(t); }
         else if (f == 1) { Node n; if (!parse_node(sub, n)) { err = "bad NodeProto"; return FVAD_ERR_MODEL_FORMAT; } nodes.push_back(std::move(n)); }
     }
     if (!graph.ok) { err = "truncated GraphProto"; return FVAD_ERR_MODEL_FORMAT; }
@@ -385,7 +390,19 @@ int read_onnx_nsnet2(const char* path, HostWeights& hw, std::string& err)
             if (!(n.iattr.count("linear_before_reset") && n.iattr.at("linear_before_reset") == 1)) {
                 err = "GRU without linear_before_reset=1 is not the NSNet2-baseline export"; return FVAD_ERR_MODEL_FORMAT;
             }
-            if (n.in.size() >= 6 && !n.in[5].empty()) { err = "GRU with initial_h input is not supported"; return FVAD_ERR_MODEL_FORMAT; }
+            // initial_h: the reference feeds the session one tensor and no state (NSNet2.zig:57-58,71-112), so an
+            // initial state can only be a constant of the graph.  PyTorch exports of nn.GRU without h0 wire a
+            // zeros tensor built from shape ops into this input: accepted.  An all-zero initializer: accepted.
+            // A non-zero initializer or a real graph input would be a stateful model: refused.
+            if (n.in.size() >= 6 && !n.in[5].empty()) {
+                const std::string& h0 = n.in[5];
+                if (const Tensor* t0 = init_of(h0)) {
+                    for (float x : t0->data) if (x != 0.0f) { err = "GRU with a non-zero initial_h is not supported"; return FVAD_ERR_MODEL_FORMAT; }
+                } else {
+                    for (const std::string& gi_name : graph_inputs)
+                        if (gi_name == h0) { err = "GRU state is a graph input: stateful models are not supported"; return FVAD_ERR_MODEL_FORMAT; }
+                }
+            }
             grus.push_back({W, R, B});
         }
     }

@@ -287,8 +287,10 @@ def _node(op, ins, outs, iattrs=None):
     return n
 
 
-def _make_onnx(wd, gemm=False):
-    """hand-encode the NSNet2-baseline graph (MatMul+Add / GRU with linear_before_reset) as protobuf"""
+def _make_onnx(wd, gemm=False, h0=None):
+    """hand-encode the NSNet2-baseline graph (MatMul+Add / GRU with linear_before_reset) as protobuf.
+    h0: None = GRU nodes without initial_h; "computed" = a zeros tensor built by shape ops (what PyTorch
+    exports for nn.GRU without h0); "zeros" / "nonzero" = an initializer; "input" = a graph input."""
     inits, nodes = [], []
 
     def dense(i, x, y, w, b, act=None):
@@ -312,7 +314,17 @@ def _make_onnx(wd, gemm=False):
         inits.append(_tensor(f"W{g}", wd[f"gru{g}_w"][None]))
         inits.append(_tensor(f"R{g}", wd[f"gru{g}_r"][None]))
         inits.append(_tensor(f"B{g}", wd[f"gru{g}_b"][None]))
-        nodes.append(_node("GRU", [cur, f"W{g}", f"R{g}", f"B{g}"], [f"y{g}", f"h{g}"],
+        gru_in = [cur, f"W{g}", f"R{g}", f"B{g}"]
+        if h0 == "computed":
+            nodes.append(_node("Shape", [cur], [f"shp{g}"]))
+            nodes.append(_node("ConstantOfShape", [f"shp{g}"], [f"h0_{g}"]))
+            gru_in += ["", f"h0_{g}"]
+        elif h0 in ("zeros", "nonzero"):
+            inits.append(_tensor(f"h0_{g}", np.full((1, 1, 400), 0.0 if h0 == "zeros" else 0.25, np.float32)))
+            gru_in += ["", f"h0_{g}"]
+        elif h0 == "input":
+            gru_in += ["", f"h0_{g}"]
+        nodes.append(_node("GRU", gru_in, [f"y{g}", f"h{g}"],
                            {"hidden_size": 400, "linear_before_reset": 1}))
         nodes.append(_node("Squeeze", [f"y{g}"], [f"s{g}"]))
         cur = f"s{g}"
@@ -321,6 +333,9 @@ def _make_onnx(wd, gemm=False):
     x = dense(3, x, "r3", "fc3_w", "fc3_b", "Relu")
     dense(4, x, "output", "fc4_w", "fc4_b", "Sigmoid")
     graph = b"".join(_ld(1, n) for n in nodes) + _ld(2, b"nsnet2") + b"".join(_ld(5, t) for t in inits)
+    graph += _ld(11, _ld(1, b"input"))                       # GraphProto.input: ValueInfoProto{name}
+    if h0 == "input":
+        graph += _ld(11, _ld(1, b"h0_1")) + _ld(11, _ld(1, b"h0_2"))
     return _vi(1, 7) + _ld(2, b"pytorch") + _ld(7, graph)
 
 
@@ -331,6 +346,22 @@ def test_onnx_reader_roundtrip(fv, weights7, tmp_path, gemm):
     got = fv.read_onnx(str(path))
     for k in fv.WEIGHT_NAMES:
         assert np.array_equal(got[k], weights7[k]), k
+
+
+@pytest.mark.parametrize("h0,ok", [("computed", True), ("zeros", True), ("nonzero", False), ("input", False)])
+def test_onnx_reader_initial_state_variants(fv, weights7, tmp_path, h0, ok):
+    # the reference feeds the session one tensor and no state (NSNet2.zig:57-58): a constant zero
+    # initial_h (as PyTorch exports it) is the same model; a non-zero or externally fed state is not
+    path = tmp_path / f"h0_{h0}.onnx"
+    path.write_bytes(_make_onnx(weights7, h0=h0))
+    if ok:
+        got = fv.read_onnx(str(path))
+        for k in fv.WEIGHT_NAMES:
+            assert np.array_equal(got[k], weights7[k]), k
+    else:
+        L = fv.lib()
+        w, owner = fv.Weights(), C.c_void_p()
+        assert L.fvad_onnx_read_nsnet2(str(path).encode(), C.byref(w), C.byref(owner)) == -104
 
 
 def test_onnx_reader_errors(fv, weights7, tmp_path):
