@@ -262,6 +262,8 @@ struct Node {
     std::string op;
     std::vector<std::string> in, out;
     std::map<std::string, int64_t> iattr;
+    bool has_tensor = false; // AttributeProto.t (a Constant node's value)
+    Tensor tensor;
 };
 
 bool parse_tensor(Cursor c, std::string& name, Tensor& t)
@@ -302,6 +304,11 @@ bool parse_node(Cursor c, Node& n)
             while (a.next(af, aw, as, av)) {
                 if (af == 1 && aw == 2) an.assign((const char*)as.p, (size_t)(as.end - as.p));
                 else if (af == 3 && aw == 0) { ai = (int64_t)av; has_i = true; }
+                else if (af == 5 && aw == 2) { // AttributeProto.t
+                    std::string tn; Tensor t;
+                    if (!parse_tensor(as, tn, t)) return false;
+                    n.tensor = std::move(t); n.has_tensor = true;
+                }
             }
             if (has_i) n.iattr[an] = ai;
         }
@@ -344,6 +351,9 @@ int read_onnx_nsnet2(const char* path, HostWeights& hw, std::string& err)
         else if (f == 1) { Node n; if (!parse_node(sub, n)) { err = "bad NodeProto"; return FVAD_ERR_MODEL_FORMAT; } nodes.push_back(std::move(n)); }
     }
     if (!graph.ok) { err = "truncated GraphProto"; return FVAD_ERR_MODEL_FORMAT; }
+    // some exporters emit weights and biases as Constant nodes instead of initializers
+    for (Node& n : nodes)
+        if (n.op == "Constant" && n.has_tensor && !n.out.empty() && !inits.count(n.out[0])) inits[n.out[0]] = std::move(n.tensor);
 
     // walk the nodes in file (topological) order: 4 dense layers (MatMul or Gemm + Add) and 2 GRUs
     struct Dense { std::vector<float> w; std::vector<float> b; int in = 0, out = 0; bool have_b = false; };

@@ -287,20 +287,24 @@ def _node(op, ins, outs, iattrs=None):
     return n
 
 
-def _make_onnx(wd, gemm=False, h0=None):
+def _make_onnx(wd, gemm=False, h0=None, const_nodes=False):
     """hand-encode the NSNet2-baseline graph (MatMul+Add / GRU with linear_before_reset) as protobuf.
     h0: None = GRU nodes without initial_h; "computed" = a zeros tensor built by shape ops (what PyTorch
     exports for nn.GRU without h0); "zeros" / "nonzero" = an initializer; "input" = a graph input."""
-    inits, nodes = [], []
+    inits, nodes, init_names = [], [], []
+
+    def add_init(name, arr, raw=True):
+        inits.append(_tensor(name, arr, raw))
+        init_names.append(name)
 
     def dense(i, x, y, w, b, act=None):
         if gemm:
-            inits.append(_tensor(f"w{i}", wd[w]))            # [out][in], transB=1
-            inits.append(_tensor(f"b{i}", wd[b], raw=False))
+            add_init(f"w{i}", wd[w])  # [out][in], transB=1
+            add_init(f"b{i}", wd[b], raw=False)
             nodes.append(_node("Gemm", [x, f"w{i}", f"b{i}"], [f"d{i}"], {"transB": 1}))
         else:
-            inits.append(_tensor(f"w{i}", wd[w].T))          # MatMul B operand is [in][out]
-            inits.append(_tensor(f"b{i}", wd[b]))
+            add_init(f"w{i}", wd[w].T)  # MatMul B operand is [in][out]
+            add_init(f"b{i}", wd[b])
             nodes.append(_node("MatMul", [x, f"w{i}"], [f"m{i}"]))
             nodes.append(_node("Add", [f"b{i}", f"m{i}"], [f"d{i}"]))
         if act:
@@ -311,16 +315,16 @@ def _make_onnx(wd, gemm=False, h0=None):
     nodes.append(_node("Transpose", [x], ["t0"]))
     cur = "t0"
     for g in (1, 2):
-        inits.append(_tensor(f"W{g}", wd[f"gru{g}_w"][None]))
-        inits.append(_tensor(f"R{g}", wd[f"gru{g}_r"][None]))
-        inits.append(_tensor(f"B{g}", wd[f"gru{g}_b"][None]))
+        add_init(f"W{g}", wd[f"gru{g}_w"][None])
+        add_init(f"R{g}", wd[f"gru{g}_r"][None])
+        add_init(f"B{g}", wd[f"gru{g}_b"][None])
         gru_in = [cur, f"W{g}", f"R{g}", f"B{g}"]
         if h0 == "computed":
             nodes.append(_node("Shape", [cur], [f"shp{g}"]))
             nodes.append(_node("ConstantOfShape", [f"shp{g}"], [f"h0_{g}"]))
             gru_in += ["", f"h0_{g}"]
         elif h0 in ("zeros", "nonzero"):
-            inits.append(_tensor(f"h0_{g}", np.full((1, 1, 400), 0.0 if h0 == "zeros" else 0.25, np.float32)))
+            add_init(f"h0_{g}", np.full((1, 1, 400), 0.0 if h0 == "zeros" else 0.25, np.float32))
             gru_in += ["", f"h0_{g}"]
         elif h0 == "input":
             gru_in += ["", f"h0_{g}"]
@@ -332,6 +336,12 @@ def _make_onnx(wd, gemm=False, h0=None):
     x = dense(2, "t1", "r2", "fc2_w", "fc2_b", "Relu")
     x = dense(3, x, "r3", "fc3_w", "fc3_b", "Relu")
     dense(4, x, "output", "fc4_w", "fc4_b", "Sigmoid")
+    if const_nodes:  # every weight as a Constant node (AttributeProto{name="value", t=tensor, type=TENSOR})
+        consts = []
+        for name, t in zip(init_names, inits):
+            consts.append(_ld(2, name.encode()) + _ld(4, b"Constant") + _ld(5, _ld(1, b"value") + _ld(5, t) + _vi(20, 4)))
+        nodes = consts + nodes
+        inits = []
     graph = b"".join(_ld(1, n) for n in nodes) + _ld(2, b"nsnet2") + b"".join(_ld(5, t) for t in inits)
     graph += _ld(11, _ld(1, b"input"))                       # GraphProto.input: ValueInfoProto{name}
     if h0 == "input":
@@ -343,6 +353,14 @@ def _make_onnx(wd, gemm=False, h0=None):
 def test_onnx_reader_roundtrip(fv, weights7, tmp_path, gemm):
     path = tmp_path / "nsnet2-20ms-baseline.onnx"
     path.write_bytes(_make_onnx(weights7, gemm))
+    got = fv.read_onnx(str(path))
+    for k in fv.WEIGHT_NAMES:
+        assert np.array_equal(got[k], weights7[k]), k
+
+
+def test_onnx_reader_weights_as_constant_nodes(fv, weights7, tmp_path):
+    path = tmp_path / "const.onnx"
+    path.write_bytes(_make_onnx(weights7, const_nodes=True))
     got = fv.read_onnx(str(path))
     for k in fv.WEIGHT_NAMES:
         assert np.array_equal(got[k], weights7[k]), k
