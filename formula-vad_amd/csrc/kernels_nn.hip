@@ -940,6 +940,16 @@ __global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __rest
         return (gptr4)(R2frag + (size_t)J * GRU2_SLAB + (size_t)(g * GRU_J + S) * 256 + lane * 4);
     };
 
+    // The fragment ring runs across unit tiles *and* across time steps (the weights do not depend on h):
+    // after a wavefront's last tile of a step it is refilled with the first tile of the next step, so
+    // a step starts with its first five super-steps already on the way.
+    f32x4 wz[D], wr[D], wn[D];
+#pragma unroll
+    for (int S = 0; S < D; ++S) {
+        wz[S] = *frag(wave, 0, S);
+        wr[S] = *frag(wave, 1, S);
+        wn[S] = *frag(wave, 2, S);
+    }
     for (int t = 1; t < T; ++t) {
         const float* gi_t = gi_seq + (size_t)t * (3 * GRU_H);
         float* h_out = h_seq + (size_t)t * GRU_H;
@@ -950,15 +960,8 @@ __global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __rest
 #pragma unroll
         for (int S = 0; S < GRU_J; ++S) hreg[S] = hcur[S * 64];
 
-        f32x4 wz[D], wr[D], wn[D];
-#pragma unroll
-        for (int S = 0; S < D; ++S) {
-            wz[S] = *frag(wave, 0, S);
-            wr[S] = *frag(wave, 1, S);
-            wn[S] = *frag(wave, 2, S);
-        }
         for (int J = wave; J < GRU_J; J += WAVES) {
-            const int Jn = (J + WAVES < GRU_J) ? J + WAVES : J; // next tile of this wave (or a harmless re-read)
+            const int Jn = (J + WAVES < GRU_J) ? J + WAVES : wave; // this wave's next tile; after the last one, its first tile of the next step
             f32x4 az = (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 ar = az, an = az;
             f32x4 giz, gir, gin, hp, bz, br, bn;
