@@ -501,6 +501,34 @@ def side_measurements(pkg, fv, ctx, torch, dev):
         del big, b4, r4, base
     except Exception as e:  # e.g. not enough free HBM next to other tenants
         extra["cfg4_shape_21_streams_x_7200s_one_gpu"] = {"error": repr(e)}
+    # BASELINE config 5's "hipGraph-captured steady-state loop": the same device-resident call launched
+    # directly and replayed from a captured hipGraph (FVAD_GRAPH=1), at a large and at the smallest shape
+    try:
+        for tag, n_l2, n_ch2, reps in (("16384_chunks", 128, 128, 6), ("2_chunks", 2, 1, 40)):
+            xg = torch.from_numpy(np.stack([host_pcm[i % len(host_pcm)][: n_ch2 * CHUNK] for i in range(n_l2)])).to(dev)
+            bg = torch.empty((n_l2, max(1, n_ch2 * CHUNK // 1024)), device=dev)
+            rg = torch.empty((n_l2, n_ch2), device=dev)
+            dg = torch.empty((n_l2, n_ch2 * CHUNK), device=dev)
+            res = {}
+            for mode in ("direct", "graph"):
+                if mode == "graph":
+                    os.environ["FVAD_GRAPH"] = "1"
+                else:
+                    os.environ.pop("FVAD_GRAPH", None)
+                for it in range(reps + 2):
+                    if it == 2:
+                        ctx.synchronize()
+                        t0 = time.perf_counter()
+                    fv.check(L.fvad_engine_enqueue_device(ctx.h, xg.data_ptr(), n_l2, xg.stride(0), n_ch2 * CHUNK, dg.data_ptr(),
+                                                          bg.data_ptr(), rg.data_ptr(), None), "graph bench", ctx.h)
+                ctx.synchronize()
+                res[mode] = (time.perf_counter() - t0) / reps * 1e3
+            os.environ.pop("FVAD_GRAPH", None)
+            extra[f"hipgraph_replay_{tag}"] = {"direct_ms": res["direct"], "graph_ms": res["graph"],
+                                               "note": "per call of fvad_engine_enqueue_device; ~12 kernel launches per launch batch"}
+            del xg, bg, rg, dg
+    except Exception as e:
+        extra["hipgraph_replay"] = {"error": repr(e)}
     extra["cfg3_82_chunks_4100_frames"] = {"ms": dt * 1e3, "frames_per_s": 4100 / dt,
                                            "note": "latency-bound: 54 dependent GRU steps x 2 layers over only 82 sequences (gru_lat_kernel: one 16-sequence workgroup per CU, unit tiles split over 8 waves)"}
     return extra

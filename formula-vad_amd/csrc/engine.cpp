@@ -171,6 +171,7 @@ int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
     if ((rc = dev_alloc(ctx, &ws.f3, rows * 608, true))) return rc;
     if ((rc = dev_alloc(ctx, &ws.gains, rows * kFeatStride, true))) return rc;
     ws.cap_chunks = G;
+    ws.generation++;
     ws.T = TT;
     return FVAD_OK;
 }
@@ -347,8 +348,11 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
 }
 
 // K1 -> NSNet2 -> K3 over every chunk of every job, in launches of <= max_chunks chunks.
-int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks)
+int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, ChunkDesc* capture_descs)
 {
+    // capture_descs != nullptr: the call is being captured into a hipGraph.  Every launch gets its own
+    // region of that pinned table (a replay re-reads it), and no event is waited for or recorded.
+    size_t capture_off = 0;
     if (max_chunks <= 0) {
         const char* e = getenv("FVAD_MAX_CHUNKS"); // tuning aid
         max_chunks = e ? atol(e) : 49152;
@@ -369,9 +373,13 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks)
         // pinned descriptor table: two slots, so the host can build the next launch while the GPU still
         // runs this one; a slot is free once its (tiny) upload has been consumed
         const int slot = ws.desc_slot;
-        ws.desc_slot ^= 1;
-        FVAD_HIP(ctx, hipEventSynchronize(ws.desc_ev[slot]));
-        ChunkDesc* hd = ws.h_descs + (size_t)slot * (size_t)ws.cap_chunks;
+        ChunkDesc* hd;
+        if (capture_descs) hd = capture_descs + capture_off;
+        else {
+            ws.desc_slot ^= 1;
+            FVAD_HIP(ctx, hipEventSynchronize(ws.desc_ev[slot]));
+            hd = ws.h_descs + (size_t)slot * (size_t)ws.cap_chunks;
+        }
         size_t j = job, c = chunk_in_job;
         while (j < jobs.size() && n < cap) {
             LaneJob& lj = jobs[j];
@@ -394,7 +402,8 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks)
         }
         // the stream orders this copy after the previous launch's kernels
         FVAD_HIP(ctx, hipMemcpyAsync(ws.descs, hd, (size_t)n * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
-        FVAD_HIP(ctx, hipEventRecord(ws.desc_ev[slot], ctx->stream));
+        if (capture_descs) capture_off += (size_t)n;
+        else FVAD_HIP(ctx, hipEventRecord(ws.desc_ev[slot], ctx->stream));
         time_begin(ctx, "stft320_logpow");
         fvad_launch_stft(ws.descs, (int)n, ctx->tb, ws.feat, ws.spec, ctx->stream);
         time_end(ctx);
@@ -513,6 +522,10 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
         if (r->base) hipHostFree(r->base);
         for (hipEvent_t& e : r->ev) if (e) hipEventDestroy(e);
     }
+    if (ws.graph.exec) hipGraphExecDestroy(ws.graph.exec);
+    if (ws.graph.graph) hipGraphDestroy(ws.graph.graph);
+    if (ws.graph.h_descs) hipHostFree(ws.graph.h_descs);
+    if (ws.graph.h_jobs) hipHostFree(ws.graph.h_jobs);
     for (hipEvent_t& e : ws.grp_in) if (e) hipEventDestroy(e);
     for (hipEvent_t& e : ws.grp_k) if (e) hipEventDestroy(e);
     if (ws.copy_in) hipStreamDestroy(ws.copy_in);
@@ -707,6 +720,7 @@ static int grow(fvad_ctx* ctx, float** p, size_t* cap, size_t need)
     *cap = 0;
     FVAD_HIP(ctx, hipMalloc((void**)p, need * sizeof(float)));
     *cap = need;
+    ctx->ws.generation++;
     return FVAD_OK;
 }
 
@@ -1064,36 +1078,97 @@ int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes
         ws.carries = nullptr; ws.carries_cap = 0;
         FVAD_HIP(ctx, hipMalloc((void**)&ws.carries, n_scratch * sizeof(LaneCarry)));
         ws.carries_cap = n_scratch * sizeof(LaneCarry);
+        ws.generation++;
     }
-    FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
-    std::vector<LaneJob> jobs(n_lanes);
-    for (size_t l = 0; l < n_lanes; ++l) {
-        jobs[l].d_in = d_pcm + l * lane_stride;
-        jobs[l].d_den = den + l * n_den;
-        jobs[l].n_chunks = n_chunks;
-        jobs[l].carry[0] = ws.carries + 2 * l;
-        jobs[l].carry[1] = ws.carries + 2 * l + 1;
-        jobs[l].cur = 0;
-        jobs[l].d_rms = d_chunk_rms ? d_chunk_rms + l * n_chunks : nullptr;
+    if (ws.fft_jobs_cap < n_lanes) {
+        hipStreamSynchronize(st);
+        if (ws.fft_jobs) hipFree(ws.fft_jobs);
+        if (ws.h_fft_jobs) hipHostFree(ws.h_fft_jobs);
+        ws.fft_jobs = nullptr; ws.h_fft_jobs = nullptr; ws.fft_jobs_cap = 0;
+        FVAD_HIP(ctx, hipMalloc((void**)&ws.fft_jobs, n_lanes * sizeof(VadFftJob)));
+        FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_fft_jobs, n_lanes * sizeof(VadFftJob), hipHostMallocDefault));
+        ws.fft_jobs_cap = n_lanes;
+        ws.generation++;
     }
-    if ((rc = run_chunks(ctx, jobs, opts.max_chunks_per_launch))) return rc;
-    {
-        // one launch for every lane's frames
-        if (ws.fft_jobs_cap < n_lanes) {
-            if (ws.fft_jobs) hipFree(ws.fft_jobs);
-            if (ws.h_fft_jobs) hipHostFree(ws.h_fft_jobs);
-            ws.fft_jobs = nullptr; ws.h_fft_jobs = nullptr; ws.fft_jobs_cap = 0;
-            FVAD_HIP(ctx, hipMalloc((void**)&ws.fft_jobs, n_lanes * sizeof(VadFftJob)));
-            FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_fft_jobs, n_lanes * sizeof(VadFftJob), hipHostMallocDefault));
-            ws.fft_jobs_cap = n_lanes;
+
+    // the launch sequence of one call: carries reset, (descriptor upload, K1, NSNet2, K3) per launch, K4
+    auto enqueue = [&](ChunkDesc* capture_descs, VadFftJob* h_jobs) -> int {
+        FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
+        std::vector<LaneJob> jobs(n_lanes);
+        for (size_t l = 0; l < n_lanes; ++l) {
+            jobs[l].d_in = d_pcm + l * lane_stride;
+            jobs[l].d_den = den + l * n_den;
+            jobs[l].n_chunks = n_chunks;
+            jobs[l].carry[0] = ws.carries + 2 * l;
+            jobs[l].carry[1] = ws.carries + 2 * l + 1;
+            jobs[l].cur = 0;
+            jobs[l].d_rms = d_chunk_rms ? d_chunk_rms + l * n_chunks : nullptr;
         }
-        for (size_t l = 0; l < n_lanes; ++l) ws.h_fft_jobs[l] = {den + l * n_den, d_band_sum + l * n_frames, nullptr, (long)n_frames};
-        FVAD_HIP(ctx, hipMemcpyAsync(ws.fft_jobs, ws.h_fft_jobs, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice, st));
+        int r = run_chunks(ctx, jobs, opts.max_chunks_per_launch, capture_descs);
+        if (r) return r;
+        // one K4 launch for every lane's frames
+        for (size_t l = 0; l < n_lanes; ++l) h_jobs[l] = {den + l * n_den, d_band_sum + l * n_frames, nullptr, (long)n_frames};
+        FVAD_HIP(ctx, hipMemcpyAsync(ws.fft_jobs, h_jobs, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice, st));
         time_begin(ctx, "fft1024_bandsum");
         fvad_launch_vadfft_jobs(ws.fft_jobs, (int)n_lanes, (long)n_frames, ctx->tb, opts.min_bin, opts.max_bin, st);
         time_end(ctx);
-        FVAD_HIP(ctx, hipStreamSynchronize(st)); // the pinned job table is reused by the next call
+        return FVAD_OK;
+    };
+
+    // Opt-in (FVAD_GRAPH=1): capture the sequence into a hipGraph once and replay it while the arguments
+    // and the workspace stay the same -- BASELINE config 5's "hipGraph-captured steady-state loop".  A step
+    // is ~12 launches per 100 ms of GPU work, so this saves well under 1 % (measured in bench.py's extras).
+    if (getenv("FVAD_GRAPH") && !ctx->timing) {
+        long maxc = opts.max_chunks_per_launch;
+        if (maxc <= 0) { const char* e = getenv("FVAD_MAX_CHUNKS"); maxc = e ? atol(e) : 49152; }
+        const long total = (long)(n_lanes * n_chunks);
+        if ((rc = ensure_workspace(ctx, std::min(total, maxc), kRowsPerChunk))) return rc; // no allocation while capturing
+        Workspace::GraphCache& gc = ws.graph;
+        const bool hit = gc.valid && gc.pcm == d_pcm && gc.den == den && gc.band == d_band_sum && gc.rms == d_chunk_rms &&
+                         gc.n_lanes == n_lanes && gc.lane_stride == lane_stride && gc.n_samples == n_samples &&
+                         gc.min_bin == opts.min_bin && gc.max_bin == opts.max_bin && gc.max_chunks == maxc &&
+                         gc.generation == ws.generation;
+        if (!hit) {
+            hipStreamSynchronize(st);
+            if (gc.exec) hipGraphExecDestroy(gc.exec);
+            if (gc.graph) hipGraphDestroy(gc.graph);
+            gc.exec = nullptr; gc.graph = nullptr; gc.valid = false;
+            if (gc.h_descs_cap < (size_t)total) {
+                if (gc.h_descs) hipHostFree(gc.h_descs);
+                gc.h_descs = nullptr; gc.h_descs_cap = 0;
+                FVAD_HIP(ctx, hipHostMalloc((void**)&gc.h_descs, (size_t)total * sizeof(ChunkDesc), hipHostMallocDefault));
+                gc.h_descs_cap = (size_t)total;
+            }
+            if (gc.h_jobs_cap < n_lanes) {
+                if (gc.h_jobs) hipHostFree(gc.h_jobs);
+                gc.h_jobs = nullptr; gc.h_jobs_cap = 0;
+                FVAD_HIP(ctx, hipHostMalloc((void**)&gc.h_jobs, n_lanes * sizeof(VadFftJob), hipHostMallocDefault));
+                gc.h_jobs_cap = n_lanes;
+            }
+            FVAD_HIP(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            rc = enqueue(gc.h_descs, gc.h_jobs);
+            hipGraph_t g = nullptr;
+            const hipError_t ee = hipStreamEndCapture(st, &g);
+            if (rc || ee != hipSuccess || !g) {
+                if (g) hipGraphDestroy(g);
+                return rc ? rc : set_err(ctx, FVAD_ERR_HIP, "hipStreamEndCapture failed");
+            }
+            gc.graph = g;
+            FVAD_HIP(ctx, hipGraphInstantiate(&gc.exec, gc.graph, nullptr, nullptr, 0));
+            gc.pcm = d_pcm; gc.den = den; gc.band = d_band_sum; gc.rms = d_chunk_rms;
+            gc.n_lanes = n_lanes; gc.lane_stride = lane_stride; gc.n_samples = n_samples;
+            gc.min_bin = opts.min_bin; gc.max_bin = opts.max_bin; gc.max_chunks = maxc;
+            gc.generation = ws.generation;
+            gc.valid = true;
+        }
+        FVAD_HIP(ctx, hipGraphLaunch(gc.exec, st));
+        FVAD_HIP(ctx, hipStreamSynchronize(st));
+        FVAD_HIP(ctx, hipGetLastError());
+        return FVAD_OK;
     }
+
+    if ((rc = enqueue(nullptr, ws.h_fft_jobs))) return rc;
+    FVAD_HIP(ctx, hipStreamSynchronize(st)); // the pinned job table is reused by the next call
     FVAD_HIP(ctx, hipGetLastError());
     return FVAD_OK;
 }

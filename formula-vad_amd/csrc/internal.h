@@ -71,6 +71,23 @@ struct Workspace {
     // pinned staging ring for large host <-> device transfers (two halves of kPinSlots slots)
     struct PinRing { char* base = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
     PinRing ring_in, ring_out; // host->device staging / device->host draining (used by different threads)
+    unsigned generation = 0; // bumped whenever a device buffer of the workspace is reallocated
+    // one captured launch sequence of fvad_engine_enqueue_device (opt-in, FVAD_GRAPH=1): replayed while the
+    // call's arguments and the workspace are unchanged
+    struct GraphCache {
+        bool valid = false;
+        const void *pcm = nullptr, *den = nullptr, *band = nullptr, *rms = nullptr;
+        size_t n_lanes = 0, lane_stride = 0, n_samples = 0;
+        int min_bin = 0, max_bin = 0;
+        long max_chunks = 0;
+        unsigned generation = 0;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        ChunkDesc* h_descs = nullptr;  // pinned: the descriptor tables of every launch of the sequence
+        size_t h_descs_cap = 0;
+        VadFftJob* h_jobs = nullptr;   // pinned
+        size_t h_jobs_cap = 0;
+    } graph;
     // copy streams + per-group events of the pipelined host-buffer path (fvad_engine_run)
     hipStream_t copy_in = nullptr, copy_out = nullptr;
     hipEvent_t grp_in[8] = {}, grp_k[8] = {};
@@ -136,7 +153,7 @@ struct LaneJob {
     int cur;             // index of the carry holding the current state
     float* d_rms;        // device, n_chunks
 };
-int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks);
+int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, ChunkDesc* capture_descs = nullptr);
 void time_begin(fvad_ctx* ctx, const char* name);
 void time_end(fvad_ctx* ctx);
 } // namespace fvad

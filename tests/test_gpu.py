@@ -407,6 +407,67 @@ def test_two_contexts_on_two_threads(fv, weights7, pkg):
         assert np.array_equal(got[i]["band_sum"], solo[i]["band_sum"])
 
 
+_GRAPH_SCRIPT = r"""
+import os, sys
+import numpy as np
+import torch                                   # first: this process must use one HIP runtime (torch's)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_package
+pkg = load_package()
+fv = pkg.binding
+L = fv.lib()
+ctx = fv.Context(0)
+ctx.load_synth(7)
+dev = torch.device("cuda", 0)
+
+def run(d_pcm, n_samples, bufs=None):
+    n_l = d_pcm.shape[0]
+    n_ch = n_samples // 24000
+    if bufs is None:
+        bufs = (torch.zeros((n_l, n_ch * 24000 // 1024), dtype=torch.float32, device=dev),
+                torch.zeros((n_l, n_ch), dtype=torch.float32, device=dev),
+                torch.zeros((n_l, n_ch * 24000), dtype=torch.float32, device=dev))
+    band, rms, den = bufs
+    fv.check(L.fvad_engine_enqueue_device(ctx.h, d_pcm.data_ptr(), n_l, d_pcm.stride(0), n_samples,
+                                          den.data_ptr(), band.data_ptr(), rms.data_ptr(), None), "enqueue", ctx.h)
+    ctx.synchronize()
+    return band.cpu().numpy(), rms.cpu().numpy(), den.cpu().numpy()
+
+a, _ = pkg.synth.make_stream(8.0, seed=71)
+b, _ = pkg.synth.make_stream(8.0, seed=72)
+xa = torch.from_numpy(np.stack([np.roll(a[0], 997 * i) for i in range(6)])[:, : 16 * 24000].copy()).to(dev)
+xb = torch.from_numpy(np.stack([np.roll(b[0], 991 * i) for i in range(6)])[:, : 16 * 24000].copy()).to(dev)
+ref_a, ref_b, ref_short = run(xa, 16 * 24000), run(xb, 16 * 24000), run(xa, 4 * 24000)
+os.environ["FVAD_GRAPH"] = "1"
+bufs = (torch.zeros((6, 16 * 24000 // 1024), dtype=torch.float32, device=dev),
+        torch.zeros((6, 16), dtype=torch.float32, device=dev),
+        torch.zeros((6, 16 * 24000), dtype=torch.float32, device=dev))
+x = xa.clone()
+for want, src in ((ref_a, xa), (ref_a, xa), (ref_b, xb), (ref_a, xa)):   # capture, replay, new contents, back
+    x.copy_(src)
+    torch.cuda.synchronize()
+    got = run(x, 16 * 24000, bufs)
+    assert all(np.array_equal(u, v) for u, v in zip(got, want))
+got = run(xa, 4 * 24000)                                                  # another shape: re-capture
+assert all(np.array_equal(u, v) for u, v in zip(got, ref_short))
+assert np.abs(ref_a[2]).max() > 0
+ctx.close()
+print("GRAPH_OK")
+"""
+
+
+def test_graph_replay_equals_direct_launches():
+    # FVAD_GRAPH=1: the device-resident entry point captures its launch sequence into a hipGraph and replays
+    # it while arguments and workspace are unchanged.  Same results as launching directly, also after the
+    # input buffer's contents change and after a different shape invalidates the cache.  Device buffers come
+    # from torch, which has to initialise HIP before the library does: a process of its own.
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + _GRAPH_SCRIPT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "GRAPH_OK" in r.stdout, r.stderr[-3000:]
+
+
 # ------------------------------------------------------------------ B1: AudioPipeline end to end
 @pytest.mark.parametrize("n_channels,seconds,seed", [(1, 90.0, 40), (2, 60.0, 41)])
 def test_pipeline_segments_bit_identical(fv, gpu_ctx, weights7, pkg, n_channels, seconds, seed):
