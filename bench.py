@@ -112,6 +112,32 @@ def cpu_baseline(pkg, fv, weights, n_threads):
                       f"(oracle/, -O3 -march=native), one thread per stream; {dt:.1f} s wall"}
 
 
+def check_against_oracle(ctx, weights, host_pcm, lanes, d_den, n_samp, band, segments):
+    """The checker (oracle/, test infrastructure) on a few lanes of the batch the benchmark has just run.
+    Tolerances are the parity tests': denoised <= 1e-4 of peak, band sums <= 1e-4 relative, segments exact."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    out = {"lanes": list(lanes), "max_err": {"denoised_of_peak": 0.0, "band_sum_rel": 0.0}, "segments_identical": True,
+           "n_segments": 0, "checker": "oracle/ (CPU restatement), orc.Pipeline on the same samples"}
+    den = np.empty(n_samp // CHUNK * CHUNK, np.float32)
+    for lane in lanes:
+        p = orc.Pipeline(weights, n_channels=1, keep_denoised=True)
+        p.push(host_pcm[lane][None])
+        ref_den, ref_band = p.denoised()[0], p.band_volumes()[:, 0]
+        ctx.to_host(den, d_den + lane * den.nbytes)
+        e_den = float(np.abs(den.astype(np.float64) - ref_den).max() / np.abs(ref_den).max())
+        e_band = float((np.abs(band[lane].astype(np.float64) - ref_band) / np.abs(ref_band)).max())
+        out["max_err"]["denoised_of_peak"] = max(out["max_err"]["denoised_of_peak"], e_den)
+        out["max_err"]["band_sum_rel"] = max(out["max_err"]["band_sum_rel"], e_band)
+        ref_segs = [(s[0], s[1]) for s in p.segments()]
+        got_segs = [(s[0], s[1]) for s in segments[lane]]
+        out["segments_identical"] = out["segments_identical"] and got_segs == ref_segs
+        out["n_segments"] += len(ref_segs)
+    out["ok"] = bool(out["max_err"]["denoised_of_peak"] <= 1e-4 and out["max_err"]["band_sum_rel"] <= 1e-4
+                     and out["segments_identical"] and np.isfinite(out["max_err"]["denoised_of_peak"]))
+    return out
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -171,10 +197,14 @@ def main():
     n_frames_fft = (n_chunks * CHUNK) // 1024
     frames_per_step = lanes * n_chunks * FRAMES_PER_CHUNK
     host_pcm, labels = make_inputs(pkg, rank, lanes, seconds)
-    d_pcm = torch.from_numpy(host_pcm).to(dev)           # inputs resident in HBM before timing
-    d_den = torch.empty((lanes, n_chunks * CHUNK), dtype=torch.float32, device=dev)
-    d_band = [torch.empty((lanes, n_frames_fft), dtype=torch.float32, device=dev) for _ in range(2)]
-    d_rms = [torch.empty((lanes, n_chunks), dtype=torch.float32, device=dev) for _ in range(2)]
+    # device buffers come from the library's own allocator (fvad_device_alloc): no torch on the data path
+    n_samp = seconds * 48000
+    d_pcm = ctx.device_alloc(lanes * n_samp * 4)
+    for lane in range(lanes):                            # inputs resident in HBM before timing
+        ctx.to_device(d_pcm + lane * n_samp * 4, host_pcm[lane])
+    d_den = ctx.device_alloc(lanes * n_chunks * CHUNK * 4)
+    d_band = [ctx.device_alloc(lanes * n_frames_fft * 4) for _ in range(2)]
+    d_rms = [ctx.device_alloc(lanes * n_chunks * 4) for _ in range(2)]
     h_band = [np.empty((lanes, n_frames_fft), np.float32) for _ in range(2)]
     h_rms = [np.empty((lanes, n_chunks), np.float32) for _ in range(2)]
     # a 1-GPU box gives this process a 16-CPU share whatever os.cpu_count() says
@@ -211,12 +241,11 @@ def main():
         host_ms.append(((t_h1 - t_h0) * 1e3, (t_h2 - t_h1) * 1e3, (time.perf_counter() - t_h2) * 1e3))
 
     def gpu_stage(slot):
-        rc = L.fvad_engine_enqueue_device(ctx.h, d_pcm.data_ptr(), lanes, d_pcm.stride(0), seconds * 48000,
-                                          d_den.data_ptr(), d_band[slot].data_ptr(), d_rms[slot].data_ptr(), None)
+        rc = L.fvad_engine_enqueue_device(ctx.h, d_pcm, lanes, n_samp, n_samp, d_den, d_band[slot], d_rms[slot], None)
         fv.check(rc, "fvad_engine_enqueue_device", ctx.h)
-        fv.check(L.fvad_ctx_copy_to_host(ctx.h, h_band[slot].ctypes.data, d_band[slot].data_ptr(), h_band[slot].nbytes),
+        fv.check(L.fvad_ctx_copy_to_host(ctx.h, h_band[slot].ctypes.data, d_band[slot], h_band[slot].nbytes),
                  "copy band sums", ctx.h)
-        fv.check(L.fvad_ctx_copy_to_host(ctx.h, h_rms[slot].ctypes.data, d_rms[slot].data_ptr(), h_rms[slot].nbytes),
+        fv.check(L.fvad_ctx_copy_to_host(ctx.h, h_rms[slot].ctypes.data, d_rms[slot], h_rms[slot].nbytes),
                  "copy rms", ctx.h)
 
     gpu_wall_ms = []
@@ -255,6 +284,13 @@ def main():
     elapsed = time.perf_counter() - t0
     ktimes = ctx.kernel_times()                  # sums over the K timed steps, HIP events on ctx's stream
     ctx.enable_timing(False)
+
+    # self-check of the configuration that was just timed: two lanes of the LAST timed step (the first and
+    # the last of the batch) against the CPU oracle -- denoised audio, band sums, segment boundaries
+    self_check = None
+    if rank == 0:
+        self_check = check_against_oracle(ctx, weights, host_pcm, [0, lanes - 1], d_den, n_samp,
+                                          h_band[(args.steps - 1) & 1], results[("timed", args.steps - 1)])
 
     # device-only rate of the same work (no host stage), for the record
     barrier()
@@ -330,6 +366,7 @@ def main():
             "kernel_ms_per_step": {k: v / args.steps for k, v in ktimes.items()},
             "aggregate": {"ms": agg_ms, "n_streams": lanes * world, "tpr": agg.true_positive_rate.overall,
                           "ppv": agg.precision.overall, "collective": f"all_gather({args.dist_backend})" if world > 1 else "none"},
+            "self_check": self_check,
             "host_vad_threads": vad_threads,
             "gpu_stage_wall_ms": float(np.mean(gpu_wall_ms[args.warmup:])),
             "kernel_ms_sum": float(sum(ktimes.values()) / args.steps),
@@ -344,6 +381,9 @@ def main():
         if not args.no_extra and world == 1:
             out["extra"] = side_measurements(pkg, fv, ctx, torch, dev)
         print(json.dumps(out))
+        if not self_check or not self_check["ok"]:
+            print("bench.py: SELF-CHECK FAILED: the timed configuration does not match the oracle", file=sys.stderr)
+            sys.exit(1)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -198,6 +198,9 @@ SIGNATURES = {
     "fvad_vad_segments": (C.c_int, [vp, C.POINTER(SpeechSegment), sz, C.POINTER(sz)]),
     "fvad_host_alloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
     "fvad_host_free": (None, [vp, vp]),
+    "fvad_device_alloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
+    "fvad_device_free": (None, [vp, vp]),
+    "fvad_ctx_copy_to_device": (C.c_int, [vp, vp, vp, sz]),
     "fvad_vad_audit_get": (C.c_int, [vp, C.POINTER(VadAudit)]),
     "fvad_vad_lazy_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "fvad_vad_run_many": (C.c_int, [C.POINTER(vp), sz, C.POINTER(c_float_p),
@@ -419,6 +422,36 @@ class Context:
     def host_free(self, arr):
         p = self._pinned.pop(arr.ctypes.data)
         lib().fvad_host_free(self.h, p)
+
+    def device_alloc(self, n_bytes):
+        """HBM on the context's device (fvad_device_alloc); returns the device address as an int"""
+        p = vp()
+        self._ck(lib().fvad_device_alloc(self.h, int(n_bytes), C.byref(p)), "fvad_device_alloc")
+        return p.value
+
+    def device_free(self, addr):
+        lib().fvad_device_free(self.h, vp(addr))
+
+    def to_device(self, addr, arr):
+        """copy a C-contiguous numpy array to device address `addr` (returns after the copy completed)"""
+        assert arr.flags["C_CONTIGUOUS"]
+        self._ck(lib().fvad_ctx_copy_to_device(self.h, vp(addr), arr.ctypes.data, arr.nbytes), "fvad_ctx_copy_to_device")
+        self.synchronize()
+
+    def to_host(self, arr, addr):
+        """fill a C-contiguous numpy array from device address `addr`"""
+        assert arr.flags["C_CONTIGUOUS"]
+        self._ck(lib().fvad_ctx_copy_to_host(self.h, arr.ctypes.data, vp(addr), arr.nbytes), "fvad_ctx_copy_to_host")
+        self.synchronize()
+        return arr
+
+    def enqueue_device(self, d_pcm, n_lanes, lane_stride, n_samples, d_den, d_band, d_rms, max_chunks_per_launch=0):
+        opts = EngineOpts()
+        lib().fvad_engine_opts_default(C.byref(opts))
+        opts.max_chunks_per_launch = max_chunks_per_launch
+        self._ck(lib().fvad_engine_enqueue_device(self.h, vp(d_pcm), n_lanes, lane_stride, n_samples,
+                                                  vp(d_den) if d_den else None, vp(d_band), vp(d_rms) if d_rms else None,
+                                                  C.byref(opts)), "fvad_engine_enqueue_device")
 
     def lane_state(self):
         s = vp()

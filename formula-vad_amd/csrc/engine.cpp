@@ -37,7 +37,9 @@ static int dev_alloc(fvad_ctx* ctx, float** p, size_t n_floats, bool zero)
 
 static int upload(fvad_ctx* ctx, DevBuf& b, const std::vector<float>& v)
 {
-    if (b.p) { hipFree(b.p); b.p = nullptr; }
+    // a captured launch sequence (Workspace::GraphCache) holds this buffer's address in its kernel nodes
+    ctx->ws.generation++;
+    if (b.p) { hipStreamSynchronize(ctx->stream); hipFree(b.p); b.p = nullptr; }
     b.n = v.size();
     FVAD_HIP(ctx, hipMalloc((void**)&b.p, v.size() * sizeof(float)));
     FVAD_HIP(ctx, hipMemcpy(b.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -348,10 +350,12 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
 }
 
 // K1 -> NSNet2 -> K3 over every chunk of every job, in launches of <= max_chunks chunks.
-int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, ChunkDesc* capture_descs)
+int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, ChunkDesc* capture_descs, ChunkDesc* capture_dev)
 {
     // capture_descs != nullptr: the call is being captured into a hipGraph.  Every launch gets its own
-    // region of that pinned table (a replay re-reads it), and no event is waited for or recorded.
+    // region of the graph's private descriptor table (host copy capture_descs, device copy capture_dev,
+    // uploaded once by the caller after the capture): the graph holds no copy node and does not depend on
+    // the workspace's shared table, which direct calls overwrite.  No event is waited for or recorded.
     size_t capture_off = 0;
     if (max_chunks <= 0) {
         const char* e = getenv("FVAD_MAX_CHUNKS"); // tuning aid
@@ -400,18 +404,21 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
             c += take;
             if (c == lj.n_chunks) { ++j; c = 0; }
         }
-        // the stream orders this copy after the previous launch's kernels
-        FVAD_HIP(ctx, hipMemcpyAsync(ws.descs, hd, (size_t)n * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
-        if (capture_descs) capture_off += (size_t)n;
-        else FVAD_HIP(ctx, hipEventRecord(ws.desc_ev[slot], ctx->stream));
+        const ChunkDesc* dd = ws.descs;
+        if (capture_descs) { dd = capture_dev + capture_off; capture_off += (size_t)n; }
+        else {
+            // the stream orders this copy after the previous launch's kernels
+            FVAD_HIP(ctx, hipMemcpyAsync(ws.descs, hd, (size_t)n * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
+            FVAD_HIP(ctx, hipEventRecord(ws.desc_ev[slot], ctx->stream));
+        }
         time_begin(ctx, "stft320_logpow");
-        fvad_launch_stft(ws.descs, (int)n, ctx->tb, ws.feat, ws.spec, ctx->stream);
+        fvad_launch_stft(dd, (int)n, ctx->tb, ws.feat, ws.spec, ctx->stream);
         time_end(ctx);
         const long n_pad = padded_batch(ctx, n);
         rc = run_nn(ctx, n_pad, kRowsPerChunk, kWarmupRows);
         if (rc) return rc;
         time_begin(ctx, "istft320_ola_up3");
-        fvad_launch_istft(ws.descs, (int)n, ctx->tb, ws.spec, ws.gains, kFramesPerChunk, 0, ctx->stream);
+        fvad_launch_istft(dd, (int)n, ctx->tb, ws.spec, ws.gains, kFramesPerChunk, 0, ctx->stream);
         time_end(ctx);
         for (size_t t : touched) jobs[t].cur ^= 1;
         job = j;
@@ -526,6 +533,8 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     if (ws.graph.graph) hipGraphDestroy(ws.graph.graph);
     if (ws.graph.h_descs) hipHostFree(ws.graph.h_descs);
     if (ws.graph.h_jobs) hipHostFree(ws.graph.h_jobs);
+    if (ws.graph.d_descs) hipFree(ws.graph.d_descs);
+    if (ws.graph.d_jobs) hipFree(ws.graph.d_jobs);
     for (hipEvent_t& e : ws.grp_in) if (e) hipEventDestroy(e);
     for (hipEvent_t& e : ws.grp_k) if (e) hipEventDestroy(e);
     if (ws.copy_in) hipStreamDestroy(ws.copy_in);
@@ -567,6 +576,30 @@ void fvad_host_free(fvad_ctx* ctx, void* p)
     if (!ctx || !p) return;
     hipSetDevice(ctx->device);
     hipHostFree(p);
+}
+
+int fvad_device_alloc(fvad_ctx* ctx, size_t bytes, void** out)
+{
+    if (!ctx || !out || bytes == 0) return FVAD_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    hipSetDevice(ctx->device);
+    if (hipMalloc(out, bytes) != hipSuccess) { *out = nullptr; (void)hipGetLastError(); return set_err(ctx, FVAD_ERR_ALLOC_FAILED, "hipMalloc failed"); }
+    return FVAD_OK;
+}
+
+void fvad_device_free(fvad_ctx* ctx, void* p)
+{
+    if (!ctx || !p) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(p);
+}
+
+int fvad_ctx_copy_to_device(fvad_ctx* ctx, void* dst_device, const void* src_host, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst_device || !src_host))) return FVAD_ERR_INVALID_ARGUMENT;
+    if (bytes) FVAD_HIP(ctx, hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return FVAD_OK;
 }
 
 int fvad_ctx_copy_to_host(fvad_ctx* ctx, void* dst_host, const void* src_device, size_t bytes)
@@ -879,6 +912,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
         ws.carries = nullptr; ws.carries_cap = 0;
         FVAD_HIP(ctx, hipMalloc((void**)&ws.carries, n_scratch * sizeof(LaneCarry)));
         ws.carries_cap = n_scratch * sizeof(LaneCarry);
+        ws.generation++;
     }
     if (n_scratch) FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
 
@@ -948,6 +982,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
             FVAD_HIP(ctx, hipMalloc((void**)&ws.fft_jobs, n_lanes * sizeof(VadFftJob)));
             FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_fft_jobs, n_lanes * sizeof(VadFftJob), hipHostMallocDefault));
             ws.fft_jobs_cap = n_lanes;
+            ws.generation++;
         }
         for (size_t l = 0; l < n_lanes; ++l) {
             const fvad_lane& L = lanes[l];
@@ -1092,8 +1127,11 @@ int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes
     }
 
     // the launch sequence of one call: carries reset, (descriptor upload, K1, NSNet2, K3) per launch, K4
-    auto enqueue = [&](ChunkDesc* capture_descs, VadFftJob* h_jobs) -> int {
-        FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
+    auto enqueue = [&](ChunkDesc* capture_descs, ChunkDesc* capture_dev, VadFftJob* h_jobs, VadFftJob* d_jobs) -> int {
+        // A captured sequence holds kernel nodes only: memset / memcpy nodes replayed after direct launches on
+        // the same stream were observed to run with stale parameters (ROCm 7.2), so the carries are zeroed
+        // on the stream in front of every hipGraphLaunch and the tables are graph-private device copies.
+        if (!capture_descs) FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
         std::vector<LaneJob> jobs(n_lanes);
         for (size_t l = 0; l < n_lanes; ++l) {
             jobs[l].d_in = d_pcm + l * lane_stride;
@@ -1104,13 +1142,13 @@ int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes
             jobs[l].cur = 0;
             jobs[l].d_rms = d_chunk_rms ? d_chunk_rms + l * n_chunks : nullptr;
         }
-        int r = run_chunks(ctx, jobs, opts.max_chunks_per_launch, capture_descs);
+        int r = run_chunks(ctx, jobs, opts.max_chunks_per_launch, capture_descs, capture_dev);
         if (r) return r;
         // one K4 launch for every lane's frames
         for (size_t l = 0; l < n_lanes; ++l) h_jobs[l] = {den + l * n_den, d_band_sum + l * n_frames, nullptr, (long)n_frames};
-        FVAD_HIP(ctx, hipMemcpyAsync(ws.fft_jobs, h_jobs, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice, st));
+        if (!capture_descs) FVAD_HIP(ctx, hipMemcpyAsync(d_jobs, h_jobs, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice, st));
         time_begin(ctx, "fft1024_bandsum");
-        fvad_launch_vadfft_jobs(ws.fft_jobs, (int)n_lanes, (long)n_frames, ctx->tb, opts.min_bin, opts.max_bin, st);
+        fvad_launch_vadfft_jobs(d_jobs, (int)n_lanes, (long)n_frames, ctx->tb, opts.min_bin, opts.max_bin, st);
         time_end(ctx);
         return FVAD_OK;
     };
@@ -1135,18 +1173,22 @@ int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes
             gc.exec = nullptr; gc.graph = nullptr; gc.valid = false;
             if (gc.h_descs_cap < (size_t)total) {
                 if (gc.h_descs) hipHostFree(gc.h_descs);
-                gc.h_descs = nullptr; gc.h_descs_cap = 0;
+                if (gc.d_descs) hipFree(gc.d_descs);
+                gc.h_descs = nullptr; gc.d_descs = nullptr; gc.h_descs_cap = 0;
                 FVAD_HIP(ctx, hipHostMalloc((void**)&gc.h_descs, (size_t)total * sizeof(ChunkDesc), hipHostMallocDefault));
+                FVAD_HIP(ctx, hipMalloc((void**)&gc.d_descs, (size_t)total * sizeof(ChunkDesc)));
                 gc.h_descs_cap = (size_t)total;
             }
             if (gc.h_jobs_cap < n_lanes) {
                 if (gc.h_jobs) hipHostFree(gc.h_jobs);
-                gc.h_jobs = nullptr; gc.h_jobs_cap = 0;
+                if (gc.d_jobs) hipFree(gc.d_jobs);
+                gc.h_jobs = nullptr; gc.d_jobs = nullptr; gc.h_jobs_cap = 0;
                 FVAD_HIP(ctx, hipHostMalloc((void**)&gc.h_jobs, n_lanes * sizeof(VadFftJob), hipHostMallocDefault));
+                FVAD_HIP(ctx, hipMalloc((void**)&gc.d_jobs, n_lanes * sizeof(VadFftJob)));
                 gc.h_jobs_cap = n_lanes;
             }
             FVAD_HIP(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            rc = enqueue(gc.h_descs, gc.h_jobs);
+            rc = enqueue(gc.h_descs, gc.d_descs, gc.h_jobs, gc.d_jobs);
             hipGraph_t g = nullptr;
             const hipError_t ee = hipStreamEndCapture(st, &g);
             if (rc || ee != hipSuccess || !g) {
@@ -1154,6 +1196,9 @@ int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes
                 return rc ? rc : set_err(ctx, FVAD_ERR_HIP, "hipStreamEndCapture failed");
             }
             gc.graph = g;
+            // the graph's private tables: written once, read by every replay
+            FVAD_HIP(ctx, hipMemcpy(gc.d_descs, gc.h_descs, (size_t)total * sizeof(ChunkDesc), hipMemcpyHostToDevice));
+            FVAD_HIP(ctx, hipMemcpy(gc.d_jobs, gc.h_jobs, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice));
             FVAD_HIP(ctx, hipGraphInstantiate(&gc.exec, gc.graph, nullptr, nullptr, 0));
             gc.pcm = d_pcm; gc.den = den; gc.band = d_band_sum; gc.rms = d_chunk_rms;
             gc.n_lanes = n_lanes; gc.lane_stride = lane_stride; gc.n_samples = n_samples;
@@ -1161,13 +1206,14 @@ int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes
             gc.generation = ws.generation;
             gc.valid = true;
         }
+        FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
         FVAD_HIP(ctx, hipGraphLaunch(gc.exec, st));
         FVAD_HIP(ctx, hipStreamSynchronize(st));
         FVAD_HIP(ctx, hipGetLastError());
         return FVAD_OK;
     }
 
-    if ((rc = enqueue(nullptr, ws.h_fft_jobs))) return rc;
+    if ((rc = enqueue(nullptr, nullptr, ws.h_fft_jobs, ws.fft_jobs))) return rc;
     FVAD_HIP(ctx, hipStreamSynchronize(st)); // the pinned job table is reused by the next call
     FVAD_HIP(ctx, hipGetLastError());
     return FVAD_OK;

@@ -83,9 +83,11 @@ struct Workspace {
         unsigned generation = 0;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
-        ChunkDesc* h_descs = nullptr;  // pinned: the descriptor tables of every launch of the sequence
+        // the graph's private descriptor / job tables (host image + device copy): every launch of the
+        // sequence has its own region, uploaded once after the capture
+        ChunkDesc* h_descs = nullptr; ChunkDesc* d_descs = nullptr;
         size_t h_descs_cap = 0;
-        VadFftJob* h_jobs = nullptr;   // pinned
+        VadFftJob* h_jobs = nullptr; VadFftJob* d_jobs = nullptr;
         size_t h_jobs_cap = 0;
     } graph;
     // copy streams + per-group events of the pipelined host-buffer path (fvad_engine_run)
@@ -153,7 +155,8 @@ struct LaneJob {
     int cur;             // index of the carry holding the current state
     float* d_rms;        // device, n_chunks
 };
-int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, ChunkDesc* capture_descs = nullptr);
+int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, ChunkDesc* capture_descs = nullptr,
+               ChunkDesc* capture_dev = nullptr);
 void time_begin(fvad_ctx* ctx, const char* name);
 void time_end(fvad_ctx* ctx);
 } // namespace fvad

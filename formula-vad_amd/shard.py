@@ -2,7 +2,7 @@
 
 Streams never interact (one pipeline per file in the reference, src/simulator.zig:225-231), so
 whole streams are dealt round-robin to ranks and no audio crosses GPUs.  The only exchange is the
-final gather of the per-stream Evaluator statistics (13 f32 each, statistics.zig:8-37) to rank 0,
+final gather of the per-stream Evaluator statistics (11 f32 each, statistics.zig:8-37) to rank 0,
 where statistics.aggregate runs in PLAN order to keep the reference's f32 summation order
 (statistics.zig:124-129).  On GPUs the gather is one torch.distributed all_gather over RCCL
 (backend "nccl"); on CPU (tests) the same code runs over gloo."""

@@ -88,6 +88,13 @@ int fvad_ctx_copy_to_host(fvad_ctx *ctx, void *dst_host, const void *src_device,
  * injects for its sample buffers (AudioPipeline.zig:40-44).  Free with fvad_host_free. */
 int fvad_host_alloc(fvad_ctx *ctx, size_t bytes, void **out);
 void fvad_host_free(fvad_ctx *ctx, void *p);
+/* Device (HBM) memory on the context's device, for callers that keep audio resident on the GPU
+ * (fvad_engine_enqueue_device, `on_device` lanes) without linking a HIP runtime themselves: a Zig or C
+ * host needs nothing but this library.  fvad_ctx_copy_to_device is a hipMemcpyAsync(host -> device)
+ * on the context's stream: `src_host` must stay valid until fvad_ctx_synchronize. */
+int fvad_device_alloc(fvad_ctx *ctx, size_t bytes, void **out);
+void fvad_device_free(fvad_ctx *ctx, void *p);
+int fvad_ctx_copy_to_device(fvad_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
 
 /* ------------------------------------------------------------------ NSNet2 model
  * Replaces onnx.OnnxInstance.init(allocator, .{ .model_path = ... }) (NSNet2.zig:53-61): the
@@ -212,8 +219,12 @@ void fvad_engine_opts_default(fvad_engine_opts *o);
 
 int fvad_engine_run(fvad_ctx *ctx, fvad_lane *lanes, size_t n_lanes, const fvad_engine_opts *opts);
 
-/* Benchmark form: everything device-resident, nothing copied back; outputs stay in the
- * context's workspace.  Returns after enqueueing.  `d_pcm` holds n_lanes lanes of n_samples. */
+/* Device-resident form: `d_pcm` holds n_lanes lanes of n_samples (lane l at d_pcm + l * lane_stride);
+ * d_denoised [n_lanes][n_chunks*24000] (NULL: kept in the context's workspace), d_band_sum
+ * [n_lanes][n_chunks*24000/1024] and d_chunk_rms [n_lanes][n_chunks] (may be NULL) are device buffers
+ * too; nothing is copied to the host.  Every lane starts from zero history.  The call returns once
+ * the work has COMPLETED on the context's stream (its pinned descriptor tables are reused by the next
+ * call). */
 int fvad_engine_enqueue_device(fvad_ctx *ctx, const float *d_pcm, size_t n_lanes,
                                size_t lane_stride, size_t n_samples, float *d_denoised,
                                float *d_band_sum, float *d_chunk_rms,
@@ -275,10 +286,11 @@ int fvad_vad_audit_get(const fvad_vad *v, fvad_vad_audit *out);
  * evaluates it lazily, only when a bound on the incrementally carried value cannot settle the threshold
  * comparison (results are identical either way; see host_vad.cpp). */
 int fvad_vad_lazy_stats(const fvad_vad *v, uint64_t *exact_evaluations, uint64_t *lazy_pushes);
-/* Many independent streams at once, bit-identical to fvad_vad_run per stream: streams are
- * advanced in lock-step with the f64 re-summation vectorised ACROSS streams (same index order
- * within each).  band[s] points at [n_frames[s]][n_channels] f32, ratio[s] at [n_frames[s]].
- * first_index[s] + 1024*k is frame k's index. */
+/* Many independent streams at once, bit-identical to fvad_vad_run per stream: the streams are dealt to
+ * n_threads host threads (stream s -> thread s % n_threads; one thread per file is the reference's own
+ * parallelism, simulator.zig:221-232) and each thread runs its streams one after the other.
+ * band[s] points at [n_frames[s]][n_channels] f32, ratio[s] at [n_frames[s]].
+ * first_index[s] + fft_size*k is frame k's index. */
 int fvad_vad_run_many(fvad_vad *const *vads, size_t n_streams, const float *const *band,
                       const float *const *ratio, const size_t *n_frames, size_t n_channels,
                       const uint64_t *first_index, size_t fft_size, int n_threads);

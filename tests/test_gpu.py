@@ -451,6 +451,20 @@ for want, src in ((ref_a, xa), (ref_a, xa), (ref_b, xb), (ref_a, xa)):   # captu
 got = run(xa, 4 * 24000)                                                  # another shape: re-capture
 assert all(np.array_equal(u, v) for u, v in zip(got, ref_short))
 assert np.abs(ref_a[2]).max() > 0
+# a model reload frees and re-allocates every weight buffer, and a host-buffer call with more lanes
+# re-allocates the scratch carries and the K4 job table: a cached graph must not be replayed over either
+x.copy_(xa); torch.cuda.synchronize()
+assert all(np.array_equal(u, v) for u, v in zip(run(x, 16 * 24000, bufs), ref_a))      # cached again
+ctx.load_synth(8)
+got8 = run(x, 16 * 24000, bufs)
+del os.environ["FVAD_GRAPH"]
+ref8 = run(xa, 16 * 24000)
+assert all(np.array_equal(u, v) for u, v in zip(got8, ref8)) and not np.array_equal(ref8[2], ref_a[2])
+os.environ["FVAD_GRAPH"] = "1"
+assert all(np.array_equal(u, v) for u, v in zip(run(x, 16 * 24000, bufs), ref8))       # capture with seed 8
+many = [a[0][: 2 * 24000].copy() for _ in range(40)]                                     # 80 scratch carries, 40 jobs
+ctx.engine_run(many)
+assert all(np.array_equal(u, v) for u, v in zip(run(x, 16 * 24000, bufs), ref8))
 ctx.close()
 print("GRAPH_OK")
 """
@@ -466,6 +480,80 @@ def test_graph_replay_equals_direct_launches():
     from conftest import ROOT
     r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + _GRAPH_SCRIPT], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "GRAPH_OK" in r.stdout, r.stderr[-3000:]
+
+
+# ------------------------------------------------------------------ the configuration bench.py times
+def bench_shape_inputs(pkg, lanes, seconds, n_base=8, unique=()):
+    """lane i carries base stream i % n_base, except the lanes in `unique`, which get streams of their own"""
+    bases = [pkg.synth.make_stream(float(seconds), seed=2000 + k)[0][0][: seconds * 48000].copy() for k in range(n_base)]
+    uniq = {l: pkg.synth.make_stream(float(seconds), seed=3000 + l)[0][0][: seconds * 48000].copy() for l in unique}
+    return bases, uniq
+
+
+def test_bench_shape_49152_chunks_matches_oracle(fv, gpu_ctx, weights7, pkg):
+    # bench.py's default launch: 384 lanes x 64 s = 49152 chunks in ONE launch (256 x 12-wave gru_rec3
+    # workgroups, persistent panel_gemm3, 32-bit index arithmetic, 49 GB workspace), default kernel
+    # selection.  Every lane is compared with the oracle: lanes share 8 base streams (a lane must give the
+    # base's result bit for bit wherever it sits in the batch), and the lanes at the batch edges, on both
+    # sides of the 192-sequence workgroup boundaries in the middle of the batch and at the last workgroup
+    # carry streams of their own.
+    lanes, seconds = 384, 64
+    n = seconds * 48000
+    n_chunks, n_frames = n // 24000, n // 1024
+    unique = (0, 1, 190, 191, 192, 193, 382, 383)
+    bases, uniq = bench_shape_inputs(pkg, lanes, seconds, unique=unique)
+    src = lambda l: uniq[l] if l in uniq else bases[l % 8]
+    d_pcm = gpu_ctx.device_alloc(lanes * n * 4)
+    d_den = gpu_ctx.device_alloc(lanes * n * 4)
+    d_band = gpu_ctx.device_alloc(lanes * n_frames * 4)
+    d_rms = gpu_ctx.device_alloc(lanes * n_chunks * 4)
+    try:
+        for l in range(lanes):
+            gpu_ctx.to_device(d_pcm + l * n * 4, src(l))
+        gpu_ctx.enqueue_device(d_pcm, lanes, n, n, d_den, d_band, d_rms)
+        band = gpu_ctx.to_host(np.empty((lanes, n_frames), np.float32), d_band)
+        rms = gpu_ctx.to_host(np.empty((lanes, n_chunks), np.float32), d_rms)
+        refs = {}
+        for key, x in [(("b", k), bases[k]) for k in range(8)] + [(("u", l), uniq[l]) for l in unique]:
+            p = orc.Pipeline(weights7, n_channels=1, keep_denoised=True)
+            p.push(x[None])
+            refs[key] = {"den": p.denoised()[0].copy(), "band": p.band_volumes()[:, 0].copy(), "rms": p.chunk_rms()[:, 0].copy(),
+                         "segs": [(s[0], s[1]) for s in p.segments()]}
+        first_of = {}
+        den = np.empty(n, np.float32)
+        for l in range(lanes):
+            key = ("u", l) if l in uniq else ("b", l % 8)
+            gpu_ctx.to_host(den, d_den + l * n * 4)
+            if key not in first_of:
+                r = refs[key]
+                assert_audio(den, r["den"], what=f"denoised lane {l}")
+                assert_rel(band[l], r["band"], 1e-4, what=f"band lane {l}")
+                assert_rel(rms[l], r["rms"], 1e-4, what=f"rms lane {l}")
+                first_of[key] = (l, den.copy())
+            else:
+                l0, d0 = first_of[key]
+                assert np.array_equal(den, d0), f"lane {l} differs from lane {l0} (same stream)"
+                assert np.array_equal(band[l], band[l0]) and np.array_equal(rms[l], rms[l0]), (l, l0)
+        # host stage on the GPU's band sums: segment lists bit-identical to the oracle pipeline's
+        ratio = np.where(rms > 0, np.where(rms < 1, 1.0, 1.0 / np.maximum(rms, 1e-30)), 0.0).astype(np.float32)
+        fs = np.arange(n_frames) * 1024
+        c0, c1 = fs // 24000, (fs + 1023) // 24000
+        w0 = (np.minimum((c0 + 1) * 24000, fs + 1024) - fs).astype(np.float32)
+        w1 = np.float32(1024) - w0
+        rat = ((ratio[:, c0] * w0 + np.where(w1 > 0, ratio[:, c1] * w1, np.float32(0))) / (w0 + w1)).astype(np.float32)
+        check = sorted({l for l, _ in first_of.values()})
+        ms = [fv.VadMachine() for _ in check]
+        fv.vad_run_many(ms, [band[l][:, None] for l in check], [rat[l] for l in check], n_threads=8)
+        n_seg = 0
+        for m, l in zip(ms, check):
+            key = ("u", l) if l in uniq else ("b", l % 8)
+            assert [(s[0], s[1]) for s in m.segments()] == refs[key]["segs"], f"segments of lane {l}"
+            n_seg += len(refs[key]["segs"])
+            m.close()
+        assert n_seg >= 16
+    finally:
+        for d in (d_pcm, d_den, d_band, d_rms):
+            gpu_ctx.device_free(d)
 
 
 # ------------------------------------------------------------------ B1: AudioPipeline end to end
