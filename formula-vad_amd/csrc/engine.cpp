@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <mutex>
 #include <thread>
 
 #include "internal.h"
@@ -198,14 +199,33 @@ void time_end(fvad_ctx* ctx)
 // one wavefront (16 sequences) per workgroup so that more CUs take part.
 struct GruChoice {
     int version; // 2: gru_rec2, 3: gru_rec3 (expects the z/r recurrent biases folded into gi),
-                 // 4: gru_lat (16 sequences per workgroup, tiles split over 8 waves)
+                 // 4: gru_lat (16 sequences per workgroup, tiles split over 8 waves),
+                 // 5: gru_ws (weights stationary in registers across 25 x G workgroups, kernels_ws.hip)
     int waves;
 };
+
+constexpr size_t kWsSyncWords = 520; // 2 x 256 flags + error word, padded to a multiple of 16 bytes
+
+// gru_ws launches spin on each other's flags, so two of them must not share the chip half-resident.
+// Within a process every such launch waits (on the GPU) for the previous one on the same device; across
+// processes the kernel's bounded spins and its gru_lat fallback take over.
+static std::mutex g_ws_mu;
+static hipEvent_t g_ws_ev[64] = {};
 
 // Measured cycles per time step of one workgroup on MI355X; a launch costs
 // ceil(workgroups / CUs) rounds of that.  The workgroup shapes trade sequences per CU against
 // wavefronts per SIMD: 192 sequences (12 waves), 128 (8), 64 (4), or the low-latency shape (waves = 0
 // here): 16 sequences with the unit tiles of a step split over 8 waves.
+// weight-stationary kernel, measured (tools/gru_crossover.py): a step costs 2.6 us of exchange (publish, flag,
+// barriers) plus 3.9 us per row tile (25 KB of h from the memory side + 100 MFMAs per gate wavefront), against
+// ~40 us for a step of the low-latency kernel: it wins up to ~1900 sequences
+static double gru_ws_cost(long n_pad, int n_cu)
+{
+    int RT = 0, G = 0;
+    if (!fvad_gru_ws_shape(n_pad, n_cu, &RT, &G)) return 1e30;
+    return 6.2e3 + 9.4e3 * RT;
+}
+
 static double gru_cost(long n_pad, int waves, int n_cu)
 {
     const double per_step = waves == 12 ? 25 * 32.3e3 : waves == 8 ? 25 * 23.4e3 : waves == 4 ? 25 * 13.0e3 : 120e3;
@@ -219,8 +239,15 @@ static double gru_cost(long n_pad, int waves, int n_cu)
 static long padded_batch(const fvad_ctx* ctx, long n)
 {
     const long a = (n + 383) / 384 * 384, b = (n + 127) / 128 * 128;
-    if (getenv("FVAD_GRU_KERNEL") || a == b) return a;
+    const char* force = getenv("FVAD_GRU_KERNEL");
     const int cu = ctx->n_cu;
+    // the weight-stationary recurrence and the small-batch GEMMs (64-row workgroups over 54 n and 50 n rows)
+    // only need a multiple of 32 sequences
+    const long c = (n + 31) / 32 * 32;
+    if ((!force || force[1] == '5') && !getenv("FVAD_GEMM_KERNEL") && c < 2048 &&
+        gru_ws_cost(c, cu) < std::min(gru_cost(b, 0, cu), gru_cost(b, 4, cu)))
+        return c;
+    if (force || a == b) return a;
     const double cost_a = std::min(std::min(gru_cost(a, 12, cu), gru_cost(a, 8, cu)), std::min(gru_cost(a, 4, cu), gru_cost(a, 0, cu)));
     const double cost_b = std::min(gru_cost(b, 8, cu), std::min(gru_cost(b, 4, cu), gru_cost(b, 0, cu)));
     return cost_b <= cost_a ? b : a;
@@ -239,14 +266,58 @@ static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, bool allow_v3)
     if (n_pad % 64 == 0 && gru_cost(n_pad, 4, cu) < gru_cost(n_pad, best, cu)) best = 4;
     if (n_pad % 128 == 0 && gru_cost(n_pad, 8, cu) < gru_cost(n_pad, best, cu)) best = 8;
     if (n_pad % 192 == 0 && gru_cost(n_pad, 12, cu) < gru_cost(n_pad, best, cu)) best = 12;
+    if (!allow_v3 && gru_ws_cost(n_pad, cu) < gru_cost(n_pad, best, cu)) return {5, 0}; // small-batch GEMM path only
     if (best == 0) return {4, 8};
     return {allow_v3 ? 3 : 2, best};
 }
 
-static int launch_gru(fvad_ctx* ctx, GruChoice c, const float* gi, const DevBuf& r_v2, const float* bR,
-                      float* hout, long n_pad, int T)
+// buffers of the weight-stationary recurrence; the polled words are zeroed once per network pass
+static int prepare_gru_ws(fvad_ctx* ctx, long n_pad)
 {
-    if (c.version == 4) return fvad_launch_gru_lat(gi, r_v2.p, bR, hout, n_pad, T, ctx->stream);
+    Workspace& ws = ctx->ws;
+    const size_t need = fvad_gru_ws_exchange_floats(n_pad);
+    if (need > ws.hx_cap) {
+        hipStreamSynchronize(ctx->stream);
+        if (ws.hx) hipFree(ws.hx);
+        ws.hx = nullptr; ws.hx_cap = 0;
+        FVAD_HIP(ctx, hipMalloc((void**)&ws.hx, need * sizeof(float)));
+        ws.hx_cap = need;
+        ws.generation++;
+    }
+    if (!ws.ws_sync) {
+        FVAD_HIP(ctx, hipMalloc((void**)&ws.ws_sync, kWsSyncWords * sizeof(unsigned)));
+        ws.generation++;
+    }
+    FVAD_HIP(ctx, hipMemsetAsync(ws.ws_sync, 0, kWsSyncWords * sizeof(unsigned), ctx->stream));
+    return FVAD_OK;
+}
+
+static int launch_gru(fvad_ctx* ctx, GruChoice c, const float* gi, const DevBuf& r_v2, const float* bR,
+                      float* hout, long n_pad, int T, int layer)
+{
+    if (c.version == 4) return fvad_launch_gru_lat(gi, r_v2.p, bR, hout, n_pad, T, nullptr, ctx->stream);
+    if (c.version == 5) {
+        Workspace& ws = ctx->ws;
+        unsigned* err = ws.ws_sync + 512;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(ctx->stream, &cap);
+        const bool serialise = cap == hipStreamCaptureStatusNone && ctx->device >= 0 && ctx->device < 64;
+        int rc;
+        {
+            std::unique_lock<std::mutex> lk(g_ws_mu, std::defer_lock);
+            if (serialise) {
+                lk.lock();
+                hipEvent_t& ev = g_ws_ev[ctx->device];
+                if (!ev) { if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return -1; }
+                else if (hipStreamWaitEvent(ctx->stream, ev, 0) != hipSuccess) return -1;
+            }
+            rc = fvad_launch_gru_ws(gi, r_v2.p, bR, hout, ws.hx, ws.ws_sync + 256 * layer, err, n_pad, T, ctx->n_cu, ctx->stream);
+            if (serialise && hipEventRecord(g_ws_ev[ctx->device], ctx->stream) != hipSuccess) return -1;
+        }
+        if (rc) return rc;
+        // fallback behind it: returns at once unless a workgroup of the launch above gave up waiting
+        return fvad_launch_gru_lat(gi, r_v2.p, bR, hout, n_pad, T, err, ctx->stream);
+    }
     if (c.waves <= 0 || n_pad % (16 * c.waves)) return -1;
     if (c.version == 3) return fvad_launch_gru_rec3(gi, r_v2.p, bR, hout, n_pad, T, c.waves, ctx->stream);
     if (c.version == 2) return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, c.waves, ctx->stream);
@@ -281,6 +352,7 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
         };
         const bool fold = !(force && strstr(force, "nofold"));
         const GruChoice gc = pick_gru(ctx, n_pad, fold);
+        if (gc.version == 5 && (rc = prepare_gru_ws(ctx, n_pad))) return rc; // only when forced: tuning / tests
         const bool bzr = gc.version == 3;
         if (fold) {
             time_begin(ctx, "gru1_in_gemm_fc1folded");
@@ -295,13 +367,13 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
             time_end(ctx);
         }
         time_begin(ctx, "gru1_rec");
-        rc |= launch_gru(ctx, gc, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T);
+        rc |= launch_gru(ctx, gc, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T, 0);
         time_end(ctx);
         time_begin(ctx, "gru2_in_gemm");
         rc |= gemm(ws.h1, 400, m.gi2v2_w.p, bzr ? m.gi2_bzr.p : m.gi2_b.p, ws.gi, 1200, rows, 15, 5, 25, 400, FVAD_ACT_NONE, 75, 0, 0);
         time_end(ctx);
         time_begin(ctx, "gru2_rec");
-        rc |= launch_gru(ctx, gc, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T);
+        rc |= launch_gru(ctx, gc, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T, 1);
         time_end(ctx);
         time_begin(ctx, "fc2_gemm");
         const bool fc13 = allow_v3 && !(force && strstr(force, "fc19"));
@@ -325,15 +397,16 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     time_begin(ctx, "gru1_in_gemm");
     rc |= fvad_launch_panel_gemm(ws.a1, 400, m.gi1_w.p, m.gi1_b.p, ws.gi, 1200, rows, 25, 3, 25, FVAD_ACT_NONE, 0, 0, st);
     time_end(ctx);
-    time_begin(ctx, "gru1_rec");
     const GruChoice gcs = pick_gru(ctx, n_pad, false);
-    rc |= launch_gru(ctx, gcs, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T);
+    if (gcs.version == 5 && (rc = prepare_gru_ws(ctx, n_pad))) return rc;
+    time_begin(ctx, "gru1_rec");
+    rc |= launch_gru(ctx, gcs, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T, 0);
     time_end(ctx);
     time_begin(ctx, "gru2_in_gemm");
     rc |= fvad_launch_panel_gemm(ws.h1, 400, m.gi2_w.p, m.gi2_b.p, ws.gi, 1200, rows, 25, 3, 25, FVAD_ACT_NONE, 0, 0, st);
     time_end(ctx);
     time_begin(ctx, "gru2_rec");
-    rc |= launch_gru(ctx, gcs, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T);
+    rc |= launch_gru(ctx, gcs, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T, 1);
     time_end(ctx);
     time_begin(ctx, "fc2_gemm");
     rc |= fvad_launch_panel_gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, skip ? T : 0, skip, st);
@@ -525,6 +598,8 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     if (ws.band) hipFree(ws.band);
     if (ws.bins) hipFree(ws.bins);
     if (ws.carries) hipFree(ws.carries);
+    if (ws.hx) hipFree(ws.hx);
+    if (ws.ws_sync) hipFree(ws.ws_sync);
     for (Workspace::PinRing* r : {&ws.ring_in, &ws.ring_out}) {
         if (r->base) hipHostFree(r->base);
         for (hipEvent_t& e : r->ev) if (e) hipEventDestroy(e);

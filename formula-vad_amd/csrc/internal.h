@@ -67,6 +67,10 @@ struct Workspace {
     float* band = nullptr; size_t band_cap = 0;
     float* bins = nullptr; size_t bins_cap = 0;
     LaneCarry* carries = nullptr; size_t carries_cap = 0; // scratch carries (2 per lane)
+    // weight-stationary recurrence (kernels_ws.hip): h exchange buffer and the block of polled words
+    // (256 flags per GRU layer + the error word, zeroed by ONE memset in front of every network pass)
+    float* hx = nullptr; size_t hx_cap = 0;
+    unsigned* ws_sync = nullptr;
     VadFftJob* fft_jobs = nullptr; VadFftJob* h_fft_jobs = nullptr; size_t fft_jobs_cap = 0;
     // pinned staging ring for large host <-> device transfers (two halves of kPinSlots slots)
     struct PinRing { char* base = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };

@@ -26,9 +26,7 @@
 
 #include "kernels.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#include "nn_device.h"
 
 __device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -581,8 +579,7 @@ int fvad_launch_panel_gemm3(const float* A, int lda, const float* Wfrag, const f
 // registers as the 25 activation float4s (100 VGPRs); new h values are written straight to hout in the
 // layout the lane itself re-reads as next step's operand, so the only cross-lane traffic in the
 // recurrence is the MFMA itself.
-constexpr int GRU_H = 400;
-constexpr int GRU_J = GRU_H / 16;     // 25 unit tiles
+// (GRU_H, GRU_J, GRU2_SLAB and the gate nonlinearities live in nn_device.h)
 
 // ------------------------------------------------------------------ GRU recurrence, v2
 // Large batches: every weight slab is shared by the wavefronts of a workgroup through LDS:
@@ -593,16 +590,6 @@ constexpr int GRU_J = GRU_H / 16;     // 25 unit tiles
 //     150 KB of the CU's 160 KB LDS -> 25 barriers per step instead of 125;
 //   * gate nonlinearities on v_exp_f32 / v_rcp_f32.
 // R2frag: [25 J][3 g][25 S][64][4].
-constexpr int GRU2_SLAB = 3 * GRU_J * 256; // floats per unit tile: 19200 (75 KB)
-
-__device__ __forceinline__ float fast_sigmoid(float x)
-{
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
-}
-__device__ __forceinline__ float fast_tanh(float x)
-{
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681f));
-}
 
 template <int WAVES>
 __device__ __forceinline__ void gru2_issue_slab(const float* __restrict__ src, float* lds_dst, int wave, int lane)
@@ -897,11 +884,13 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __restrict__ gi,
                                                              const float* __restrict__ R2frag,
                                                              const float* __restrict__ bR,
-                                                             float* hout, int T)
+                                                             float* hout, int T, const unsigned* guard)
 {
     __shared__ __attribute__((aligned(16))) float hs[2][GRU_J * 256];
     typedef const __attribute__((address_space(1))) f32x4* gptr4;
     constexpr int D = 5;
+    // launched behind gru_ws_kernel as its fallback: runs only if that kernel raised *guard (kernels_ws.hip)
+    if (guard && *guard == 0) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1019,10 +1008,10 @@ __global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __rest
 }
 
 int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, float* hout,
-                        long n_seq_pad, int T, hipStream_t stream)
+                        long n_seq_pad, int T, const unsigned* guard, hipStream_t stream)
 {
     if (n_seq_pad % 16) return -1;
-    hipLaunchKernelGGL((gru_lat_kernel<8>), dim3((unsigned)(n_seq_pad / 16)), dim3(512), 0, stream, gi, R2frag, bR, hout, T);
+    hipLaunchKernelGGL((gru_lat_kernel<8>), dim3((unsigned)(n_seq_pad / 16)), dim3(512), 0, stream, gi, R2frag, bR, hout, T, guard);
     return 0;
 }
 

@@ -198,6 +198,7 @@ def test_nsnet2_forward_matches_oracle(fv, gpu_ctx, weights7):
     {}, {"FVAD_GRU_KERNEL": "v3w12"}, {"FVAD_GRU_KERNEL": "v3w8"}, {"FVAD_GRU_KERNEL": "v3w4"},
     {"FVAD_GRU_KERNEL": "v2w12"}, {"FVAD_GRU_KERNEL": "v2w8"}, {"FVAD_GEMM_KERNEL": "v2"},
     {"FVAD_GEMM_KERNEL": "v2nofold"}, {"FVAD_GEMM_KERNEL": "v1"}, {"FVAD_GRU_KERNEL": "v4w8"},
+    {"FVAD_GRU_KERNEL": "v5w0"},
 ], ids=lambda e: "-".join(e.values()) or "default")
 def test_nsnet2_large_batch_kernels_match_oracle(fv, gpu_ctx, weights7, env, monkeypatch):
     # 2100 sequences take the large-batch path (LDS-DMA GEMMs, persistent GEMM, multi-wave recurrence);

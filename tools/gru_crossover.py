@@ -10,10 +10,11 @@ fv = pkg.binding
 ctx = fv.Context(0)
 ctx.load_synth(7)
 rng = np.random.default_rng(0)
-for n in (1024, 2048, 4096, 8192, 12288, 16384, 24576, 32768):
+sizes = [int(a) for a in sys.argv[1:]] or [1024, 2048, 4096, 8192, 12288, 16384, 24576, 32768]
+for n in sizes:
     f = rng.uniform(-11, 2, (n, 54, 161)).astype(np.float32)
     row = []
-    for k in ("v4w8", "v3w4", "v3w8", "v3w12", ""):
+    for k in ("v5w0", "v4w8", "v3w4", "v3w8", "v3w12", ""):
         if k:
             os.environ["FVAD_GRU_KERNEL"] = k
         else:
