@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfvad_hip.so")
+LIB_PATH = os.environ.get("FVAD_LIB_PATH") or os.path.join(_HERE, "libfvad_hip.so")  # the env override is a tuning aid (A/B builds)
 
 c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p

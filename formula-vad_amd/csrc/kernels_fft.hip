@@ -39,6 +39,11 @@ template <bool INV> __device__ __forceinline__ cpx mul_mi(cpx a) // a * (-i) for
     return INV ? cpx{-a.i, a.r} : cpx{a.i, -a.r};
 }
 __device__ __forceinline__ cpx ld_tw(const float* t, int idx) { return {t[2 * idx], t[2 * idx + 1]}; }
+// twiddle multiply inside the wavefront FFT: one rounding less per component than cmul (fused multiply-add)
+__device__ __forceinline__ cpx cmul_fma(cpx a, cpx b)
+{
+    return {__builtin_fmaf(a.r, b.r, -(a.i * b.i)), __builtin_fmaf(a.r, b.i, a.i * b.r)};
+}
 
 // ---- R-point DFT in registers (exponent sign: -, or + when INV)
 template <bool INV> __device__ __forceinline__ void dft5(cpx (&v)[5])
@@ -98,7 +103,9 @@ template <int R, bool INV> __device__ __forceinline__ void reg_dft(cpx (&v)[R])
 template <int R, int L> struct LaneTw {
     static constexpr int LOG_L = (L == 64) ? 6 : 5;
     cpx lane[R - 1];   // W_N^{p k1}, k1 = 1..R-1
-    cpx stage[LOG_L];  // DIF stage twiddle of this lane (1 for the lower half of a butterfly)
+    cpx stage[LOG_L];  // DIF stage twiddle of this lane: 1 for the lower half of a butterfly; for the upper half the
+                       // twiddle (strides 16, 32) or MINUS the twiddle (strides 2..8, where wave_fft forms
+                       // mine - other); unused for the last stage
 };
 
 template <int R, int L, bool INV>
@@ -117,26 +124,25 @@ __device__ __forceinline__ void lane_tw_load(LaneTw<R, L>& tw, const float* tabl
         if (p & h) {
             t = ld_tw(table, (p & (h - 1)) * (N / (2 * h)));
             if (INV) t = cconj(t);
+            if (h < 16) t = {-t.r, -t.i}; // the DPP stages form mine - other on the upper lane (see wave_fft)
         }
         tw.stage[s] = t;
     }
 }
 
-// value of lane (l ^ H).  __shfl_xor compiles to ds_bpermute_b32, which goes through the LDS pipe; the DIF
-// butterflies only need fixed xor patterns, and those exist as VALU data movement: quad permutes and
-// row rotates as DPP modifiers (H = 1, 2, 4, 8), gfx950's v_permlane16/32_swap for the row- and
-// half-crossing strides.
+// value of lane (l ^ H).  The FFT kernels are VALU-issue-bound (a wave64 VALU instruction holds its SIMD for
+// four cycles, and ~80 % of all SIMD cycles of the batch FFT are VALU), while the LDS pipe is nearly idle.  The
+// in-row strides therefore go through the LDS crossbar: ds_swizzle_b32 in bit-mask mode (lane ^ H inside groups
+// of 32, no LDS memory, no address VGPR), one LDS-pipe instruction per exchange and NO VALU instruction -- the DPP
+// forms (quad_perm / row_ror as v_mov_b32_dpp, two masked row shifts for H = 4) cost one to two VALU slots each.
+// Strides 16 and 32 use gfx950's v_permlane16/32_swap on scalar pairs (swap_butterfly).
 template <int H> __device__ __forceinline__ float lane_xor(float v, int lane)
 {
     const int x = __float_as_int(v);
     int r;
-    if constexpr (H == 1) r = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
-    else if constexpr (H == 2) r = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
-    else if constexpr (H == 4) {
-        r = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);                 // row_shl:4 into banks 0, 2
-        r = __builtin_amdgcn_update_dpp(r, x, 0x114, 0xF, 0xA, false);                 // row_shr:4 into banks 1, 3
-    } else if constexpr (H == 8) r = __builtin_amdgcn_mov_dpp(x, 0x128, 0xF, 0xF, true); // row_ror:8
-    else if constexpr (H == 16) {
+    if constexpr (H < 16) {
+        r = __builtin_amdgcn_ds_swizzle(x, (H << 10) | 0x1F); // and_mask 0x1f, or_mask 0, xor_mask H
+    } else if constexpr (H == 16) {
         const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
         r = (int)((lane & 16) ? sw[0] : sw[1]);
     } else {
@@ -158,26 +164,65 @@ __device__ __forceinline__ float lane_xor_dyn(float v, int h, int lane) // h is 
     }
 }
 
+// DIF butterflies of TWO scalars x, y across lanes l and l ^ H for the row- and half-crossing strides, with
+// gfx950's v_permlane16/32_swap (exchanges the odd rows / upper half of its first operand with the even rows /
+// lower half of its second).  swap(x, y) leaves a = [x_low, y_low], b = [x_high, y_high] (position by lane half);
+// a + b and a - b are then x's two results on the lower lanes and y's two on the upper lanes, and a second swap
+// puts each result on the lane that owns it: 4 instructions for 2 scalars instead of 2 x (2 copies, swap,
+// select, fma).  Values: lower lane x_low + x_high, upper lane x_low - x_high, exactly as before.
+template <int H> __device__ __forceinline__ void swap_butterfly(float& x, float& y)
+{
+    static_assert(H == 16 || H == 32, "swap_butterfly: stride");
+    const unsigned xi = (unsigned)__float_as_int(x), yi = (unsigned)__float_as_int(y);
+    const auto sw = (H == 16) ? __builtin_amdgcn_permlane16_swap(xi, yi, false, false)
+                              : __builtin_amdgcn_permlane32_swap(xi, yi, false, false);
+    const float a = __int_as_float((int)sw[0]), b = __int_as_float((int)sw[1]);
+    const float sum = a + b, dif = a - b;
+    const unsigned si = (unsigned)__float_as_int(sum), di = (unsigned)__float_as_int(dif);
+    const auto sw2 = (H == 16) ? __builtin_amdgcn_permlane16_swap(si, di, false, false)
+                               : __builtin_amdgcn_permlane32_swap(si, di, false, false);
+    x = __int_as_float((int)sw2[0]);
+    y = __int_as_float((int)sw2[1]);
+}
+
 // v[j] = z[p + L j] in, v[k1] = Z[k1 + R * bitrev_L(p)] out.
 template <int R, int L, bool INV>
 __device__ __forceinline__ void wave_fft(cpx (&v)[R], const LaneTw<R, L>& tw, int p)
 {
     reg_dft<R, INV>(v);
 #pragma unroll
-    for (int k1 = 1; k1 < R; ++k1) v[k1] = cmul(v[k1], tw.lane[k1 - 1]);
+    for (int k1 = 1; k1 < R; ++k1) v[k1] = cmul_fma(v[k1], tw.lane[k1 - 1]);
     int s = 0;
 #pragma unroll
     for (int h = L / 2; h >= 1; h >>= 1, ++s) {
-        const bool upper = (p & h) != 0;
+        // DIF butterfly across lanes l and l ^ h: lower lane a + b, upper lane (a_low - a_high) * w.
+        // With sgn = +1 on the lower and -1 on the upper lane both are one fma per component, exactly the
+        // sum / difference (a product by +-1 is exact):
+        //   h > 1:  t = other * sgn + mine  (upper: mine - other, the twiddle table holds -w there), written so that
+        //           the lane exchange folds into the fma as a DPP operand;
+        //   h = 1:  t = sgn * mine + other  (upper: other - mine; the last stage's twiddle is W^0 = 1).
+        if (h >= 16) {
+#pragma unroll
+            for (int k1 = 0; k1 < R; ++k1) {
+                if (h == 16) swap_butterfly<16>(v[k1].r, v[k1].i);
+                else swap_butterfly<32>(v[k1].r, v[k1].i);
+                v[k1] = cmul_fma(v[k1], tw.stage[s]);
+            }
+            continue;
+        }
+        const float sgn = (p & h) ? -1.0f : 1.0f;
 #pragma unroll
         for (int k1 = 0; k1 < R; ++k1) {
             const cpx mine = v[k1];
             cpx other;
             other.r = lane_xor_dyn(mine.r, h, p); // bit h of p is bit h of the lane index for every h < L
             other.i = lane_xor_dyn(mine.i, h, p);
-            // lower lane: a + b ; upper lane: (a_low - a_high) * w = (other - mine) * w
-            const cpx t = upper ? csub(other, mine) : cadd(mine, other);
-            v[k1] = cmul(t, tw.stage[s]);
+            if (h > 1) {
+                const cpx t = {__builtin_fmaf(other.r, sgn, mine.r), __builtin_fmaf(other.i, sgn, mine.i)};
+                v[k1] = cmul_fma(t, tw.stage[s]);
+            } else {
+                v[k1] = {__builtin_fmaf(sgn, mine.r, other.r), __builtin_fmaf(sgn, mine.i, other.i)};
+            }
         }
     }
 }
@@ -196,6 +241,19 @@ __device__ __forceinline__ void unmix_fwd(cpx zk, cpx znk, cpx st, cpx& xk, cpx&
     const cpx tw = cmul(f2k, st);
     xk = {(f1k.r + tw.r) * 0.5f, (f1k.i + tw.i) * 0.5f};
     xnk = {(f1k.r - tw.r) * 0.5f, (tw.i - f1k.i) * 0.5f};
+}
+// The same un-mixing with the factor 1/2 folded into the table (sth = st / 2, exact) and the final sums as fmas:
+// 0.5 * f1k + f2k * sth is (f1k + f2k * st) / 2 with the same roundings (products and their difference are halved
+// exactly, and round(a / 2 + b / 2) = round(a + b) / 2), in 14 instructions instead of 18.  Entry 0 of the table,
+// (0, -1/2), extends it to k = 0 with znk := z[0]: it yields X[0] = z.r + z.i and X[160] = z.r - z.i, kissfft's
+// special case, without a branch.
+__device__ __forceinline__ void unmix_fwd_h(cpx zk, cpx znk, cpx sth, cpx& xk, cpx& xnk)
+{
+    const cpx f1k = {zk.r + znk.r, zk.i - znk.i};
+    const cpx f2k = {zk.r - znk.r, zk.i + znk.i};
+    const cpx twh = cmul(f2k, sth);
+    xk = {__builtin_fmaf(0.5f, f1k.r, twh.r), __builtin_fmaf(0.5f, f1k.i, twh.i)};
+    xnk = {__builtin_fmaf(0.5f, f1k.r, -twh.r), __builtin_fmaf(-0.5f, f1k.i, twh.i)};
 }
 // and the inverse pre-mixing: T[k], T[ncfft-k] from Y[k], Y[ncfft-k]; st is the INVERSE twiddle
 __device__ __forceinline__ void premix_inv(cpx fk, cpx fnk, cpx st_inv, cpx& tk, cpx& tnk)
@@ -694,79 +752,147 @@ __global__ __launch_bounds__(256) void rfft1024_batch_kernel(const float* __rest
     }
 }
 
-// 320-point: two frames per wavefront, 8 frames per workgroup, frames straight from global
-__global__ __launch_bounds__(256) void rfft320_batch_kernel(const float* __restrict__ frames,
-                                                            long n_frames,
-                                                            const float* __restrict__ window,
-                                                            FftTables tb, float* __restrict__ bins,
-                                                            float* __restrict__ mag)
+// 320-point batch (BASELINE config 2).  Every wavefront runs its own pipeline over groups of 4 consecutive frames,
+// two at a time (two frames per 64-lane wavefront, as in K1) -- no workgroup barrier anywhere, so wavefronts
+// drift apart and cover each other's memory waits.  Per group and wavefront:
+//   * input: the 4 frames are 5 KB of contiguous samples; each lane fetches five float4 of the NEXT group into
+//     registers before this group's arithmetic and parks them in the wavefront's LDS slab after it (a request
+//     has a whole iteration to land);
+//   * the complex transform of a frame pair is written over the pair's (consumed) samples in the slab, un-mixed
+//     from there, and the 4 x 161 magnitudes (4 x 161 complex bins) are assembled in an LDS tile that leaves as
+//     flat float4 stores: a group's output starts at a multiple of 4 x 161 floats, i.e. 16-byte aligned.
+// LDS accesses of one wavefront execute in program order, so the slab needs no synchronisation beyond the
+// compiler keeping that order (wave_barrier).
+constexpr int RB_WF = 4;                        // frames per wavefront iteration
+#ifndef RB_OCC
+#define RB_OCC 4
+#endif
+
+template <bool HAS_BINS>
+__global__ __launch_bounds__(256, RB_OCC) void rfft320_batch_kernel(const float* __restrict__ frames,
+                                                                    long n_frames,
+                                                                    const float* __restrict__ window,
+                                                                    FftTables tb, float* __restrict__ bins,
+                                                                    float* __restrict__ mag, int vec_ok)
 {
-    __shared__ __attribute__((aligned(16))) float zb[4][2][2 * 160];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) float s_in[4][RB_WF * kNFft];
+    __shared__ __attribute__((aligned(16))) float s_mag[4][RB_WF * kNBins];
+    __shared__ __attribute__((aligned(16))) float s_bin[4][HAS_BINS ? RB_WF * kNBins * 2 : 4];
+    __shared__ __attribute__((aligned(8))) float s_sth[2 * 81]; // un-mixing table / 2, entry k for bin k (unmix_fwd_h)
+    __shared__ __attribute__((aligned(8))) float s_win[kNFft];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
     const int half = lane >> 5;
     const int p = lane & 31;
     LaneTw<5, 32> tw;
     lane_tw_load<5, 32, false>(tw, tb.tw160, p);
     const int k2 = bitrev_lane<32>(p);
-    float wre[5], wim[5];
+    // window coefficients are re-read from LDS for every frame pair (5 x ds_read_b64): ten registers less, which
+    // is what lets five wavefronts per SIMD fit without spilling
+    for (int i = tid; i < kNFft; i += 256) s_win[i] = window[i];
+    for (int i = tid; i < 162; i += 256) s_sth[i] = i >= 2 ? tb.st320[i - 2] * 0.5f : (i == 0 ? 0.0f : -0.5f);
+    __syncthreads(); // the only workgroup barrier: window and un-mixing table
+
+    float* in = s_in[wave];
+    float* tmag = s_mag[wave];
+    float* tbin = s_bin[wave];
+    constexpr int N4 = RB_WF * kNFft / 4; // 320 float4 per group = 5 per lane
+    // this lane's five float4 of the group starting at `base` (lanes past the end of the batch re-read the last
+    // valid float4: the loads stay unconditional, their values are never used)
+    auto fetch = [&](long base, f32x4 (&r)[5]) {
+        const long left4 = (n_frames - base) * (kNFft / 4);
+        const f32x4* src = reinterpret_cast<const f32x4*>(frames + base * kNFft);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        wre[j] = window[2 * (p + 32 * j)];
-        wim[j] = window[2 * (p + 32 * j) + 1];
-    }
-    // grid-stride over groups of 8 frames
-    for (long base = (long)blockIdx.x * 8; base < n_frames; base += (long)gridDim.x * 8) {
-        const long frame = base + 2 * wave + half;
-        if (frame < n_frames) {
-            const float* x = frames + frame * kNFft;
+        for (int j = 0; j < 5; ++j) {
+            long i4 = lane + 64 * j;
+            i4 = i4 < left4 ? i4 : left4 - 1;
+            r[j] = src[i4];
+        }
+    };
+    auto park = [&](const f32x4 (&r)[5]) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) reinterpret_cast<f32x4*>(in)[lane + 64 * j] = r[j];
+    };
+    const long stride = (long)gridDim.x * 4 * RB_WF;
+    long base = ((long)blockIdx.x * 4 + wave) * RB_WF;
+    f32x4 stage[5];
+    if (base < n_frames) { fetch(base, stage); park(stage); }
+    for (; base < n_frames; base += stride) {
+        const bool more = base + stride < n_frames;
+        if (more) fetch(base + stride, stage);
+#pragma unroll 1
+        for (int q = 0; q < RB_WF / 2; ++q) {
+            __builtin_amdgcn_wave_barrier();
+            const int fl = 2 * q + half; // frame of this half-wavefront within the group
             cpx v[5];
+            {
+                const float* x = in + fl * kNFft;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int n = 2 * (p + 32 * j);
-                const float2 xv = *reinterpret_cast<const float2*>(x + n);
-                v[j] = {xv.x * wre[j], xv.y * wim[j]};
+                for (int j = 0; j < 5; ++j) {
+                    const int n = 2 * (p + 32 * j);
+                    const float2 xv = *reinterpret_cast<const float2*>(x + n);
+                    const float2 wv = *reinterpret_cast<const float2*>(s_win + n);
+                    v[j] = {xv.x * wv.x, xv.y * wv.y}; // loadSamplesFwd, FFT.zig:183-199
+                }
             }
             wave_fft<5, 32, false>(v, tw, p);
-            float* z = zb[wave][half];
+            __builtin_amdgcn_wave_barrier();
+            {
+                float* z = in + fl * kNFft; // over the pair's own samples, which are in registers by now
 #pragma unroll
-            for (int k1 = 0; k1 < 5; ++k1) {
-                const int k = k1 + 5 * k2;
-                z[2 * k] = v[k1].r;
-                z[2 * k + 1] = v[k1].i;
-            }
-        }
-        __syncthreads();
-        for (int item = lane; item < 2 * 81; item += 64) {
-            const int hh = item / 81;
-            const int k = item - hh * 81;
-            const long fr = base + 2 * wave + hh;
-            if (fr < n_frames) {
-                const float* z = zb[wave][hh];
-                cpx xk, xnk;
-                int kn;
-                if (k == 0) {
-                    xk = {z[0] + z[1], 0.0f};
-                    xnk = {z[0] - z[1], 0.0f};
-                    kn = 160;
-                } else {
-                    kn = 160 - k;
-                    unmix_fwd({z[2 * k], z[2 * k + 1]}, {z[2 * kn], z[2 * kn + 1]},
-                              {tb.st320[2 * (k - 1)], tb.st320[2 * (k - 1) + 1]}, xk, xnk);
-                }
-                if (bins) {
-                    float* b = bins + fr * kNBins * 2;
-                    if (k != 80) { b[2 * k] = xk.r; b[2 * k + 1] = xk.i; }
-                    b[2 * kn] = xnk.r; b[2 * kn + 1] = xnk.i;
-                }
-                if (mag) {
-                    float* mrow = mag + fr * kNBins;
-                    if (k != 80) mrow[k] = sqrtf(xk.r * xk.r + xk.i * xk.i);
-                    mrow[kn] = sqrtf(xnk.r * xnk.r + xnk.i * xnk.i);
+                for (int k1 = 0; k1 < 5; ++k1) {
+                    const int k = k1 + 5 * k2;
+                    *reinterpret_cast<float2*>(z + 2 * k) = make_float2(v[k1].r, v[k1].i);
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+            // un-mix: lanes 0..31 take the pair's first frame, lanes 32..63 the second; bins k = p, p + 32, p + 64
+            // (<= 80) and their mirrors 160 - k.  Bin 80 is its own mirror: both forms are written, the X[ncfft - k]
+            // one last, as kissfft does.
+            if (base + fl < n_frames) {
+                const float* z = in + fl * kNFft;
+                float* mt = tmag + fl * kNBins;
+                float* bt = tbin + (HAS_BINS ? fl * (kNBins * 2) : 0);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int k = p + 32 * u;
+                    if (u < 2 || k <= 80) {
+                        const int kn = 160 - k;
+                        const int ksrc = (u == 0 && k == 0) ? 0 : kn; // z[160] does not exist: k = 0 pairs with itself
+                        const float2 zk = *reinterpret_cast<const float2*>(z + 2 * k);
+                        const float2 zn = *reinterpret_cast<const float2*>(z + 2 * ksrc);
+                        const float2 st = *reinterpret_cast<const float2*>(s_sth + 2 * k);
+                        cpx xk, xnk;
+                        unmix_fwd_h({zk.x, zk.y}, {zn.x, zn.y}, {st.x, st.y}, xk, xnk);
+                        if (HAS_BINS) {
+                            *reinterpret_cast<float2*>(bt + 2 * k) = make_float2(xk.r, xk.i);
+                            *reinterpret_cast<float2*>(bt + 2 * kn) = make_float2(xnk.r, xnk.i);
+                        }
+                        if (mag) { // v_sqrt_f32 (1 ulp): the batched magnitudes are a convenience output (FFT.zig:16-18)
+                            mt[k] = __builtin_amdgcn_sqrtf(__builtin_fmaf(xk.r, xk.r, xk.i * xk.i));
+                            mt[kn] = __builtin_amdgcn_sqrtf(__builtin_fmaf(xnk.r, xnk.r, xnk.i * xnk.i));
+                        }
+                    }
+                }
+            }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        // the next group's samples: the only wait for global memory in the loop, placed before this group's stores
+        // are issued (vmcnt retires in order: a wait behind the stores would wait for them too)
+        if (more) park(stage);
+        __builtin_amdgcn_wave_barrier();
+        const int nfr = (n_frames - base < RB_WF) ? (int)(n_frames - base) : RB_WF;
+        auto flush = [&](float* dst, const float* tile, int nfl) {
+            if (vec_ok) {
+                for (int i = lane; i < nfl / 4; i += 64) reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(tile)[i];
+                for (int i = (nfl & ~3) + lane; i < nfl; i += 64) dst[i] = tile[i];
+            } else {
+                for (int i = lane; i < nfl; i += 64) dst[i] = tile[i];
+            }
+        };
+        if (mag) flush(mag + base * kNBins, tmag, nfr * kNBins);
+        if (HAS_BINS) flush(bins + base * (kNBins * 2), tbin, nfr * kNBins * 2);
     }
 }
 
@@ -779,10 +905,16 @@ void fvad_launch_rfft_batch(const float* frames, long n_frames, int n_fft, const
         hipLaunchKernelGGL(rfft1024_batch_kernel, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0,
                            stream, frames, n_frames, window, tb, bins_or_null, mag_or_null);
     } else {
-        long groups = (n_frames + 7) / 8;
-        if (groups > 4096) groups = 4096;
-        hipLaunchKernelGGL(rfft320_batch_kernel, dim3((unsigned)groups), dim3(256), 0, stream, frames,
-                           n_frames, window, tb, bins_or_null, mag_or_null);
+        long groups = (n_frames + 15) / 16; // 4 wavefronts x 4 frames per workgroup and iteration
+        if (groups > 2048) groups = 2048;
+        // flat float4 stores need 16-byte aligned outputs (a group's tile starts at a multiple of 8 x 161 floats)
+        const int vec_ok = (((uintptr_t)bins_or_null | (uintptr_t)mag_or_null) % 16) == 0;
+        if (bins_or_null)
+            hipLaunchKernelGGL(rfft320_batch_kernel<true>, dim3((unsigned)groups), dim3(256), 0, stream, frames,
+                               n_frames, window, tb, bins_or_null, mag_or_null, vec_ok);
+        else
+            hipLaunchKernelGGL(rfft320_batch_kernel<false>, dim3((unsigned)groups), dim3(256), 0, stream, frames,
+                               n_frames, window, tb, bins_or_null, mag_or_null, vec_ok);
     }
 }
 
