@@ -57,6 +57,11 @@ def parse():
     ap.add_argument("--vad-threads", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL; one rank per GPU) or gloo (rehearsal: every rank on cuda:0)")
+    ap.add_argument("--config", default="headline", choices=("headline", "cfg4"),
+                    help="headline: BASELINE config 3's pipeline at a saturating batch (the metric's workload); "
+                         "cfg4: BASELINE config 4, 21 Miami-race-sized streams dealt round-robin to the ranks")
+    ap.add_argument("--cfg4-streams", type=int, default=21)
+    ap.add_argument("--cfg4-seconds", type=int, default=7200, help="seconds per stream (a multiple of 600)")
     return ap.parse_args()
 
 
@@ -138,6 +143,159 @@ def check_against_oracle(ctx, weights, host_pcm, lanes, d_den, n_samp, band, seg
     return out
 
 
+def gather_all_stats(pkg, fv, ctx, dist, world, args, cdev, local_ids, local_stats, n_streams):
+    """Per-stream SingleStats of every rank, in plan order.  One rank per GPU: the library's own RCCL
+    all-gather (fvad_stats_allgather, no torch on the path); rehearsal ranks that share a GPU, or a failure of
+    the native path, use the same exchange over torch.distributed.  Returns (stats, description)."""
+    if world == 1:
+        return pkg.shard.gather_stats(local_ids, [fv.single_stats_to_array(s) for s in local_stats], n_streams), "none"
+    if args.dist_backend == "nccl":
+        try:
+            comm = pkg.shard.native_comm(ctx, dist)
+            out = pkg.shard.gather_stats_native(comm, local_ids, local_stats, n_streams)
+            comm.close()
+            return out, "fvad_stats_allgather (ncclAllGather via librccl, C ABI)"
+        except Exception as e:  # keep the run alive; the JSON line says what happened
+            note = f"torch.distributed all_gather(nccl) after native path failed: {e!r}"
+    else:
+        note = f"torch.distributed all_gather({args.dist_backend})"
+    out = pkg.shard.gather_stats(local_ids, [fv.single_stats_to_array(s) for s in local_stats], n_streams,
+                                 dist=dist, device=cdev)
+    return out, note
+
+
+def roll_labels(labels, shift_s, period_s, reps):
+    """labels of np.tile(np.roll(x, shift), reps): every burst moves by shift_s modulo the period (split where it
+    wraps) and repeats every period"""
+    out = []
+    for a, b in labels:
+        a2, b2 = (a + shift_s) % period_s, (b + shift_s) % period_s
+        parts = [(a2, b2)] if a2 < b2 else [(a2, period_s), (0.0, b2)]
+        for r in range(reps):
+            out += [(x + r * period_s, y + r * period_s) for x, y in parts if y - x > 1e-6]
+    return sorted(out)
+
+
+def run_cfg4(args, pkg, fv, ctx, torch, dist, rank, world, cdev):
+    """BASELINE config 4: 21 independent streams (Miami-race sized) dealt round-robin to the ranks
+    (shard.streams_for_rank: 3,3,3,3,3,2,2,2 over 8), every rank runs the whole path for its streams -- GPU
+    kernels, host VAD, Evaluator statistics against the streams' labels -- then ONE all-gather of the per-stream
+    SingleStats and the plan-order aggregate (statistics.zig:116-172).  A step = the whole plan."""
+    L = fv.lib()
+    n_streams, seconds = args.cfg4_streams, args.cfg4_seconds
+    period = min(600, seconds)
+    reps = seconds // period
+    seconds = reps * period
+    mine = pkg.shard.streams_for_rank(n_streams, rank, world)
+    n_l = len(mine)
+    n_samp = seconds * 48000
+    n_chunks = n_samp // CHUNK
+    n_frames_fft = n_chunks * CHUNK // 1024
+    base, base_labels = pkg.synth.make_stream(float(period) + 0.5, seed=900)
+    base = base[0][: period * 48000].copy()
+    labels = {}
+    d_pcm = ctx.device_alloc(max(n_l, 1) * n_samp * 4)
+    for j, sid in enumerate(mine):                       # inputs resident in HBM before timing
+        x = np.tile(np.roll(base, 4801 * sid), reps)
+        ctx.to_device(d_pcm + j * n_samp * 4, x)
+        labels[sid] = roll_labels(base_labels, 4801 * sid / 48000.0, float(period), reps)
+        del x
+    d_band = ctx.device_alloc(max(n_l, 1) * n_frames_fft * 4)
+    d_rms = ctx.device_alloc(max(n_l, 1) * n_chunks * 4)
+    h_band = np.empty((n_l, n_frames_fft), np.float32)
+    h_rms = np.empty((n_l, n_chunks), np.float32)
+    fs = np.arange(n_frames_fft) * 1024
+    c0, c1 = fs // CHUNK, (fs + 1023) // CHUNK
+    w0 = (np.minimum((c0 + 1) * CHUNK, fs + 1024) - fs).astype(np.float32)
+    w1 = np.float32(1024) - w0
+    stat_cfg = {"ignore_shorter_than_sec": 0.7, "extrude_start": 5.0, "extrude_end": 10.0, "fill_gaps": 5.0}
+    vad_threads = args.vad_threads or min(max(n_l, 1), 16)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    comm = None
+    collective = "none"
+    if world > 1 and args.dist_backend == "nccl":
+        try:
+            comm = pkg.shard.native_comm(ctx, dist)
+            collective = "fvad_stats_allgather (ncclAllGather via librccl, C ABI)"
+        except Exception as e:
+            collective = f"torch.distributed all_gather(nccl) after native bootstrap failed: {e!r}"
+    elif world > 1:
+        collective = f"torch.distributed all_gather({args.dist_backend})"
+    timing = {}
+
+    def step():
+        t0 = time.perf_counter()
+        if n_l:
+            fv.check(L.fvad_engine_enqueue_device(ctx.h, d_pcm, n_l, n_samp, n_samp, None, d_band, d_rms, None), "cfg4 enqueue", ctx.h)
+            fv.check(L.fvad_ctx_copy_to_host(ctx.h, h_band.ctypes.data, d_band, h_band.nbytes), "cfg4 band", ctx.h)
+            fv.check(L.fvad_ctx_copy_to_host(ctx.h, h_rms.ctypes.data, d_rms, h_rms.nbytes), "cfg4 rms", ctx.h)
+            ctx.synchronize()
+        t1 = time.perf_counter()
+        rc = np.where(h_rms > 0, np.where(h_rms < 1, 1.0, 1.0 / np.maximum(h_rms, 1e-30)), 0.0).astype(np.float32)
+        rat = ((rc[:, c0] * w0 + np.where(w1 > 0, rc[:, c1] * w1, np.float32(0))) / (w0 + w1)).astype(np.float32)
+        ms = [fv.VadMachine() for _ in range(n_l)]
+        if n_l:
+            fv.vad_run_many(ms, [h_band[i][:, None] for i in range(n_l)], [rat[i] for i in range(n_l)], n_threads=vad_threads)
+        local = []
+        n_seg = 0
+        for m, sid in zip(ms, mine):
+            segs = m.segments()
+            n_seg += len(segs)
+            secs = [(np.float32(s_[0]) / np.float32(48000), np.float32(s_[1]) / np.float32(48000)) for s_ in segs]
+            local.append(fv.stats_from_segments(secs, labels[sid], stat_cfg))
+            m.close()
+        t2 = time.perf_counter()
+        if comm is not None:
+            allst = pkg.shard.gather_stats_native(comm, mine, local, n_streams)
+        else:
+            allst = pkg.shard.gather_stats(mine, [fv.single_stats_to_array(s_) for s_ in local], n_streams,
+                                           dist=dist if world > 1 else None, device=cdev if world > 1 else None)
+        agg = fv.stats_aggregate([fv.array_to_single_stats(a) for a in allst])   # plan order, every rank
+        t3 = time.perf_counter()
+        timing.update(gpu=(t1 - t0), host=(t2 - t1), gather_aggregate=(t3 - t2), segments=n_seg)
+        return allst, agg
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        allst, agg = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t[0])
+    if comm is not None:
+        comm.close()
+    if rank == 0:
+        frames = n_streams * n_chunks * FRAMES_PER_CHUNK
+        out = {
+            "metric": "20ms audio frames/sec end-to-end VAD pipeline", "value": frames * args.steps / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic 48 kHz mono (one 600 s seeded pattern, rolled per stream and tiled), random-init NSNet2 weights seed 7",
+            "config": {"workload": f"BASELINE config 4: {n_streams} streams x {seconds} s, whole streams dealt round-robin to "
+                                   f"{world} rank(s) ({[len(pkg.shard.streams_for_rank(n_streams, r, world)) for r in range(world)]}), "
+                                   "per-rank GPU path + host VAD + Evaluator statistics, one all-gather, plan-order aggregate",
+                       "streams": n_streams, "seconds_per_stream": seconds,
+                       "parallelism": f"streams sharded over {world} rank(s), no data-path collective"},
+            "audio_seconds_per_s": frames * args.steps / elapsed / 100.0,
+            "aggregate": {"n_streams": n_streams, "tpr": agg.true_positive_rate.overall, "ppv": agg.precision.overall,
+                          "collective": collective},
+            "rank0_step_s": timing,
+        }
+        print(json.dumps(out))
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -191,6 +349,14 @@ def main():
     ctx = fv.Context(local_rank)
     ctx.load_synth(7)
     weights = ctx.weights()
+
+    if args.config == "cfg4":
+        run_cfg4(args, pkg, fv, ctx, torch, dist, rank, world, cdev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        ctx.close()
+        return
 
     lanes, seconds = args.lanes, args.seconds
     n_chunks = seconds * 48000 // CHUNK
@@ -307,10 +473,9 @@ def main():
     local_stats = []
     for lane in range(lanes):
         segs = [(np.float32(s[0]) / np.float32(48000), np.float32(s[1]) / np.float32(48000)) for s in last[lane]]
-        local_stats.append(fv.single_stats_to_array(fv.stats_from_segments(segs, labels[lane], stat_cfg)))
+        local_stats.append(fv.stats_from_segments(segs, labels[lane], stat_cfg))
     ta = time.perf_counter()
-    allst = pkg.shard.gather_stats(local_ids, local_stats, lanes * world, dist=dist if world > 1 else None,
-                                   device=cdev if world > 1 else None)
+    allst, collective = gather_all_stats(pkg, fv, ctx, dist, world, args, cdev, local_ids, local_stats, lanes * world)
     agg = fv.stats_aggregate([fv.array_to_single_stats(a) for a in allst])
     agg_ms = (time.perf_counter() - ta) * 1e3
 
@@ -365,7 +530,7 @@ def main():
                 "hbm_frac_of_8TBps": frames_per_step * 3840 / (dev_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS if dev_ms_step else 0.0},
             "kernel_ms_per_step": {k: v / args.steps for k, v in ktimes.items()},
             "aggregate": {"ms": agg_ms, "n_streams": lanes * world, "tpr": agg.true_positive_rate.overall,
-                          "ppv": agg.precision.overall, "collective": f"all_gather({args.dist_backend})" if world > 1 else "none"},
+                          "ppv": agg.precision.overall, "collective": collective},
             "self_check": self_check,
             "host_vad_threads": vad_threads,
             "gpu_stage_wall_ms": float(np.mean(gpu_wall_ms[args.warmup:])),

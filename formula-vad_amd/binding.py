@@ -228,6 +228,12 @@ SIGNATURES = {
     "fvad_stats_from_segments": (C.c_int, [C.POINTER(SegmentSec), sz, C.POINTER(SegmentSec), sz,
                                            C.POINTER(StatConfig), C.POINTER(SingleStats)]),
     "fvad_stats_aggregate": (C.c_int, [C.POINTER(SingleStats), sz, C.POINTER(AggregateStats)]),
+    "fvad_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8), sz]),
+    "fvad_comm_create": (C.c_int, [vp, C.POINTER(C.c_uint8), sz, C.c_int, C.c_int, C.POINTER(vp)]),
+    "fvad_comm_destroy": (None, [vp]),
+    "fvad_comm_world": (C.c_int, [vp]),
+    "fvad_comm_rank": (C.c_int, [vp]),
+    "fvad_stats_allgather": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(SingleStats), sz, sz, C.POINTER(SingleStats)]),
     "fvad_parse_audacity": (C.c_int, [C.c_char_p, sz, C.POINTER(SegmentSec), sz, C.POINTER(sz)]),
     "fvad_wav_read": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(c_float_p)), C.POINTER(sz),
                                 C.POINTER(sz), C.POINTER(sz)]),
@@ -750,6 +756,41 @@ def stats_from_segments(vad, ref, cfg):
     check(lib().fvad_stats_from_segments(v, len(vad), r, len(ref), C.byref(sc), C.byref(out)),
           "statistics.fromEvaluator")
     return out
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """rank 0: the 128-byte RCCL bootstrap id (bytes) to hand to the other ranks"""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    check(lib().fvad_comm_unique_id(buf, COMM_ID_BYTES), "fvad_comm_unique_id")
+    return bytes(buf)
+
+
+class Comm:
+    """fvad_comm: one rank of the per-stream statistics all-gather (RCCL, bound to the context's device)"""
+
+    def __init__(self, ctx, unique_id, world, rank):
+        self.ctx = ctx
+        self.h = vp()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        check(lib().fvad_comm_create(ctx.h, buf, COMM_ID_BYTES, world, rank, C.byref(self.h)), "fvad_comm_create", ctx.h)
+        self.world, self.rank = world, rank
+
+    def allgather_stats(self, local_ids, local_stats, n_streams):
+        """local_stats: list of SingleStats -> list of n_streams SingleStats in plan order"""
+        n = len(local_ids)
+        ids = (C.c_uint32 * max(n, 1))(*local_ids)
+        loc = (SingleStats * max(n, 1))(*local_stats)
+        out = (SingleStats * n_streams)()
+        check(lib().fvad_stats_allgather(self.h, ids, loc, n, n_streams, out), "fvad_stats_allgather", self.ctx.h)
+        return list(out)
+
+    def close(self):
+        if self.h:
+            lib().fvad_comm_destroy(self.h)
+            self.h = vp()
 
 
 def stats_aggregate(stats):

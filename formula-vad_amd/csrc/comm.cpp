@@ -1,0 +1,170 @@
+// comm.cpp -- the one collective of the path: gathering the per-stream Evaluator statistics of a plan whose
+// streams were dealt to several GPUs (BASELINE config 4).
+//
+// The reference runs one pipeline per file on its own thread (src/simulator.zig:221-232) and builds the
+// report from the per-instance statistics IN PLAN ORDER (src/simulator/report_generator.zig:48-68,
+// src/Evaluator/statistics.zig:116-172: in-order f32 sums).  Here the instances live on different ranks, so
+// the 11-float SingleStats of every stream are all-gathered (ncclAllGather of one fixed block per rank,
+// <= 48 B per stream: latency only, xGMI bandwidth is irrelevant) and every rank can then run
+// fvad_stats_aggregate over the plan-ordered array -- bit-identical to the single-process aggregate.  A bare
+// all-reduce of the sums would reorder the f32 additions.
+//
+// RCCL is opened lazily (dlopen) the first time a communicator is asked for: single-GPU users of the library
+// never load it, and a Zig / C host needs no PyTorch for the multi-GPU leg.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "internal.h"
+
+using namespace fvad;
+
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+
+RcclApi* rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (!api.handle) { api.err = std::string("dlopen(librccl.so) failed: ") + (dlerror() ? dlerror() : "?"); return; }
+#define SYM(field, sym)                                                             \
+    api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, sym));      \
+    if (!api.field) { api.err = std::string("RCCL symbol missing: ") + sym; return; }
+        SYM(GetUniqueId, "ncclGetUniqueId")
+        SYM(CommInitRank, "ncclCommInitRank")
+        SYM(CommDestroy, "ncclCommDestroy")
+        SYM(AllGather, "ncclAllGather")
+        SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    });
+    return &api;
+}
+constexpr int kRow = 12; // stream id (bit pattern) + the 11 floats of fvad_single_stats
+static_assert(sizeof(fvad_single_stats) == 11 * sizeof(float), "SingleStats layout");
+static_assert(sizeof(ncclUniqueId) == FVAD_COMM_ID_BYTES, "ncclUniqueId size");
+} // namespace
+
+struct fvad_comm {
+    fvad_ctx* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0;
+    float* d_send = nullptr;
+    float* d_recv = nullptr;
+    size_t cap_rows = 0; // rows per rank the device blocks can hold
+};
+
+extern "C" {
+
+int fvad_comm_unique_id(uint8_t* id, size_t n)
+{
+    if (!id || n < FVAD_COMM_ID_BYTES) return FVAD_ERR_INVALID_ARGUMENT;
+    RcclApi* a = rccl();
+    if (!a->err.empty()) return FVAD_ERR_NO_DEVICE;
+    ncclUniqueId u;
+    if (a->GetUniqueId(&u) != ncclSuccess) return FVAD_ERR_HIP;
+    memcpy(id, &u, sizeof u);
+    return FVAD_OK;
+}
+
+int fvad_comm_create(fvad_ctx* ctx, const uint8_t* id, size_t n, int world, int rank, fvad_comm** out)
+{
+    if (!ctx || !id || !out || n < FVAD_COMM_ID_BYTES || world < 1 || rank < 0 || rank >= world) return FVAD_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    RcclApi* a = rccl();
+    if (!a->err.empty()) return set_err(ctx, FVAD_ERR_NO_DEVICE, a->err);
+    hipSetDevice(ctx->device);
+    auto* c = new (std::nothrow) fvad_comm();
+    if (!c) return FVAD_ERR_ALLOC_FAILED;
+    c->ctx = ctx; c->world = world; c->rank = rank;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    const ncclResult_t r = a->CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return set_err(ctx, FVAD_ERR_HIP, std::string("ncclCommInitRank: ") + a->GetErrorString(r));
+    }
+    *out = c;
+    return FVAD_OK;
+}
+
+void fvad_comm_destroy(fvad_comm* c)
+{
+    if (!c) return;
+    hipSetDevice(c->ctx->device);
+    hipStreamSynchronize(c->ctx->stream);
+    if (c->comm) rccl()->CommDestroy(c->comm);
+    if (c->d_send) hipFree(c->d_send);
+    if (c->d_recv) hipFree(c->d_recv);
+    delete c;
+}
+
+int fvad_comm_world(const fvad_comm* c) { return c ? c->world : 0; }
+int fvad_comm_rank(const fvad_comm* c) { return c ? c->rank : -1; }
+
+int fvad_stats_allgather(fvad_comm* c, const uint32_t* local_ids, const fvad_single_stats* local_stats, size_t n_local,
+                         size_t n_streams, fvad_single_stats* out)
+{
+    if (!c || !out || (n_local && (!local_ids || !local_stats)) || n_streams == 0) return FVAD_ERR_INVALID_ARGUMENT;
+    fvad_ctx* ctx = c->ctx;
+    RcclApi* a = rccl();
+    hipSetDevice(ctx->device);
+    const size_t per_rank = (n_streams + (size_t)c->world - 1) / (size_t)c->world;
+    if (n_local > per_rank) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "more local streams than ceil(n_streams / world)");
+    if (per_rank > c->cap_rows) {
+        hipStreamSynchronize(ctx->stream);
+        if (c->d_send) hipFree(c->d_send);
+        if (c->d_recv) hipFree(c->d_recv);
+        c->d_send = c->d_recv = nullptr; c->cap_rows = 0;
+        FVAD_HIP(ctx, hipMalloc((void**)&c->d_send, per_rank * kRow * sizeof(float)));
+        FVAD_HIP(ctx, hipMalloc((void**)&c->d_recv, per_rank * kRow * sizeof(float) * (size_t)c->world));
+        c->cap_rows = per_rank;
+    }
+    // this rank's block: [per_rank][12], unused rows carry the id 0xFFFFFFFF
+    std::vector<float> block(per_rank * kRow, 0.0f);
+    for (size_t j = 0; j < per_rank; ++j) {
+        uint32_t id = 0xFFFFFFFFu;
+        if (j < n_local) {
+            if (local_ids[j] >= n_streams) return set_err(ctx, FVAD_ERR_OUT_OF_RANGE, "stream id >= n_streams");
+            id = local_ids[j];
+            memcpy(&block[j * kRow + 1], &local_stats[j], sizeof(fvad_single_stats));
+        }
+        memcpy(&block[j * kRow], &id, sizeof id);
+    }
+    FVAD_HIP(ctx, hipMemcpyAsync(c->d_send, block.data(), block.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    const ncclResult_t r = a->AllGather(c->d_send, c->d_recv, per_rank * kRow, ncclFloat, c->comm, ctx->stream);
+    if (r != ncclSuccess) return set_err(ctx, FVAD_ERR_HIP, std::string("ncclAllGather: ") + a->GetErrorString(r));
+    std::vector<float> all(per_rank * kRow * (size_t)c->world);
+    FVAD_HIP(ctx, hipMemcpyAsync(all.data(), c->d_recv, all.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    FVAD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // plan order: row `id` of the result is stream `id`, whichever rank computed it
+    std::vector<char> seen(n_streams, 0);
+    for (size_t j = 0; j < per_rank * (size_t)c->world; ++j) {
+        uint32_t id;
+        memcpy(&id, &all[j * kRow], sizeof id);
+        if (id == 0xFFFFFFFFu) continue;
+        if (id >= n_streams || seen[id]) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "stream id gathered twice or out of range");
+        memcpy(&out[id], &all[j * kRow + 1], sizeof(fvad_single_stats));
+        seen[id] = 1;
+    }
+    for (size_t i = 0; i < n_streams; ++i)
+        if (!seen[i]) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "a stream's statistics never arrived");
+    return FVAD_OK;
+}
+
+} // extern "C"

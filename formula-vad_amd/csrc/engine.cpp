@@ -271,15 +271,13 @@ static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, bool allow_v3)
     return {allow_v3 ? 3 : 2, best};
 }
 
-// buffers of the weight-stationary recurrence; the polled words are zeroed once per network pass
-static int prepare_gru_ws(fvad_ctx* ctx, long n_pad)
+// buffers of the weight-stationary recurrence, sized once for the largest batch that kernel takes (2560
+// sequences: 8 MB of h exchange) so that nothing is allocated inside a stream capture
+int ensure_gru_ws(fvad_ctx* ctx)
 {
     Workspace& ws = ctx->ws;
-    const size_t need = fvad_gru_ws_exchange_floats(n_pad);
-    if (need > ws.hx_cap) {
-        hipStreamSynchronize(ctx->stream);
-        if (ws.hx) hipFree(ws.hx);
-        ws.hx = nullptr; ws.hx_cap = 0;
+    const size_t need = fvad_gru_ws_exchange_floats(2560);
+    if (!ws.hx) {
         FVAD_HIP(ctx, hipMalloc((void**)&ws.hx, need * sizeof(float)));
         ws.hx_cap = need;
         ws.generation++;
@@ -288,7 +286,17 @@ static int prepare_gru_ws(fvad_ctx* ctx, long n_pad)
         FVAD_HIP(ctx, hipMalloc((void**)&ws.ws_sync, kWsSyncWords * sizeof(unsigned)));
         ws.generation++;
     }
-    FVAD_HIP(ctx, hipMemsetAsync(ws.ws_sync, 0, kWsSyncWords * sizeof(unsigned), ctx->stream));
+    return FVAD_OK;
+}
+
+// the polled words (flags of both GRU layers, error word) are zeroed once per network pass -- by a kernel, not
+// a memset: the launch sequence may be under capture, and a captured graph holds kernel nodes only
+static int prepare_gru_ws(fvad_ctx* ctx, long n_pad)
+{
+    int rc = ensure_gru_ws(ctx);
+    if (rc) return rc;
+    if (fvad_gru_ws_exchange_floats(n_pad) > ctx->ws.hx_cap) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "batch too large for gru_ws");
+    fvad_launch_zero_words(ctx->ws.ws_sync, (int)kWsSyncWords, ctx->stream);
     return FVAD_OK;
 }
 
@@ -1236,6 +1244,7 @@ int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes
         if (maxc <= 0) { const char* e = getenv("FVAD_MAX_CHUNKS"); maxc = e ? atol(e) : 49152; }
         const long total = (long)(n_lanes * n_chunks);
         if ((rc = ensure_workspace(ctx, std::min(total, maxc), kRowsPerChunk))) return rc; // no allocation while capturing
+        if ((rc = ensure_gru_ws(ctx))) return rc;
         Workspace::GraphCache& gc = ws.graph;
         const bool hit = gc.valid && gc.pcm == d_pcm && gc.den == den && gc.band == d_band_sum && gc.rms == d_chunk_rms &&
                          gc.n_lanes == n_lanes && gc.lane_stride == lane_stride && gc.n_samples == n_samples &&

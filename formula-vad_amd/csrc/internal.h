@@ -147,6 +147,7 @@ int hip_fail(const fvad_ctx* ctx, hipError_t e, const char* what);
 
 int upload_model(fvad_ctx* ctx);
 int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T);
+int ensure_gru_ws(fvad_ctx* ctx);
 // NSNet2 on ws.feat -> ws.gains for n_chunks sequences of T rows; gains rows skip..T-1 only
 int run_nn(fvad_ctx* ctx, long n_chunks_pad, int T, int skip);
 

@@ -76,6 +76,7 @@ int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, f
 // small batches: recurrent weights stationary in registers across 25 x G workgroups, h exchanged per step
 // (kernels_ws.hip).  hx: fvad_gru_ws_exchange_floats(n_seq_pad) floats; flags: 256 zeroed words per launch;
 // err: one zeroed word shared by the launches of a network pass.  Returns -1 when the batch is too large.
+void fvad_launch_zero_words(unsigned* p, int n, hipStream_t stream);
 bool fvad_gru_ws_shape(long n_seq_pad, int n_cu, int* RT, int* G);
 size_t fvad_gru_ws_exchange_floats(long n_seq_pad);
 int fvad_launch_gru_ws(const float* gi, const float* R2frag, const float* bR, float* hout, float* hx, unsigned* flags,

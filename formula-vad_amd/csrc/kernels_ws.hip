@@ -234,6 +234,16 @@ __global__ __launch_bounds__(256) void gru_ws_kernel(const float* __restrict__ g
     }
 }
 
+__global__ void zero_words_kernel(unsigned* p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+void fvad_launch_zero_words(unsigned* p, int n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, n);
+}
+
 // Geometry of a launch over n_seq_pad sequences (a multiple of 16) on n_cu compute units: G groups of
 // RT row tiles, 25 workgroups per group.  Returns false when the batch is too large for this kernel.
 bool fvad_gru_ws_shape(long n_seq_pad, int n_cu, int* RT, int* G)
@@ -258,8 +268,8 @@ int fvad_launch_gru_ws(const float* gi, const float* R2frag, const float* bR, fl
     if (!fvad_gru_ws_shape(n_seq_pad, n_cu, &RT, &G)) return -1;
     const int n_rt = (int)(n_seq_pad / 16);
     // more than half of a CU's 160 KB of LDS: one workgroup per CU, whatever the exchange tile needs
-    const size_t lds = 84 * 1024;
-    if ((size_t)(2 * GRU_J + RT * 3) * 1024 + 16 > lds) return -1;
+    const size_t need = (size_t)(2 * GRU_J + RT * 3) * 1024 + 16;
+    const size_t lds = need > 84 * 1024 ? need : 84 * 1024;
 #define WS_CASE(OWN_)                                                                                               \
     {                                                                                                               \
         if (hipFuncSetAttribute((const void*)gru_ws_kernel<OWN_>, hipFuncAttributeMaxDynamicSharedMemorySize,       \

@@ -4,8 +4,10 @@ Streams never interact (one pipeline per file in the reference, src/simulator.zi
 whole streams are dealt round-robin to ranks and no audio crosses GPUs.  The only exchange is the
 final gather of the per-stream Evaluator statistics (11 f32 each, statistics.zig:8-37) to rank 0,
 where statistics.aggregate runs in PLAN order to keep the reference's f32 summation order
-(statistics.zig:124-129).  On GPUs the gather is one torch.distributed all_gather over RCCL
-(backend "nccl"); on CPU (tests) the same code runs over gloo."""
+(statistics.zig:124-129).  On GPUs the gather is the library's own ncclAllGather (fvad_stats_allgather,
+csrc/comm.cpp: no PyTorch on that path, `native_comm` only borrows torch.distributed to hand the 128-byte
+bootstrap id around); `gather_stats` is the same exchange over torch.distributed, used with gloo for CPU
+tests and for rehearsals of several ranks on one GPU (RCCL refuses two ranks on one device)."""
 import numpy as np
 
 N_STAT = 11  # floats in SingleStats as laid out in include/fvad.h (f_score_beta included)
@@ -45,3 +47,20 @@ def gather_stats(local_ids, local_stats, n_streams, dist=None, device=None):
                 seen[sid] = True
     assert seen.all(), "a stream's statistics never arrived"
     return out
+
+
+def native_comm(ctx, dist):
+    """One fvad Comm (RCCL) per rank of an initialised torch.distributed job: rank 0 creates the bootstrap
+    id, broadcast_object_list carries it (any backend), every rank joins with its context's device."""
+    from . import binding as fv
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [fv.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return fv.Comm(ctx, box[0], world, rank)
+
+
+def gather_stats_native(comm, local_ids, local_stats, n_streams):
+    """local_stats: list of binding.SingleStats -> [n_streams][N_STAT] float32 in plan order (every rank)"""
+    from . import binding as fv
+    allst = comm.allgather_stats(list(local_ids), list(local_stats), n_streams)
+    return np.stack([fv.single_stats_to_array(s) for s in allst]) if allst else np.zeros((0, N_STAT), np.float32)

@@ -9,8 +9,9 @@ Plan schema = the reference's (simulator.zig:41-76, tmp/plan.example.json), unkn
 (simulator.zig:152-154); audio/ref paths are relative to the plan file (simulator.zig:146,
 SimulationInstance.zig:101-104).  Differences, by design:
   * audio files are WAV (PCM16 / float32), not OGG: there is no libsndfile here;
-  * instances are not run one-thread-each (simulator.zig:221-232): all channels of all instances
-    form ONE GPU batch, then the per-instance VAD state machines run lock-step on the host;
+  * instances are not run one-thread-each (simulator.zig:221-232): all channels of all instances on a GPU
+    form ONE batch, then the per-instance VAD state machines run on the host; with --devices the
+    instances are dealt round-robin to one context + one host thread per GPU;
   * `preload_audio` only changes how samples are pushed in the reference, not the result.
 """
 import argparse
@@ -146,39 +147,32 @@ def audacity_txt(vad_secs, debug_infos, ref_secs, cfg):
     return "".join(lines)
 
 
-def run_plan(plan_path, ctx=None, synth_seed=None, out=sys.stdout):
-    """Runs a whole plan; returns (report_text, per_instance_results)."""
-    plan = load_plan(plan_path)
-    own_ctx = ctx is None
-    if own_ctx:
-        ctx = fv.Context(0)
-        if plan["denoiser_model_path"]:
-            ctx.load_onnx(os.path.join(plan["base_path"], plan["denoiser_model_path"]))
-        elif os.path.exists("data/nsnet2-20ms-baseline.onnx"):   # NSNet2.zig:56 default
-            ctx.load_onnx("data/nsnet2-20ms-baseline.onnx")
-        else:
-            if synth_seed is None:
-                raise FileNotFoundError("no denoiser_model_path in the plan and no data/nsnet2-20ms-baseline.onnx "
-                                        "(pass synth_seed to run on random-init weights)")
-            ctx.load_synth(synth_seed)
-    # --- load everything, one GPU batch over all channels of all instances
-    audio, refs = [], []
-    for inst in plan["instances"]:
-        pcm, sr = fv.wav_read(inst["audio_path"])
-        if sr != 48000:
-            raise fv.FvadError(-9, f"{inst['name']}: sample rate {sr}")   # VADPipeline.zig:55-58
-        audio.append(pcm)
-        with open(inst["ref_path"], "rb") as f:
-            refs.append(fv.parse_audacity(f.read()))
-    t0 = time.perf_counter()
+def _make_ctx(plan, device, synth_seed):
+    ctx = fv.Context(device)
+    if plan["denoiser_model_path"]:
+        ctx.load_onnx(os.path.join(plan["base_path"], plan["denoiser_model_path"]))
+    elif os.path.exists("data/nsnet2-20ms-baseline.onnx"):   # NSNet2.zig:56 default
+        ctx.load_onnx("data/nsnet2-20ms-baseline.onnx")
+    else:
+        if synth_seed is None:
+            ctx.close()
+            raise FileNotFoundError("no denoiser_model_path in the plan and no data/nsnet2-20ms-baseline.onnx "
+                                    "(pass synth_seed to run on random-init weights)")
+        ctx.load_synth(synth_seed)
+    return ctx
+
+
+def _run_instances(ctx, plan, audio):
+    """The path for a set of instances on one context: ONE GPU batch over all their channels, then the
+    per-instance VAD state machines on the host.  Returns [(segments, audit)] in the order given."""
+    if not audio:
+        return []
     lanes = [pcm[c] for pcm in audio for c in range(pcm.shape[0])]
-    lo = fv.lib().fvad_fft_freq_to_bin  # band edges via FFT.freqToBin on a 1024 / 48 kHz transform
     vm = plan["vad_machine_config"]
-    bin_w = np.float32(48000) / np.float32(plan["fft_size"])
+    bin_w = np.float32(48000) / np.float32(plan["fft_size"])  # band edges: FFT.freqToBin (FFT.zig:156-167)
     min_bin = int(np.round(np.float32(vm.get("speech_min_freq", 500.0)) / bin_w))
     max_bin = int(np.round(np.float32(vm.get("speech_max_freq", 2000.0)) / bin_w))
     res = ctx.engine_run(lanes, min_bin=min_bin, max_bin=max_bin)
-    # --- host: metadata + VAD state machines, all instances lock-step
     machines, bands, ratios = [], [], []
     k = 0
     for pcm in audio:
@@ -190,24 +184,79 @@ def run_plan(plan_path, ctx=None, synth_seed=None, out=sys.stdout):
         ratios.append(frame_ratios(rms, band.shape[0], plan["fft_size"]))
         bands.append(band)
         machines.append(fv.VadMachine(n_channels=C_, fft_size=plan["fft_size"], overrides=vm))
-    for nch in sorted({m.n_channels for m in machines}):      # the lock-step driver wants one channel count
+    for nch in sorted({m.n_channels for m in machines}):      # the batched driver wants one channel count
         idx = [i for i, m in enumerate(machines) if m.n_channels == nch]
         fv.vad_run_many([machines[i] for i in idx], [bands[i] for i in idx], [ratios[i] for i in idx],
                         fft_size=plan["fft_size"], n_threads=min(16, len(idx)))
+    out = [(m.segments(), m.audit()) for m in machines]
+    for m in machines:
+        m.close()
+    return out
+
+
+def run_plan(plan_path, ctx=None, synth_seed=None, out=sys.stdout, devices=None):
+    """Runs a whole plan; returns (report_text, per_instance_results).
+
+    devices: list of HIP device indices -- one context and one host thread per entry, instance i on
+    devices[i % len(devices)] (the reference's unit of parallelism is the instance: one thread per file,
+    simulator.zig:221-232; here one thread per GPU with that GPU's instances as one batch).  The report is built
+    from the per-instance statistics in PLAN order whatever the split (report_generator.zig:48-68,
+    statistics.zig:116-172), so it is identical for every device list."""
+    import threading
+    plan = load_plan(plan_path)
+    own_ctx = ctx is None
+    if own_ctx:
+        ctxs = [_make_ctx(plan, d, synth_seed) for d in (devices or [0])]
+    else:
+        ctxs = [ctx]
+    audio, refs = [], []
+    for inst in plan["instances"]:
+        pcm, sr = fv.wav_read(inst["audio_path"])
+        if sr != 48000:
+            raise fv.FvadError(-9, f"{inst['name']}: sample rate {sr}")   # VADPipeline.zig:55-58
+        audio.append(pcm)
+        with open(inst["ref_path"], "rb") as f:
+            refs.append(fv.parse_audacity(f.read()))
+    t0 = time.perf_counter()
+    n_ctx = len(ctxs)
+    parts = [[i for i in range(len(audio)) if i % n_ctx == d] for d in range(n_ctx)]
+    done = [None] * n_ctx
+    errs = []
+
+    def work(d):
+        try:
+            done[d] = _run_instances(ctxs[d], plan, [audio[i] for i in parts[d]])
+        except Exception as e:  # re-raised below, in the caller's thread
+            errs.append(e)
+
+    if n_ctx == 1:
+        work(0)
+    else:
+        th = [threading.Thread(target=work, args=(d,)) for d in range(n_ctx)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    if errs:
+        raise errs[0]
+    per_inst = [None] * len(audio)
+    for d in range(n_ctx):
+        for i, r in zip(parts[d], done[d]):
+            per_inst[i] = r
     elapsed = time.perf_counter() - t0
+    vm = plan["vad_machine_config"]
     # --- Evaluator + statistics (simulator.zig:127-132)
     stat_cfg = {"ignore_shorter_than_sec": float(np.float32(vm.get("min_vad_duration_sec", 0.7))),
                 "extrude_start": 5.0, "extrude_end": 10.0, "fill_gaps": 5.0}
     names, stats, results = [], [], []
-    for inst, m, ref in zip(plan["instances"], machines, refs):
-        segs = m.segments()
+    for inst, (segs, audit), ref in zip(plan["instances"], per_inst, refs):
         secs = [(float(np.float32(s[0]) / np.float32(48000)), float(np.float32(s[1]) / np.float32(48000))) for s in segs]
         infos = ["vr:{} vad:{}s".format(zig_fixed(s[2], 2), zig_fixed(s[3], 1)) for s in segs]  # SimulationInstance.zig:240-244
         st = fv.stats_from_segments(secs, ref, stat_cfg)
         names.append(inst["name"])
         stats.append(st)
         results.append({"name": inst["name"], "segments": segs, "segments_sec": secs, "debug_info": infos,
-                        "stats": st, "audacity": audacity_txt(secs, infos, ref, stat_cfg), "audit": m.audit()})
+                        "stats": st, "audacity": audacity_txt(secs, infos, ref, stat_cfg), "audit": audit})
     agg = fv.stats_aggregate(stats)
     text = report_text(names, stats, agg)
     if plan["output_dir"]:
@@ -223,7 +272,8 @@ def run_plan(plan_path, ctx=None, synth_seed=None, out=sys.stdout):
         audio_s = sum(p.shape[1] for p in audio) / 48000.0
         out.write(f"\n[{audio_s:.0f} s of audio in {elapsed:.2f} s = {audio_s / elapsed:.0f}x realtime]\n")
     if own_ctx:
-        ctx.close()
+        for c in ctxs:
+            c.close()
     return text, results
 
 
@@ -258,8 +308,10 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description="Formula-VAD simulator harness on MI355X")
     ap.add_argument("-i", "--input", required=True, help="Simulation plan (path to JSON)")  # simulator.zig:78-82
     ap.add_argument("--synth-seed", type=int, default=None, help="use random-init NSNet2 weights")
+    ap.add_argument("--devices", default="0", help="comma-separated HIP devices: one context + one thread each, "
+                                                   "instances dealt round-robin (e.g. 0,1,2,3,4,5,6,7)")
     a = ap.parse_args(argv)
-    run_plan(a.input, synth_seed=a.synth_seed)
+    run_plan(a.input, synth_seed=a.synth_seed, devices=[int(d) for d in a.devices.split(",") if d != ""])
 
 
 if __name__ == "__main__":

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FVAD_ABI_VERSION 1
+#define FVAD_ABI_VERSION 2
 
 /* ------------------------------------------------------------------ status codes */
 enum {
@@ -385,6 +385,23 @@ int fvad_stats_from_segments(const fvad_segment_sec *vad, size_t n_vad,
                              const fvad_stat_config *cfg, fvad_single_stats *out);
 /* statistics.aggregate(stats)  statistics.zig:116-172 -- in slice order */
 int fvad_stats_aggregate(const fvad_single_stats *stats, size_t n, fvad_aggregate_stats *out);
+/* ---- multi-GPU: the plan's streams are dealt round-robin to one rank (process or thread) per GPU, nothing but
+ * these per-stream statistics ever crosses GPUs.  Replaces the join of the reference's one-thread-per-file
+ * instances (src/simulator.zig:221-232) in front of report_generator.zig:48-68: every rank hands in the
+ * SingleStats of its streams, every rank receives all n_streams of them in PLAN order (stream id = index in
+ * the plan), ready for fvad_stats_aggregate -- bit-identical to a single-process run.  Transport: one
+ * ncclAllGather over RCCL / xGMI (RCCL is dlopen'ed on first use).  Bootstrap like NCCL's own: rank 0 makes
+ * the 128-byte id and hands it to the other ranks by whatever channel the host has (file, socket, env). */
+#define FVAD_COMM_ID_BYTES 128
+typedef struct fvad_comm fvad_comm;
+int fvad_comm_unique_id(uint8_t *id, size_t n_bytes);                   /* ncclGetUniqueId */
+int fvad_comm_create(fvad_ctx *ctx, const uint8_t *id, size_t n_bytes, int world, int rank,
+                     fvad_comm **out);                                   /* ncclCommInitRank on ctx's device */
+void fvad_comm_destroy(fvad_comm *c);
+int fvad_comm_world(const fvad_comm *c);
+int fvad_comm_rank(const fvad_comm *c);
+int fvad_stats_allgather(fvad_comm *c, const uint32_t *local_ids, const fvad_single_stats *local_stats,
+                         size_t n_local, size_t n_streams, fvad_single_stats *out /* [n_streams] */);
 /* formats.parseAudacitySegments / serialize  (Evaluator/formats.zig:7-56) */
 int fvad_parse_audacity(const char *txt, size_t len, fvad_segment_sec *out, size_t cap,
                         size_t *n);

@@ -660,3 +660,41 @@ def test_pipeline_recordings_match_oracle(fv, gpu_ctx, weights7, pkg):
     q = fv.AudioPipeline(gpu_ctx, n_channels=2)
     q.push_samples(pcm)
     assert q.segments() == segs and q.recordings == {"original": [], "denoised": []}
+
+
+# ------------------------------------------------------------------ multi-GPU leg (BASELINE config 4)
+def test_native_comm_single_rank_allgather(fv, gpu_ctx):
+    # the C ABI's RCCL all-gather on a one-rank communicator (what a one-GPU box can run): plan order out
+    comm = fv.Comm(gpu_ctx, fv.comm_unique_id(), 1, 0)
+    stats = []
+    for i in range(5):
+        st = fv.SingleStats()
+        for j, (name, _) in enumerate(fv.SingleStats._fields_):
+            setattr(st, name, float(100 * i + j))
+        stats.append(st)
+    order = [3, 0, 4, 1, 2]
+    out = comm.allgather_stats(order, [stats[i] for i in order], 5)
+    assert [bytes(o) for o in out] == [bytes(s) for s in stats]
+    with pytest.raises(fv.FvadError):
+        comm.allgather_stats([0, 1], stats[:2], 5)      # three streams never arrive
+    comm.close()
+
+
+def test_bench_cfg4_one_rank_equals_two_rank_rehearsal():
+    # bench.py --config cfg4: 21 streams dealt round-robin; world 1 and a 2-rank gloo rehearsal on the one GPU
+    # (11 + 10 streams) must report the same plan-order aggregate
+    import json
+    import subprocess
+    import sys
+    base = [os.path.join(ROOT, "bench.py"), "--config", "cfg4", "--cfg4-seconds", "600", "--steps", "1", "--warmup", "0"]
+    one = subprocess.run([sys.executable] + base, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533"] + base + ["--gpus", "2", "--dist-backend", "gloo"],
+                         capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    b = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2
+    assert a["aggregate"]["tpr"] == b["aggregate"]["tpr"] and a["aggregate"]["ppv"] == b["aggregate"]["ppv"]
+    assert 0.5 < a["aggregate"]["tpr"] <= 1.0 and a["aggregate"]["n_streams"] == 21

@@ -142,5 +142,11 @@ def test_run_plan_end_to_end(pkg, fv, gpu_ctx, weights7, tmp_path):
         assert r["audacity"].count("\n") >= len(segs_ref)
         assert r["debug_info"][0].startswith("vr:") and r["debug_info"][0].endswith("s")
     assert "stream0" in text and "stream1" in text and "=> Aggregate stats" in text
+    # one context + one host thread per device entry, instances dealt round-robin: same report, same segments
+    # (two contexts on device 0 stand in for two GPUs)
+    text2, results2 = pkg.simulator.run_plan(str(tmp_path / "plan.json"), synth_seed=7, out=None, devices=[0, 0])
+    assert text2 == text
+    assert [r["segments"] for r in results2] == [r["segments"] for r in results]
+    assert all(bytes(a["stats"]) == bytes(b["stats"]) for a, b in zip(results, results2))
     outs = os.listdir(tmp_path / "out")
-    assert len(outs) == 1 and sorted(os.listdir(tmp_path / "out" / outs[0])) == ["report.txt", "stream0-audacity.txt", "stream1-audacity.txt"]
+    assert len(outs) >= 1 and sorted(os.listdir(tmp_path / "out" / outs[0])) == ["report.txt", "stream0-audacity.txt", "stream1-audacity.txt"]

@@ -25,7 +25,7 @@ def test_abi_exports_every_declared_symbol(fv):
     missing = [n for n in sorted(declared) if not hasattr(L, n)]
     assert not missing, f"declared in fvad.h but not exported: {missing}"
     assert declared == set(fv.SIGNATURES), (declared ^ set(fv.SIGNATURES))
-    assert L.fvad_abi_version() == 1
+    assert L.fvad_abi_version() == 2
     assert L.fvad_status_name(-8) == b"InvalidInputLength"
 
 
@@ -435,6 +435,59 @@ def test_gather_stats_two_ranks_gloo(tmp_path):
         procs.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for rank, p in enumerate(procs):
         out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, out.decode()
+        assert f"rank {rank} ok" in out.decode()
+
+
+_WORKER_CFG4 = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_package
+import torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(PORT), RANK=str(RANK), WORLD_SIZE=str(WORLD))
+dist.init_process_group("gloo")
+pkg = load_package()
+fv = pkg.binding
+n_streams = 21
+# every rank can build every stream's statistics (seeded); it contributes only its own
+rng = np.random.default_rng(5)
+cfg = {"ignore_shorter_than_sec": 0.7, "extrude_start": 5.0, "extrude_end": 10.0, "fill_gaps": 5.0}
+every = []
+for i in range(n_streams):
+    t = np.sort(rng.uniform(0, 7200, 80)).astype(np.float32)
+    ref = [(float(t[2 * k]), float(t[2 * k + 1])) for k in range(40)]
+    vad = [(a + float(rng.normal(0, 0.3)), b + float(rng.normal(0, 0.5))) for a, b in ref if rng.uniform() > 0.1]
+    every.append(fv.stats_from_segments(vad, ref, cfg))
+ids = pkg.shard.streams_for_rank(n_streams, RANK, WORLD)
+assert len(ids) == (3 if RANK < 5 else 2)                       # 3,3,3,3,3,2,2,2
+allst = pkg.shard.gather_stats(ids, [fv.single_stats_to_array(every[i]) for i in ids], n_streams, dist=dist)
+got = fv.stats_aggregate([fv.array_to_single_stats(a) for a in allst])
+want = fv.stats_aggregate(every)                                # the single-process aggregate, plan order
+assert bytes(got) == bytes(want), RANK
+assert all(np.array_equal(allst[i], fv.single_stats_to_array(every[i])) for i in range(n_streams))
+dist.barrier()
+dist.destroy_process_group()
+print("rank", RANK, "ok")
+"""
+
+
+def test_cfg4_uneven_21_stream_gather_equals_single_process_aggregate():
+    # BASELINE config 4's deal: 21 streams over 8 ranks = 3,3,3,3,3,2,2,2.  The gathered, plan-ordered statistics
+    # must aggregate to the same bytes as statistics.aggregate over all 21 in one process (statistics.zig:116-172:
+    # in-order f32 sums)
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 8
+    procs = []
+    for rank in range(world):
+        code = f"ROOT={ROOT!r}\nPORT={port}\nRANK={rank}\nWORLD={world}\n" + _WORKER_CFG4
+        procs.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for rank, p in enumerate(procs):
+        out, _ = p.communicate(timeout=300)
         assert p.returncode == 0, out.decode()
         assert f"rank {rank} ok" in out.decode()
 
