@@ -83,7 +83,7 @@ class Lane(C.Structure):
     _fields_ = [("pcm", c_float_p), ("n_samples", sz), ("state", vp), ("denoised", c_float_p),
                 ("band_sum", c_float_p), ("band_sum_capacity", sz),
                 ("chunk_rms", c_float_p), ("chunk_rms_capacity", sz),
-                ("fft_bins", c_float_p),
+                ("fft_bins", c_float_p), ("spectrogram", c_float_p), ("features", c_float_p),
                 ("n_chunks", sz), ("n_fft_frames", sz), ("first_frame_index", C.c_uint64)]
 
 
@@ -375,7 +375,7 @@ class Context:
         return g
 
     def engine_run(self, lanes_pcm, want_denoised=False, want_bins=False, states=None,
-                   max_chunks_per_launch=0, min_bin=11, max_bin=43):
+                   max_chunks_per_launch=0, min_bin=11, max_bin=43, want_taps=False):
         """lanes_pcm: list of float32 1-D arrays (host). Returns list of dicts."""
         n = len(lanes_pcm)
         arr = (Lane * n)()
@@ -388,7 +388,9 @@ class Context:
             rms = np.zeros(max(n_chunks, 1), np.float32)
             den = np.zeros(n_chunks * 24000, np.float32) if want_denoised else None
             bins = np.zeros((cap_frames, 513), np.float32) if want_bins else None
-            keep.append((x, band, rms, den, bins))
+            spec = np.zeros((n_chunks, 50, 161, 2), np.float32) if want_taps else None
+            feat = np.zeros((n_chunks, 54, 161), np.float32) if want_taps else None
+            keep.append((x, band, rms, den, bins, spec, feat))
             L = arr[i]
             L.pcm = fptr(x)
             L.n_samples = x.shape[0]
@@ -399,6 +401,8 @@ class Context:
             L.chunk_rms = fptr(rms)
             L.chunk_rms_capacity = rms.shape[0]
             L.fft_bins = fptr(bins) if bins is not None else None
+            L.spectrogram = fptr(spec) if spec is not None and spec.size else None
+            L.features = fptr(feat) if feat is not None and feat.size else None
         opts = EngineOpts()
         lib().fvad_engine_opts_default(C.byref(opts))
         opts.max_chunks_per_launch = max_chunks_per_launch
@@ -407,13 +411,15 @@ class Context:
         self._ck(lib().fvad_engine_run(self.h, arr, n, C.byref(opts)), "fvad_engine_run")
         out = []
         for i in range(n):
-            x, band, rms, den, bins = keep[i]
+            x, band, rms, den, bins, spec, feat = keep[i]
             nf = arr[i].n_fft_frames
             nc = arr[i].n_chunks
             out.append({"n_chunks": nc, "n_fft_frames": nf,
                         "first_frame_index": arr[i].first_frame_index,
                         "band_sum": band[:nf].copy(), "chunk_rms": rms[:nc].copy(),
-                        "denoised": den, "fft_bins": None if bins is None else bins[:nf].copy()})
+                        "denoised": den, "fft_bins": None if bins is None else bins[:nf].copy(),
+                        "spectrogram": None if spec is None else spec.view(np.complex64)[..., 0],
+                        "features": feat})
         return out
 
     def host_alloc(self, n_floats):

@@ -455,6 +455,8 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
         // fill one launch, lane-contiguous
         long n = 0;
         std::vector<size_t> touched;
+        struct Tap { size_t job, chunk0, count; long batch0; };
+        std::vector<Tap> taps;
         // pinned descriptor table: two slots, so the host can build the next launch while the GPU still
         // runs this one; a slot is free once its (tiny) upload has been consumed
         const int slot = ws.desc_slot;
@@ -470,6 +472,7 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
             LaneJob& lj = jobs[j];
             if (lj.n_chunks == 0) { ++j; c = 0; continue; }
             const size_t take = std::min<size_t>(lj.n_chunks - c, (size_t)(cap - n));
+            if (lj.h_spec || lj.h_feat) taps.push_back({j, c, take, n});
             for (size_t k = 0; k < take; ++k) {
                 ChunkDesc& d = hd[n + (long)k];
                 d.in = lj.d_in + (c + k) * (size_t)kChunk48;
@@ -495,6 +498,18 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
         time_begin(ctx, "stft320_logpow");
         fvad_launch_stft(dd, (int)n, ctx->tb, ws.feat, ws.spec, ctx->stream);
         time_end(ctx);
+        // parity taps: K1's own outputs (the buffers the network and K3 read), straight to the caller
+        for (const Tap& t : taps) {
+            const LaneJob& lj = jobs[t.job];
+            if (lj.h_spec)
+                FVAD_HIP(ctx, hipMemcpyAsync(lj.h_spec + t.chunk0 * (size_t)(kFramesPerChunk * kNBins * 2),
+                                             ws.spec + (size_t)t.batch0 * (kFramesPerChunk * kNBins * 2),
+                                             t.count * (size_t)(kFramesPerChunk * kNBins * 2) * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+            if (lj.h_feat)
+                FVAD_HIP(ctx, hipMemcpy2DAsync(lj.h_feat + t.chunk0 * (size_t)(kRowsPerChunk * kNBins), kNBins * sizeof(float),
+                                               ws.feat + (size_t)t.batch0 * (kRowsPerChunk * kFeatStride), kFeatStride * sizeof(float),
+                                               kNBins * sizeof(float), t.count * (size_t)kRowsPerChunk, hipMemcpyDeviceToHost, ctx->stream));
+        }
         const long n_pad = padded_batch(ctx, n);
         rc = run_nn(ctx, n_pad, kRowsPerChunk, kWarmupRows);
         if (rc) return rc;
@@ -1018,6 +1033,8 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
         j.d_den = den_base;
         j.n_chunks = L.n_chunks;
         j.d_rms = d_rms + rms_off[l];
+        j.h_spec = L.spectrogram;
+        j.h_feat = L.features;
         if (L.state) {
             j.carry[0] = L.state->carry[0]; j.carry[1] = L.state->carry[1]; j.cur = L.state->cur;
             if (n_rem[l]) FVAD_HIP(ctx, hipMemcpyAsync(den_base - n_rem[l], L.state->den_rem, n_rem[l] * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -159,6 +159,8 @@ struct LaneJob {
     LaneCarry* carry[2];
     int cur;             // index of the carry holding the current state
     float* d_rms;        // device, n_chunks
+    float* h_spec = nullptr; // host taps (parity / debug): [n_chunks][50][161][2], [n_chunks][54][161]
+    float* h_feat = nullptr;
 };
 int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, ChunkDesc* capture_descs = nullptr,
                ChunkDesc* capture_dev = nullptr);

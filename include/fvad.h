@@ -202,6 +202,10 @@ typedef struct {
     float *chunk_rms;        /* out: one f32 per chunk */
     size_t chunk_rms_capacity;
     float *fft_bins;         /* out, optional (parity/debug): [n_fft_frames][513] magnitudes */
+    float *spectrogram;      /* out, optional (parity/debug, host): [n_chunks][50][161] {r,i} -- NSNet2.calcSpectrogram's
+                                bins before the gain (NSNet2.zig:239-264) */
+    float *features;         /* out, optional (parity/debug, host): [n_chunks][54][161] -- the ONNX input rows: 4 warm-up
+                                rows (previous chunk's last 4, zeros at t = 0) + calcFeatures (NSNet2.zig:188-203,266-287) */
     /* filled by the call: */
     size_t n_chunks;         /* chunks consumed */
     size_t n_fft_frames;     /* band sums written */

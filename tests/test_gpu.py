@@ -583,13 +583,40 @@ def test_pipeline_segments_bit_identical(fv, gpu_ctx, weights7, pkg, n_channels,
     assert p.segments(alt=0) == segs            # default alt config == main machine
     thr_margin, ratio_margin, n = p.audit()
     assert n == band.shape[0]
-    # margin audit: no frame came within the GPU/CPU float difference of flipping a decision
+    # margin audit: no frame came within the GPU/CPU float difference of flipping a decision, neither
+    # `short_term > threshold` nor `channel_vol_ratio > 0.5` (VADMachine.zig:169-171; the tree-sum RMS moves the
+    # ratio by <= 2e-5)
     assert thr_margin > 1e-3, f"a frame sat {thr_margin:.2e} from the threshold"
+    assert ratio_margin > 1e-3, f"a frame sat {ratio_margin:.2e} from the channel-ratio threshold"
     if n_channels == 1:
         assert np.all(ratio == 1.0)             # min/max of a single channel
     # detected segments overlap the burst schedule
     for a, b in labels[:3]:
         assert any(s[0] / 48000 <= b and s[1] / 48000 >= a for s in segs)
+
+
+def test_pipeline_stereo_channel_ratio_near_threshold(fv, gpu_ctx, weights7, pkg):
+    # a stereo stream whose channel RMS ratio sits just above 0.5 (channel 1 = 0.503 x channel 0 plus a little
+    # independent noise): the `channel_vol_ratio > 0.5` gate (VADMachine.zig:171) is the comparison a GPU RMS
+    # difference could flip.  Segments must still be bit-identical and the audit must show how close it came.
+    pcm, labels = pkg.synth.make_stream(60.0, seed=43, n_channels=1, peak=0.6)   # the half-level channel must still open the VAD
+    rng = np.random.default_rng(7)
+    ch1 = (np.float32(0.503) * pcm[0] + rng.normal(0, 2e-4, pcm.shape[1]).astype(np.float32)).astype(np.float32)
+    st = np.stack([pcm[0], ch1])
+    ref = orc.Pipeline(weights7, n_channels=2)
+    ref.push(st)
+    p = fv.AudioPipeline(gpu_ctx, n_channels=2)
+    p.push_samples(st)
+    band, ratio = p.trace()
+    assert_rel(ratio, ref.frame_vol_ratio(), 1e-4, what="volume ratio near 0.5")
+    assert 0.5 < ratio.min() and ratio.max() < 0.51
+    segs, segs_ref = p.segments(), ref.segments()
+    assert len(segs_ref) >= 2 and [(s[0], s[1]) for s in segs] == [(s[0], s[1]) for s in segs_ref]
+    _, ratio_margin, _ = p.audit()
+    # the closest frame is further from 0.5 than 10x the largest GPU/oracle ratio difference seen
+    worst = np.abs(ratio - ref.frame_vol_ratio()).max()
+    assert ratio_margin > 10 * worst, (ratio_margin, worst)
+    assert ratio_margin < 1e-2
 
 
 def test_pipeline_errors_and_skip_processing(fv, gpu_ctx):
@@ -698,3 +725,107 @@ def test_bench_cfg4_one_rank_equals_two_rank_rehearsal():
     assert a["n_gpus"] == 1 and b["n_gpus"] == 2
     assert a["aggregate"]["tpr"] == b["aggregate"]["tpr"] and a["aggregate"]["ppv"] == b["aggregate"]["ppv"]
     assert 0.5 < a["aggregate"]["tpr"] <= 1.0 and a["aggregate"]["n_streams"] == 21
+
+
+# ------------------------------------------------------------------ K1's own outputs (NSNet2.zig:239-287)
+def test_k1_spectrogram_and_features_taps_match_oracle(fv, gpu_ctx, weights7, pkg):
+    # fvad_lane.spectrogram / .features expose what stft_kernel hands to the network and to K3 -- not the
+    # separate batch-FFT kernel: 50 x 161 complex bins per chunk (calcSpectrogram) and the 54 x 161 ONNX input rows
+    # (4 warm-up rows + calcFeatures), through a state hand-over and for digital silence
+    pcm, _ = pkg.synth.make_stream(3.0, seed=77)
+    x = pcm[0][: 6 * 24000].copy()
+    x[3 * 24000: 4 * 24000] = 0.0                      # silent frames: features are log10(1e-12) = -12
+    st = gpu_ctx.lane_state()
+    outs = [gpu_ctx.engine_run([x[: 2 * 24000]], states=[st], want_taps=True)[0],
+            gpu_ctx.engine_run([x[2 * 24000:]], states=[st], want_taps=True, max_chunks_per_launch=3)[0]]
+    fv.lib().fvad_lane_state_destroy(st)
+    spec = np.concatenate([o["spectrogram"] for o in outs])
+    feat = np.concatenate([o["features"] for o in outs])
+    assert spec.shape == (6, 50, 161) and feat.shape == (6, 54, 161)
+    d = orc.Denoiser(weights7)
+    dec = x[::3]
+    for c in range(6):
+        rc, _ = d.denoise(x[24000 * c: 24000 * (c + 1)])
+        assert rc == 0
+        f_ref = d.features()
+        # pre-gain spectrogram of this chunk: audio_input = [last 160 decimated samples of the previous chunk | 8000]
+        ai = np.concatenate([dec[8000 * c - 160: 8000 * c] if c else np.zeros(160, np.float32), dec[8000 * c: 8000 * (c + 1)]])
+        s_ref = np.zeros((50, 161, 2), np.float32)
+        f50 = np.zeros((50, 161), np.float32)
+        orc.lib().orc_nsnet2_spec_features(orc.fptr(np.ascontiguousarray(ai)), s_ref.ctypes.data_as(C.POINTER(orc.Cpx)), orc.fptr(f50))
+        s_ref = s_ref.view(np.complex64)[..., 0]
+        assert np.array_equal(f50, f_ref[4:])                      # the oracle agrees with itself
+        if np.abs(s_ref).max() == 0:
+            assert np.all(spec[c] == 0) and np.abs(feat[c, 4:] + 12.0).max() <= 2e-6
+        else:
+            assert_bins_close(spec[c], s_ref, f"K1 spectrogram chunk {c}")
+            # log-power rows: 1e-4 absolute where the bin carries signal (the rule of assert_bins_close: a 1e-4
+            # relative amplitude error is 8.7e-5 in log10 power); bins that are round-off of the transform are
+            # compared as amplitudes (<= 2e-6 of the frame maximum), a log of noise is noise
+            amp = np.abs(s_ref.astype(np.complex128))
+            mx = amp.max(axis=1, keepdims=True)
+            big = (amp >= 1e-3 * mx) & (amp ** 2 > 1e-10)
+            assert np.abs(feat[c, 4:] - f_ref[4:])[big].max() <= 1e-4, f"features chunk {c}"
+            a_gpu, a_ref = 10.0 ** (feat[c, 4:].astype(np.float64) / 2), 10.0 ** (f_ref[4:].astype(np.float64) / 2)
+            assert (np.abs(a_gpu - a_ref) / np.maximum(mx, 1e-3)).max() <= 2e-6, f"feature amplitudes chunk {c}"
+            silent = (mx[:, 0] == 0)                               # frames of digital silence: log10(1e-12) to 1 ulp
+            assert np.abs(feat[c, 4:][silent] + 12.0).max(initial=0.0) <= 2e-6
+        if c == 0:
+            assert np.all(feat[0, :4] == 0.0)                      # literal zeros, not -12 (NSNet2.zig:77-79)
+        else:
+            assert np.array_equal(feat[c, :4], feat[c - 1, 50:])   # copyBackwards of the previous rows 50..53
+
+
+def _nsnet2_float64(w, f):
+    """The ONNX graph in float64 numpy: fc1 -> GRU x2 (gate order z,r,h; linear_before_reset = 1; zero initial
+    state) -> relu(fc2) -> relu(fc3) -> sigmoid(fc4)"""
+    W = {k: np.asarray(v, np.float64) for k, v in w.items()}
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))  # noqa: E731
+    x = f.astype(np.float64) @ W["fc1_w"].T + W["fc1_b"]
+
+    def gru(x, w_, r_, b_):
+        H = r_.shape[1]
+        wb, rb = b_[: 3 * H], b_[3 * H:]
+        h = np.zeros(H)
+        out = np.empty((x.shape[0], H))
+        for t in range(x.shape[0]):
+            gi = w_ @ x[t] + wb
+            gh = r_ @ h + rb
+            z = sig(gi[:H] + gh[:H])
+            r = sig(gi[H:2 * H] + gh[H:2 * H])
+            n = np.tanh(gi[2 * H:] + r * gh[2 * H:])
+            h = (1 - z) * n + z * h
+            out[t] = h
+        return out
+
+    x = gru(x, W["gru1_w"], W["gru1_r"], W["gru1_b"])
+    x = gru(x, W["gru2_w"], W["gru2_r"], W["gru2_b"])
+    x = np.maximum(x @ W["fc2_w"].T + W["fc2_b"], 0)
+    x = np.maximum(x @ W["fc3_w"].T + W["fc3_b"], 0)
+    return sig(x @ W["fc4_w"].T + W["fc4_b"])
+
+
+def test_gpu_against_float64_directly(fv, gpu_ctx, weights7):
+    # so that the GPU is not merely "as right as the oracle": the network and the FFT against float64 numpy.
+    # The oracle's own distance from float64 is the yardstick (both are f32 evaluations of the same maths).
+    rng = np.random.default_rng(21)
+    f = rng.uniform(-11, 2, (3, 54, 161)).astype(np.float32)
+    g64 = np.stack([_nsnet2_float64(weights7, s) for s in f])
+    g_gpu = gpu_ctx.nsnet2_forward(f)
+    g_orc = np.stack([orc.nsnet2_forward(weights7, s) for s in f])
+    e_gpu, e_orc = np.abs(g_gpu - g64).max(), np.abs(g_orc - g64).max()
+    assert e_gpu <= max(2 * e_orc, 2e-6), (e_gpu, e_orc)           # gains live in [0, 1]
+    # a large batch goes through the MFMA row-panel kernels and the multi-wave recurrence
+    fb = np.tile(f, (700, 1, 1))
+    gb = gpu_ctx.nsnet2_forward(fb)
+    assert np.abs(gb[-3:] - g64).max() <= max(2 * e_orc, 2e-6)
+    frames = rng.uniform(-1, 1, (64, 320)).astype(np.float32)
+    win = orc.nsnet2_window()
+    X64 = np.fft.rfft(frames.astype(np.float64) * win.astype(np.float64), axis=1)
+    ff = fv.FFT(gpu_ctx, 320, 16000)
+    Xg, Mg = ff.fft_batch(frames, win)
+    Xo = np.stack([orc.rfft(fr * win) for fr in frames])
+    scale = np.abs(X64).max(axis=1, keepdims=True)
+    eg, eo = (np.abs(Xg - X64) / scale).max(), (np.abs(Xo - X64) / scale).max()
+    assert eg <= max(2 * eo, 4e-7), (eg, eo)
+    assert (np.abs(Mg - np.abs(X64)) / scale).max() <= max(2 * eo, 6e-7)
