@@ -222,6 +222,7 @@ SIGNATURES = {
     "fvad_pipeline_alt_segments": (C.c_int, [vp, sz, C.POINTER(SpeechSegment), sz,
                                              C.POINTER(sz)]),
     "fvad_pipeline_audit": (C.c_int, [vp, C.POINTER(VadAudit)]),
+    "fvad_pipeline_enable_trace": (C.c_int, [vp, C.c_int]),
     "fvad_pipeline_n_fft_frames": (sz, [vp]),
     "fvad_pipeline_trace": (C.c_int, [vp, c_float_p, c_float_p, sz]),
     "fvad_segment_to_sec": (SegmentSec, [C.POINTER(SpeechSegment), sz]),
@@ -577,10 +578,11 @@ class AudioPipeline:
     """fvad_pipeline <-> reference src/AudioPipeline.zig"""
 
     def __init__(self, ctx, n_channels=1, sample_rate=48000, fft_size=1024, vad_overrides=None,
-                 alt_configs=None, skip_processing=False, record=False):
+                 alt_configs=None, skip_processing=False, record=False, trace=True, buffer_length=0):
         self.ctx = ctx
         cfg = PipelineConfig()
         lib().fvad_pipeline_config_default(C.byref(cfg))
+        cfg.buffer_length = buffer_length
         cfg.n_channels = n_channels
         cfg.sample_rate = sample_rate
         cfg.fft_size = fft_size
@@ -612,6 +614,8 @@ class AudioPipeline:
             cbs = C.byref(self._cbs)
         ctx._ck(lib().fvad_pipeline_create(ctx.h, C.byref(cfg), cbs, C.byref(self.h)),
                 "AudioPipeline.init")
+        if trace:   # per-frame band sums / ratios for parity tests (the library keeps none by default)
+            lib().fvad_pipeline_enable_trace(self.h, 1)
         self.n_channels = n_channels
 
     def push_samples(self, pcm):

@@ -240,16 +240,21 @@ struct fvad_pipeline {
     std::vector<std::unique_ptr<VadMachine>> alt;
     long min_bin = 0, max_bin = 0;
     // metadata carried between the stages (VADMetadata.zig)
-    std::vector<float> chunk_ratio;           // per chunk: volume_ratio after the denoiser stage
+    std::vector<float> chunk_ratio;           // per chunk from chunk_ratio_base on: volume_ratio after the denoiser stage
+    uint64_t chunk_ratio_base = 0;            // chunks before this one are no longer covered by any future frame
     uint64_t frames_done = 0;                 // FFT frames handed to the state machine so far
-    // traces
+    // traces (parity tests; off unless fvad_pipeline_enable_trace: a live pipeline must not grow without bound)
+    bool keep_trace = false;
     std::vector<float> trace_band, trace_ratio;
-    // recorder (only when callbacks were given): processed original + denoised audio from
-    // hist_base on, and the state MRBRecorder/Recorder keep (MRBRecorder.zig:76-118)
+    // recorders (only when callbacks were given), [0] over the original audio, [1] over the denoised audio
+    // (AudioPipeline.zig:30-33): every WRITTEN original sample / every denoised sample from hist_base on, and
+    // the state MRBRecorder + Recorder keep (MRBRecorder.zig:26-36, Recorder.zig:12-17)
     std::vector<std::vector<float>> hist_orig, hist_den;
     uint64_t hist_base = 0;
-    bool rec_active = false;
-    uint64_t rec_from = 0;
+    struct Rec {
+        bool recording = false; uint64_t start = 0;   // Recorder.status / startIndex
+        bool has_end = false; uint64_t end = 0;       // MRBRecorder.end_recording_on_sample
+    } rec[2];
     std::vector<std::vector<float>> den_host; // per-channel D2H landing buffers
     // scratch
     std::vector<std::vector<float>> band, rms;
@@ -257,8 +262,8 @@ struct fvad_pipeline {
 
 // BufferedFFT.write's metadata for frame k (BufferedFFT.zig:137-140,153): weighted mean of the
 // chunk ratios over the chunks whose samples the 1024-sample window covers, accumulated in f32 in
-// chunk order exactly like VADMetadata.push / toResult.
-static MetaResult frame_metadata(const std::vector<float>& chunk_ratio, uint64_t frame, size_t fft_size, size_t chunk_size)
+// chunk order exactly like VADMetadata.push / toResult.  chunk_ratio[0] belongs to chunk `base`.
+static MetaResult frame_metadata(const std::vector<float>& chunk_ratio, uint64_t base, uint64_t frame, size_t fft_size, size_t chunk_size)
 {
     Metadata m;
     const uint64_t from = frame * fft_size, to = from + fft_size;
@@ -267,7 +272,7 @@ static MetaResult frame_metadata(const std::vector<float>& chunk_ratio, uint64_t
         const uint64_t hi = std::min<uint64_t>(to, (c + 1) * chunk_size);
         MetaResult r;
         r.has_ratio = true;
-        r.volume_ratio = chunk_ratio[(size_t)c];
+        r.volume_ratio = chunk_ratio[(size_t)(c - base)];
         m.push(r, (float)(hi - lo)); // weight = n_written, an integer -> @floatFromInt
     }
     return m.to_result();
@@ -289,31 +294,52 @@ static size_t best_channel(const std::vector<std::vector<float>>& hist, size_t o
     return best;
 }
 
-// pipeline.endRecording(to, keep = true): AudioPipeline.zig:187-191 -> MRBRecorder.stopRecording
-// (:88-118) -> Recorder.finalize / segmentToAudioBuffer (Recorder.zig:73-164).  The samples up to
-// `to` have always been processed by the time the state machine reports `completed` (the frame
-// that closes a segment starts at >= to), so both clips are cut immediately.
-static void emit_recordings(fvad_pipeline* p, uint64_t to)
+// MRBRecorder.maybeFinalizeRecording (MRBRecorder.zig:160-192): recorder `which` finalises once its buffer holds
+// the samples up to end_recording_on_sample (`available` = what has been written to that buffer at this point
+// of the reference's schedule) -> Recorder.finalize / segmentToAudioBuffer (Recorder.zig:73-164) -> callback.
+static void maybe_finalize_recording(fvad_pipeline* p, int which, uint64_t available)
 {
-    p->rec_active = false;
-    if (to < p->rec_from || p->rec_from < p->hist_base) return;
-    const size_t off = (size_t)(p->rec_from - p->hist_base);
-    const size_t len = (size_t)(to - p->rec_from);
-    if (off + len > p->hist_orig[0].size() || off + len > p->hist_den[0].size()) return;
-    const std::vector<std::vector<float>>* src[2] = {&p->hist_orig, &p->hist_den};
-    const fvad_recording_cb cbs[2] = {p->cb.on_original_recording, p->cb.on_denoised_recording};
-    for (int w = 0; w < 2; ++w) {
-        if (!cbs[w]) continue;
-        const size_t best = best_channel(*src[w], off, len);
-        const float* chan = (*src[w])[best].data() + off;
-        fvad_audio_buffer ab;
-        ab.channel_pcm = &chan;
-        ab.n_channels = 1;
-        ab.length = len;
-        ab.sample_rate = p->cfg.sample_rate;
-        ab.duration_seconds = (float)len / (float)p->cfg.sample_rate;
-        ab.global_start_frame_number = p->rec_from;
-        cbs[w](p->cb.ctx, &ab);
+    fvad_pipeline::Rec& r = p->rec[which];
+    if (!r.recording || !r.has_end || available < r.end) return;
+    r.has_end = false;
+    r.recording = false;
+    const fvad_recording_cb cb = which == 0 ? p->cb.on_original_recording : p->cb.on_denoised_recording;
+    const std::vector<std::vector<float>>& src = which == 0 ? p->hist_orig : p->hist_den;
+    if (!cb || r.end < r.start || r.start < p->hist_base) return; // (the history window covers every possible start)
+    const size_t off = (size_t)(r.start - p->hist_base);
+    const size_t len = (size_t)(r.end - r.start);
+    if (off + len > src[0].size()) return;
+    const size_t best = best_channel(src, off, len);
+    const float* chan = src[best].data() + off;
+    fvad_audio_buffer ab;
+    ab.channel_pcm = &chan;
+    ab.n_channels = 1;
+    ab.length = len;
+    ab.sample_rate = p->cfg.sample_rate;
+    ab.duration_seconds = (float)len / (float)p->cfg.sample_rate;
+    ab.global_start_frame_number = r.start;
+    cb(p->cb.ctx, &ab);
+}
+
+// VADPipeline.stateMachineStep's recorder calls (VADPipeline.zig:215-229 -> AudioPipeline.zig:181-191 ->
+// MRBRecorder.startRecording / stopRecording, MRBRecorder.zig:76-118), original recorder first
+static void recorder_event(fvad_pipeline* p, const fvad_vad_result& res, uint64_t avail_orig, uint64_t avail_den)
+{
+    for (int which = 0; which < 2; ++which) {
+        fvad_pipeline::Rec& r = p->rec[which];
+        if (res.recording_state == FVAD_REC_STARTED) {
+            r.has_end = false;            // "scheduled to stop ... but has been restarted": the pending clip is dropped
+            r.recording = true;
+            r.start = res.sample_number;
+        } else if (res.recording_state == FVAD_REC_COMPLETED) {
+            if (!r.recording || r.start > res.sample_number) continue; // error.NotRecording / EndIndexBeforeStart
+            r.has_end = true;
+            r.end = res.sample_number;
+            maybe_finalize_recording(p, which, which == 0 ? avail_orig : avail_den);
+        } else if (res.recording_state == FVAD_REC_ABORTED) {
+            r.has_end = false;
+            r.recording = false;
+        }
     }
 }
 
@@ -367,6 +393,16 @@ int fvad_pipeline_create(fvad_ctx* ctx, const fvad_pipeline_config* cfg, const f
         if (rc) { for (auto* t : p->states) fvad_lane_state_destroy(t); return rc; }
         p->states.push_back(s);
     }
+    // a zero-length channel_vol_ratio ring would divide by zero (RollingAverage.zig:36; same check as fvad_vad_create)
+    auto ratio_ring_ok = [&](const fvad_vad_config& vc) {
+        return (size_t)(((float)cfg->sample_rate / (float)cfg->fft_size) * vc.channel_vol_ratio_avg_sec) != 0;
+    };
+    bool rings_ok = ratio_ring_ok(cfg->vad_machine_config);
+    for (size_t i = 0; i < cfg->n_alt_vad_machine_configs; ++i) rings_ok = rings_ok && ratio_ring_ok(cfg->alt_vad_machine_configs[i]);
+    if (!rings_ok) {
+        for (auto* t : p->states) fvad_lane_state_destroy(t);
+        return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "channel_vol_ratio_avg_sec is shorter than one FFT frame");
+    }
     p->vad.reset(new VadMachine(cfg->vad_machine_config, cfg->sample_rate, cfg->n_channels, cfg->fft_size));
     for (size_t i = 0; i < cfg->n_alt_vad_machine_configs; ++i)
         p->alt.emplace_back(new VadMachine(cfg->alt_vad_machine_configs[i], cfg->sample_rate, cfg->n_channels, cfg->fft_size));
@@ -390,49 +426,55 @@ int fvad_pipeline_push_samples(fvad_pipeline* p, const float* const* channel_pcm
     fvad_ctx* ctx = p->ctx;
     const size_t C = p->cfg.n_channels;
     if (first_sample_index) *first_sample_index = p->total_write_count; // AudioPipeline.zig:119
-    for (size_t c = 0; c < C; ++c) {
+    for (size_t c = 0; c < C; ++c)
         if (n_samples && !channel_pcm[c]) return set_err(ctx, FVAD_ERR_CHANNEL_COUNT_MISMATCH, "missing channel");
-        p->pending[c].insert(p->pending[c].end(), channel_pcm[c], channel_pcm[c] + n_samples);
-    }
-    p->total_write_count += n_samples;
     if (p->cfg.skip_processing) { // AudioPipeline.zig:212: samples are written but never read
-        for (auto& v : p->pending) v.clear();
+        p->total_write_count += n_samples;
         return FVAD_OK;
     }
+    const uint64_t w0 = p->total_write_count;   // written before this push
+    const uint64_t d0 = p->pipeline_read_count; // processed (= denoised) before this push
+    for (size_t c = 0; c < C; ++c) p->pending[c].insert(p->pending[c].end(), channel_pcm[c], channel_pcm[c] + n_samples);
     // VADPipeline.collectInputStep (VADPipeline.zig:144-166): every complete chunk, in order -- here
     // all of them in one batched engine call
-    const size_t n_chunks = (size_t)((p->total_write_count - p->pipeline_read_count) / p->chunk_size);
-    if (n_chunks == 0) return FVAD_OK;
+    const size_t n_chunks = (size_t)((w0 + n_samples - d0) / p->chunk_size);
     std::vector<fvad_lane> lanes(C);
-    const size_t max_frames = (n_chunks * p->chunk_size + p->cfg.fft_size) / p->cfg.fft_size + 1;
-    for (size_t c = 0; c < C; ++c) {
-        p->band[c].resize(max_frames);
-        p->rms[c].resize(n_chunks);
-        fvad_lane& L = lanes[c];
-        memset(&L, 0, sizeof L);
-        L.pcm = p->pending[c].data();
-        L.n_samples = n_chunks * p->chunk_size;
-        L.state = p->states[c];
-        L.band_sum = p->band[c].data();
-        L.band_sum_capacity = max_frames;
-        L.chunk_rms = p->rms[c].data();
-        L.chunk_rms_capacity = n_chunks;
-        if (p->has_cb) {
-            p->den_host[c].resize(n_chunks * p->chunk_size);
-            L.denoised = p->den_host[c].data();
+    if (n_chunks) {
+        const size_t max_frames = (n_chunks * p->chunk_size + p->cfg.fft_size) / p->cfg.fft_size + 1;
+        for (size_t c = 0; c < C; ++c) {
+            p->band[c].resize(max_frames);
+            p->rms[c].resize(n_chunks);
+            fvad_lane& L = lanes[c];
+            memset(&L, 0, sizeof L);
+            L.pcm = p->pending[c].data();
+            L.n_samples = n_chunks * p->chunk_size;
+            L.state = p->states[c];
+            L.band_sum = p->band[c].data();
+            L.band_sum_capacity = max_frames;
+            L.chunk_rms = p->rms[c].data();
+            L.chunk_rms_capacity = n_chunks;
+            if (p->has_cb) {
+                p->den_host[c].resize(n_chunks * p->chunk_size);
+                L.denoised = p->den_host[c].data();
+            }
+        }
+        fvad_engine_opts opts;
+        fvad_engine_opts_default(&opts);
+        opts.min_bin = (int32_t)p->min_bin;
+        opts.max_bin = (int32_t)p->max_bin;
+        const int rc = fvad_engine_run(ctx, lanes.data(), C, &opts);
+        if (rc) { // nothing was consumed: the lane states only advance when the call succeeds
+            for (size_t c = 0; c < C; ++c) p->pending[c].resize(p->pending[c].size() - n_samples);
+            return rc;
         }
     }
-    fvad_engine_opts opts;
-    fvad_engine_opts_default(&opts);
-    opts.min_bin = (int32_t)p->min_bin;
-    opts.max_bin = (int32_t)p->max_bin;
-    const int rc = fvad_engine_run(ctx, lanes.data(), C, &opts);
-    if (rc) return rc;
-    p->pipeline_read_count += (uint64_t)n_chunks * p->chunk_size;
+    // ---- the push is accepted from here on
+    p->total_write_count = w0 + n_samples;
+    p->pipeline_read_count = d0 + (uint64_t)n_chunks * p->chunk_size;
     if (p->has_cb)
         for (size_t c = 0; c < C; ++c) {
-            p->hist_orig[c].insert(p->hist_orig[c].end(), p->pending[c].begin(), p->pending[c].begin() + (long)(n_chunks * p->chunk_size));
-            p->hist_den[c].insert(p->hist_den[c].end(), p->den_host[c].begin(), p->den_host[c].end());
+            p->hist_orig[c].insert(p->hist_orig[c].end(), channel_pcm[c], channel_pcm[c] + n_samples);
+            if (n_chunks) p->hist_den[c].insert(p->hist_den[c].end(), p->den_host[c].begin(), p->den_host[c].end());
         }
     for (auto& v : p->pending) v.erase(v.begin(), v.begin() + (long)(n_chunks * p->chunk_size));
 
@@ -448,40 +490,82 @@ int fvad_pipeline_push_samples(fvad_pipeline* p, const float* const* channel_pcm
         Metadata m2; m2.push(r1, (float)p->chunk_size);
         p->chunk_ratio.push_back(m2.to_result().volume_ratio);
     }
-    // the state machine, frame by frame (VADPipeline.stateMachineStep, VADPipeline.zig:209-237)
-    const size_t n_frames = lanes[0].n_fft_frames;
-    const uint64_t first_index = lanes[0].first_frame_index;
+
+    // ---- the state machine, frame by frame (VADPipeline.stateMachineStep, VADPipeline.zig:209-237), replayed
+    // on the reference's schedule: pushSamples writes <= capacity / 2 samples, runs the pipeline over every
+    // complete chunk, repeats, and ends with the first short write (AudioPipeline.zig:121-140).  The schedule
+    // matters to the recorders only: each looks for its pending end in front of every write to ITS buffer
+    // (recordBeforeMRBWrite: a write step for the original audio, a 0.5 s chunk for the denoised audio).
+    const size_t n_frames = n_chunks ? lanes[0].n_fft_frames : 0;
+    const uint64_t first_index = n_chunks ? lanes[0].first_frame_index : 0;
+    const size_t capacity = p->cfg.buffer_length ? p->cfg.buffer_length : p->cfg.sample_rate * 10; // AudioPipeline.zig:46
+    const size_t write_chunk = capacity / 2;
     std::vector<float> vols(C);
-    for (size_t k = 0; k < n_frames; ++k) {
+    size_t k = 0; // next frame of this push
+    auto run_frame = [&](uint64_t avail_orig, uint64_t avail_den) {
         for (size_t c = 0; c < C; ++c) vols[c] = p->band[c][k];
-        const MetaResult md = frame_metadata(p->chunk_ratio, p->frames_done + k, p->cfg.fft_size, p->chunk_size);
+        const MetaResult md = frame_metadata(p->chunk_ratio, p->chunk_ratio_base, p->frames_done + k, p->cfg.fft_size, p->chunk_size);
         const uint64_t index = first_index + (uint64_t)k * p->cfg.fft_size;
         const fvad_vad_result res = p->vad->run(index, vols.data(), md.has_ratio, md.volume_ratio);
-        if (p->has_cb) { // VADPipeline.zig:215-229
-            if (res.recording_state == FVAD_REC_STARTED) { p->rec_active = true; p->rec_from = res.sample_number; }
-            else if (res.recording_state == FVAD_REC_COMPLETED && p->rec_active) emit_recordings(p, res.sample_number);
-            else if (res.recording_state == FVAD_REC_ABORTED) p->rec_active = false;
-        }
+        if (p->has_cb && res.recording_state != FVAD_REC_NONE) recorder_event(p, res, avail_orig, avail_den);
         for (auto& a : p->alt) a->run(index, vols.data(), md.has_ratio, md.volume_ratio);
-        p->trace_band.insert(p->trace_band.end(), vols.begin(), vols.end());
-        p->trace_ratio.push_back(md.has_ratio ? md.volume_ratio : NAN);
+        if (p->keep_trace) {
+            p->trace_band.insert(p->trace_band.end(), vols.begin(), vols.end());
+            p->trace_ratio.push_back(md.has_ratio ? md.volume_ratio : NAN);
+        }
+        ++k;
+    };
+    uint64_t w = w0, d = d0;
+    size_t off = 0;
+    for (;;) {
+        const size_t step = std::min(write_chunk, n_samples - off);
+        if (p->has_cb) maybe_finalize_recording(p, 0, w);
+        w += step;
+        off += step;
+        while (d + p->chunk_size <= w) {
+            if (p->has_cb) maybe_finalize_recording(p, 1, d);
+            d += p->chunk_size;
+            // the frames this chunk completes: BufferedFFT emits a frame when its last sample has been denoised
+            while (k < n_frames && first_index + (uint64_t)(k + 1) * p->cfg.fft_size <= d) run_frame(w, d);
+        }
+        if (step < write_chunk) break;
     }
+    while (k < n_frames) run_frame(w, d); // (none are left: every frame is completed by a chunk of this push)
     p->frames_done += n_frames;
+
+    // chunk ratios no future frame covers
+    {
+        const uint64_t next_frame_chunk = (p->frames_done * (uint64_t)p->cfg.fft_size) / p->chunk_size;
+        if (next_frame_chunk > p->chunk_ratio_base) {
+            const size_t drop = (size_t)std::min<uint64_t>(next_frame_chunk - p->chunk_ratio_base, p->chunk_ratio.size());
+            p->chunk_ratio.erase(p->chunk_ratio.begin(), p->chunk_ratio.begin() + (long)drop);
+            p->chunk_ratio_base += drop;
+        }
+    }
     if (p->has_cb) {
-        // keep what a future `started` can still reach back to: its start is at most the opening
-        // time (>= 0.2 s, i.e. ~11 frames) plus the 2 s margin before the next frame
-        const uint64_t next_index = first_index + (uint64_t)n_frames * p->cfg.fft_size;
-        uint64_t keep_from = next_index > 3 * p->cfg.sample_rate ? next_index - 3 * p->cfg.sample_rate : 0;
-        if (p->rec_active) keep_from = std::min(keep_from, p->rec_from);
+        // keep what a recording can still start at: a `started` carries getOffsetRecordingStart(speech start)
+        // = speech start - 2 s (VADMachine.zig:309-315); the earliest speech start still to come is the one of
+        // an opening in progress, else the next frame
+        const uint64_t next_index = p->frames_done * (uint64_t)p->cfg.fft_size;
+        uint64_t earliest = p->vad->state != VadMachine::CLOSED ? std::min(next_index, p->vad->speech_start_index) : next_index;
+        uint64_t keep_from = p->vad->offset_start(earliest);
+        for (const auto& r : p->rec) if (r.recording) keep_from = std::min(keep_from, r.start);
         if (keep_from > p->hist_base) {
             const size_t drop = (size_t)(keep_from - p->hist_base);
             for (size_t c = 0; c < C; ++c) {
-                p->hist_orig[c].erase(p->hist_orig[c].begin(), p->hist_orig[c].begin() + (long)drop);
-                p->hist_den[c].erase(p->hist_den[c].begin(), p->hist_den[c].begin() + (long)drop);
+                p->hist_orig[c].erase(p->hist_orig[c].begin(), p->hist_orig[c].begin() + (long)std::min(drop, p->hist_orig[c].size()));
+                p->hist_den[c].erase(p->hist_den[c].begin(), p->hist_den[c].begin() + (long)std::min(drop, p->hist_den[c].size()));
             }
             p->hist_base = keep_from;
         }
     }
+    return FVAD_OK;
+}
+
+int fvad_pipeline_enable_trace(fvad_pipeline* p, int on)
+{
+    if (!p) return FVAD_ERR_INVALID_ARGUMENT;
+    p->keep_trace = on != 0;
     return FVAD_OK;
 }
 
@@ -520,7 +604,7 @@ size_t fvad_pipeline_n_fft_frames(const fvad_pipeline* p) { return p ? (size_t)p
 int fvad_pipeline_trace(const fvad_pipeline* p, float* band_volumes, float* vol_ratio, size_t cap_frames)
 {
     if (!p) return FVAD_ERR_INVALID_ARGUMENT;
-    if (cap_frames < p->frames_done) return FVAD_ERR_BUFFER_TOO_SMALL;
+    if (cap_frames * p->cfg.n_channels < p->trace_band.size() || cap_frames < p->trace_ratio.size()) return FVAD_ERR_BUFFER_TOO_SMALL;
     if (band_volumes && !p->trace_band.empty()) memcpy(band_volumes, p->trace_band.data(), p->trace_band.size() * sizeof(float));
     if (vol_ratio && !p->trace_ratio.empty()) memcpy(vol_ratio, p->trace_ratio.data(), p->trace_ratio.size() * sizeof(float));
     return FVAD_OK;

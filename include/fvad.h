@@ -320,9 +320,12 @@ typedef struct fvad_audio_buffer {
     uint64_t global_start_frame_number;
 } fvad_audio_buffer;
 /* AudioPipeline.Callbacks (AudioPipeline.zig:14-18).  When callbacks are given, every segment the
- * state machine completes (VADPipeline.zig:215-229) produces one original-audio clip and then one
- * denoised-audio clip, in that order (AudioPipeline.zig:187-191); the denoised audio is then also
- * copied back from the GPU (1920 B per frame). */
+ * state machine completes (VADPipeline.zig:215-229) schedules one original-audio clip and one
+ * denoised-audio clip (AudioPipeline.zig:187-191); each is delivered as soon as its buffer holds the
+ * samples up to the clip's end -- at once, or during a later push -- and a recording that restarts
+ * before then replaces it, exactly like MRBRecorder.zig:76-118,160-192 on the reference's write schedule
+ * (pushes written in steps of buffer_length / 2, denoised audio in 0.5 s chunks).  The denoised audio is
+ * then also copied back from the GPU (1920 B per frame). */
 typedef void (*fvad_recording_cb)(void *ctx, const fvad_audio_buffer *recording);
 typedef struct {                              /* AudioPipeline.Callbacks, AudioPipeline.zig:14-18 */
     void *ctx;
@@ -358,7 +361,9 @@ int fvad_pipeline_segments(const fvad_pipeline *p, fvad_speech_segment *out, siz
 int fvad_pipeline_alt_segments(const fvad_pipeline *p, size_t alt_index,
                                fvad_speech_segment *out, size_t cap, size_t *n);
 int fvad_pipeline_audit(const fvad_pipeline *p, fvad_vad_audit *out);
-/* traces for parity tests: per-FFT-frame band sums [n][n_channels] and volume ratios [n] */
+/* traces for parity tests: per-FFT-frame band sums [n][n_channels] and volume ratios [n], kept for the frames
+ * processed while tracing is enabled (off by default: a live pipeline does not grow with the stream) */
+int fvad_pipeline_enable_trace(fvad_pipeline *p, int on);
 size_t fvad_pipeline_n_fft_frames(const fvad_pipeline *p);
 int fvad_pipeline_trace(const fvad_pipeline *p, float *band_volumes, float *vol_ratio,
                         size_t cap_frames);

@@ -198,6 +198,7 @@ typedef struct {
     int32_t fft_size;         /* VADPipeline.zig:21 */
     int32_t keep_denoised;    /* oracle-only: retain the denoised PCM that pushDenoisedSamples
                                  (VADPipeline.zig:183) hands back, for parity traces */
+    int32_t buffer_length;    /* AudioPipeline.Config.buffer_length (:24,46); 0 = sample_rate * 10 */
     orc_vad_config vad;
 } orc_pipeline_config;
 void orc_pipeline_config_default(orc_pipeline_config *c);
@@ -220,11 +221,13 @@ size_t orc_pipeline_n_chunks(const orc_pipeline *p);
 const float *orc_pipeline_denoised(const orc_pipeline *p, int channel); /* keep_denoised only */
 size_t orc_pipeline_n_denoised(const orc_pipeline *p);
 /* Recordings (MRBRecorder.zig:76-203 + Recorder.zig:60-164), kept only when keep_denoised: on a
- * `started` result recording begins at its sample_number, on `completed` the samples
- * [start, sample_number) of the quietest channel (Recorder.findBestChannel, :113-129) become one
- * mono clip -- once from the original audio, once from the denoised audio
- * (AudioPipeline.zig:181-191).  which: 0 = original, 1 = denoised. */
-size_t orc_pipeline_n_recordings(const orc_pipeline *p);
+ * `started` result both recorders begin at its sample_number (dropping an end that is still pending);
+ * on `completed` each recorder notes end_recording_on_sample and finalises as soon as ITS buffer holds
+ * the samples up to it -- at once, or in front of a later write (recordBeforeMRBWrite: before every
+ * <= capacity/2 write step of pushSamples for the original audio, before every 0.5 s chunk of
+ * pushDenoisedSamples for the denoised audio).  A clip is the quietest channel
+ * (Recorder.findBestChannel, :113-129) over [start, end).  which: 0 = original, 1 = denoised. */
+size_t orc_pipeline_n_recordings(const orc_pipeline *p, int which);
 const float *orc_pipeline_recording(const orc_pipeline *p, int which, size_t i, uint64_t *start,
                                     size_t *length, int *best_channel);
 /* full 513-bin magnitudes of BufferedFFT result `frame` (kept only when keep_denoised) */

@@ -156,11 +156,15 @@ struct orc_pipeline {
     float **denoised; size_t n_denoised, cap_denoised;
     float *all_bins; /* [frame][channel][n_bins] when keep_denoised */
     size_t cap_all_bins;
-    /* recorder (keep_denoised only) */
-    float **original; size_t n_original, cap_original; /* every processed original sample */
-    int rec_active; uint64_t rec_from;
-    struct { uint64_t start; size_t length; int best[2]; float *pcm[2]; } *recs;
-    size_t n_recs, cap_recs;
+    /* recorders (keep_denoised only): [0] over the original audio, [1] over the denoised audio
+     * (AudioPipeline.zig:30-33); MRBRecorder state = {recorder.status/startIndex, end_recording_on_sample} */
+    float **original; size_t n_original, cap_original; /* every WRITTEN original sample */
+    struct {
+        int recording; uint64_t start;
+        int has_end; uint64_t end;           /* MRBRecorder.end_recording_on_sample */
+        struct { uint64_t start; size_t length; int best; float *pcm; } *recs;
+        size_t n_recs, cap_recs;
+    } rec[2];
 };
 
 void orc_pipeline_config_default(orc_pipeline_config *c)
@@ -169,6 +173,7 @@ void orc_pipeline_config_default(orc_pipeline_config *c)
     c->n_channels = 1;
     c->fft_size = 1024; /* VADPipeline.zig:21 */
     c->keep_denoised = 0;
+    c->buffer_length = 0;
     orc_vad_config_default(&c->vad);
 }
 
@@ -228,8 +233,10 @@ void orc_pipeline_destroy(orc_pipeline *p)
         free(p->denoised[c]);
         free(p->original[c]);
     }
-    for (size_t i = 0; i < p->n_recs; ++i) { free(p->recs[i].pcm[0]); free(p->recs[i].pcm[1]); }
-    free(p->recs);
+    for (int which = 0; which < 2; ++which) {
+        for (size_t i = 0; i < p->rec[which].n_recs; ++i) free(p->rec[which].recs[i].pcm);
+        free(p->rec[which].recs);
+    }
     free(p->original);
     free(p->pending); free(p->denoisers); free(p->den_result); free(p->channel_bins);
     free(p->denoised);
@@ -254,28 +261,60 @@ static int find_best_channel(float *const *chan, int C, uint64_t from, size_t le
     return best;
 }
 
-/* pipeline.endRecording(to, keep = true) (VADPipeline.zig:220-223 -> AudioPipeline.zig:187-191 ->
- * MRBRecorder.stopRecording -> Recorder.finalize -> segmentToAudioBuffer) */
-static void finalize_recording(orc_pipeline *p, uint64_t to)
+/* samples recorder `which` can see: everything written to its ring buffer so far */
+static uint64_t rec_available(const orc_pipeline *p, int which)
 {
+    return which == 0 ? (uint64_t)p->n_original : (uint64_t)p->n_denoised;
+}
+
+/* MRBRecorder.maybeFinalizeRecording (MRBRecorder.zig:160-192): finalise once the samples up to
+ * end_recording_on_sample have arrived -> Recorder.finalize / segmentToAudioBuffer (Recorder.zig:73-164) */
+static void maybe_finalize_recording(orc_pipeline *p, int which)
+{
+    if (!p->rec[which].recording || !p->rec[which].has_end) return;
+    const uint64_t to = p->rec[which].end;
+    if (rec_available(p, which) < to) return;
+    p->rec[which].has_end = 0;
+    p->rec[which].recording = 0;
+    const uint64_t from = p->rec[which].start;
+    if (to < from) return; /* error.InvalidEndIndex */
     const int C = p->cfg.n_channels;
-    if (!p->rec_active || to < p->rec_from || to > p->n_original || to > p->n_denoised) abort();
-    if (p->n_recs == p->cap_recs) {
-        p->cap_recs = p->cap_recs ? p->cap_recs * 2 : 16;
-        p->recs = realloc(p->recs, sizeof(*p->recs) * p->cap_recs);
+    if (p->rec[which].n_recs == p->rec[which].cap_recs) {
+        p->rec[which].cap_recs = p->rec[which].cap_recs ? p->rec[which].cap_recs * 2 : 16;
+        p->rec[which].recs = realloc(p->rec[which].recs, sizeof(*p->rec[which].recs) * p->rec[which].cap_recs);
     }
-    const size_t len = (size_t)(to - p->rec_from);
-    float *const *src[2] = { p->original, p->denoised };
-    for (int w = 0; w < 2; ++w) {
-        const int best = find_best_channel(src[w], C, p->rec_from, len);
-        p->recs[p->n_recs].best[w] = best;
-        p->recs[p->n_recs].pcm[w] = (float *)malloc(sizeof(float) * (len ? len : 1));
-        memcpy(p->recs[p->n_recs].pcm[w], src[w][best] + p->rec_from, sizeof(float) * len);
+    const size_t len = (size_t)(to - from);
+    float *const *src = which == 0 ? p->original : p->denoised;
+    const int best = find_best_channel(src, C, from, len);
+    const size_t i = p->rec[which].n_recs++;
+    p->rec[which].recs[i].start = from;
+    p->rec[which].recs[i].length = len;
+    p->rec[which].recs[i].best = best;
+    p->rec[which].recs[i].pcm = (float *)malloc(sizeof(float) * (len ? len : 1));
+    memcpy(p->rec[which].recs[i].pcm, src[best] + from, sizeof(float) * len);
+}
+
+/* MRBRecorder.startRecording (MRBRecorder.zig:76-86): a pending end is dropped ("has been restarted") */
+static void start_recording(orc_pipeline *p, int which, uint64_t from)
+{
+    p->rec[which].has_end = 0;
+    p->rec[which].recording = 1; /* Recorder.start, Recorder.zig:54-60 */
+    p->rec[which].start = from;
+}
+
+/* MRBRecorder.stopRecording (MRBRecorder.zig:88-118) */
+static void stop_recording(orc_pipeline *p, int which, uint64_t to, int keep)
+{
+    if (!p->rec[which].recording) return; /* error.NotRecording */
+    if (keep) {
+        if (p->rec[which].start > to) return; /* error.EndIndexBeforeStart */
+        p->rec[which].has_end = 1;
+        p->rec[which].end = to;
+        maybe_finalize_recording(p, which);
+    } else {
+        p->rec[which].has_end = 0;
+        p->rec[which].recording = 0;
     }
-    p->recs[p->n_recs].start = p->rec_from;
-    p->recs[p->n_recs].length = len;
-    p->n_recs++;
-    p->rec_active = 0;
 }
 
 /* VADPipeline.stateMachineStep (VADPipeline.zig:209-237) + VADMachine.run's first step,
@@ -306,10 +345,12 @@ static void state_machine_step(orc_pipeline *p, uint64_t index, const orc_meta_r
     p->n_frames++;
     const orc_vad_result r =
         orc_vad_run(p->vad, index, p->temp_channel_volumes, meta->has_ratio, meta->volume_ratio);
-    if (p->cfg.keep_denoised) { /* VADPipeline.zig:215-229 */
-        if (r.recording_state == ORC_REC_STARTED) { p->rec_active = 1; p->rec_from = r.sample_number; }
-        else if (r.recording_state == ORC_REC_COMPLETED) finalize_recording(p, r.sample_number);
-        else if (r.recording_state == ORC_REC_ABORTED) p->rec_active = 0;
+    if (p->cfg.keep_denoised) { /* VADPipeline.zig:215-229 -> AudioPipeline.zig:181-191: original, then denoised */
+        for (int which = 0; which < 2; ++which) {
+            if (r.recording_state == ORC_REC_STARTED) start_recording(p, which, r.sample_number);
+            else if (r.recording_state == ORC_REC_COMPLETED) stop_recording(p, which, r.sample_number, 1);
+            else if (r.recording_state == ORC_REC_ABORTED) stop_recording(p, which, r.sample_number, 0);
+        }
     }
 }
 
@@ -404,16 +445,10 @@ static void process_chunk(orc_pipeline *p, float *const *chunk, uint64_t from)
         sw_reset(&p->den_buffer, from + n_written);               /* :97-100 defer */
         orc_meta_reset(&p->den_meta);
 
-        /* pipeline.pushDenoisedSamples (VADPipeline.zig:183) */
+        /* pipeline.pushDenoisedSamples (VADPipeline.zig:183 -> AudioPipeline.zig:145-166): the denoised
+         * recorder looks at its pending end BEFORE the new samples are written (recordBeforeMRBWrite) */
         if (p->cfg.keep_denoised) {
-            if (p->n_original + n > p->cap_original) {
-                p->cap_original = (p->n_original + n) * 2;
-                for (int c = 0; c < C; ++c)
-                    p->original[c] = (float *)realloc(p->original[c], sizeof(float) * p->cap_original);
-            }
-            for (int c = 0; c < C; ++c)
-                memcpy(p->original[c] + p->n_original, p->den_buffer.chan[c], sizeof(float) * n);
-            p->n_original += n;
+            maybe_finalize_recording(p, 1);
             if (p->n_denoised + n > p->cap_denoised) {
                 p->cap_denoised = (p->n_denoised + n) * 2;
                 for (int c = 0; c < C; ++c)
@@ -435,35 +470,54 @@ uint64_t orc_pipeline_push_samples(orc_pipeline *p, const float *const *channel_
 {
     const int C = p->cfg.n_channels;
     const uint64_t first_sample_index = p->total_write_count; /* AudioPipeline.zig:119 */
-    /* AudioPipeline.zig:124-140 writes <= capacity/2 samples then runs the pipeline; the pipeline
-     * drains every complete chunk each time, so the chunk sequence is independent of the write
-     * granularity and the FIFO may take the whole push at once. */
-    if (p->n_pending + n > p->cap_pending) {
-        p->cap_pending = (p->n_pending + n) * 2 + p->chunk_size;
-        for (int c = 0; c < C; ++c)
-            p->pending[c] = (float *)realloc(p->pending[c], sizeof(float) * p->cap_pending);
-    }
-    for (int c = 0; c < C; ++c)
-        memcpy(p->pending[c] + p->n_pending, channel_pcm[c], sizeof(float) * n);
-    p->n_pending += n;
-    p->total_write_count += n;
-
-    /* VADPipeline.collectInputStep, VADPipeline.zig:144-166 */
-    size_t consumed = 0;
+    /* AudioPipeline.zig:121-140: write at most capacity / 2 samples, run the pipeline, repeat; the loop ends
+     * with the first short write (so a push of an exact multiple makes one more, empty, round).  The chunk
+     * sequence does not depend on this granularity, the moment a recording is finalised does. */
+    const size_t capacity = p->cfg.buffer_length ? (size_t)p->cfg.buffer_length : (size_t)p->cfg.sample_rate * 10; /* :46 */
+    const size_t write_chunk_size = capacity / 2;
     float **view = (float **)malloc(sizeof(float *) * (size_t)C);
-    while (p->total_write_count - p->pipeline_read_count >= p->chunk_size) {
-        const uint64_t from = p->pipeline_read_count;
-        p->pipeline_read_count = from + p->chunk_size;
-        for (int c = 0; c < C; ++c) view[c] = p->pending[c] + consumed;
-        process_chunk(p, view, from);
-        consumed += p->chunk_size;
+    size_t read_offset = 0;
+    for (;;) {
+        const size_t step = (n - read_offset < write_chunk_size) ? n - read_offset : write_chunk_size;
+        if (p->cfg.keep_denoised) maybe_finalize_recording(p, 0); /* original_audio_recorder.recordBeforeMRBWrite */
+        if (p->n_pending + step > p->cap_pending) {
+            p->cap_pending = (p->n_pending + step) * 2 + p->chunk_size;
+            for (int c = 0; c < C; ++c)
+                p->pending[c] = (float *)realloc(p->pending[c], sizeof(float) * p->cap_pending);
+        }
+        for (int c = 0; c < C; ++c)
+            memcpy(p->pending[c] + p->n_pending, channel_pcm[c] + read_offset, sizeof(float) * step);
+        p->n_pending += step;
+        if (p->cfg.keep_denoised) {
+            if (p->n_original + step > p->cap_original) {
+                p->cap_original = (p->n_original + step) * 2;
+                for (int c = 0; c < C; ++c)
+                    p->original[c] = (float *)realloc(p->original[c], sizeof(float) * p->cap_original);
+            }
+            for (int c = 0; c < C; ++c)
+                memcpy(p->original[c] + p->n_original, channel_pcm[c] + read_offset, sizeof(float) * step);
+            p->n_original += step;
+        }
+        p->total_write_count += step;
+        read_offset += step;
+
+        /* maybeRunPipeline -> VADPipeline.collectInputStep, VADPipeline.zig:144-166 */
+        size_t consumed = 0;
+        while (p->total_write_count - p->pipeline_read_count >= p->chunk_size) {
+            const uint64_t from = p->pipeline_read_count;
+            p->pipeline_read_count = from + p->chunk_size;
+            for (int c = 0; c < C; ++c) view[c] = p->pending[c] + consumed;
+            process_chunk(p, view, from);
+            consumed += p->chunk_size;
+        }
+        if (consumed) {
+            for (int c = 0; c < C; ++c)
+                memmove(p->pending[c], p->pending[c] + consumed, sizeof(float) * (p->n_pending - consumed));
+            p->n_pending -= consumed;
+        }
+        if (step < write_chunk_size) break;
     }
     free(view);
-    if (consumed) {
-        for (int c = 0; c < C; ++c)
-            memmove(p->pending[c], p->pending[c] + consumed, sizeof(float) * (p->n_pending - consumed));
-        p->n_pending -= consumed;
-    }
     return first_sample_index;
 }
 
@@ -477,15 +531,16 @@ const float *orc_pipeline_chunk_rms(const orc_pipeline *p) { return p->chunk_rms
 size_t orc_pipeline_n_chunks(const orc_pipeline *p) { return p->n_chunks; }
 const float *orc_pipeline_denoised(const orc_pipeline *p, int channel) { return p->denoised[channel]; }
 size_t orc_pipeline_n_denoised(const orc_pipeline *p) { return p->n_denoised; }
-size_t orc_pipeline_n_recordings(const orc_pipeline *p) { return p->n_recs; }
+size_t orc_pipeline_n_recordings(const orc_pipeline *p, int which) { return p->rec[which ? 1 : 0].n_recs; }
 const float *orc_pipeline_recording(const orc_pipeline *p, int which, size_t i, uint64_t *start,
                                     size_t *length, int *best_channel)
 {
-    if (i >= p->n_recs) return NULL;
-    if (start) *start = p->recs[i].start;
-    if (length) *length = p->recs[i].length;
-    if (best_channel) *best_channel = p->recs[i].best[which ? 1 : 0];
-    return p->recs[i].pcm[which ? 1 : 0];
+    which = which ? 1 : 0;
+    if (i >= p->rec[which].n_recs) return NULL;
+    if (start) *start = p->rec[which].recs[i].start;
+    if (length) *length = p->rec[which].recs[i].length;
+    if (best_channel) *best_channel = p->rec[which].recs[i].best;
+    return p->rec[which].recs[i].pcm;
 }
 const float *orc_pipeline_fft_bins(const orc_pipeline *p, size_t frame, int channel)
 {

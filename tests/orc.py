@@ -84,7 +84,7 @@ class VadTrace(C.Structure):
 
 class PipelineConfig(C.Structure):
     _fields_ = [("sample_rate", C.c_int32), ("n_channels", C.c_int32), ("fft_size", C.c_int32),
-                ("keep_denoised", C.c_int32), ("vad", VadConfig)]
+                ("keep_denoised", C.c_int32), ("buffer_length", C.c_int32), ("vad", VadConfig)]
 
 
 class MetaResult(C.Structure):
@@ -194,7 +194,7 @@ def lib(native=False):
         "orc_pipeline_denoised": (c_float_p, [vp, C.c_int]),
         "orc_pipeline_n_denoised": (sz, [vp]),
         "orc_pipeline_fft_bins": (c_float_p, [vp, sz, C.c_int]),
-        "orc_pipeline_n_recordings": (sz, [vp]),
+        "orc_pipeline_n_recordings": (sz, [vp, C.c_int]),
         "orc_pipeline_recording": (c_float_p, [vp, C.c_int, sz, C.POINTER(C.c_uint64), C.POINTER(sz),
                                                C.POINTER(C.c_int)]),
         "orc_buffered_fft_frame": (None, [c_float_p, C.c_int, c_float_p]),
@@ -410,18 +410,21 @@ class Pipeline:
         return np.ctypeslib.as_array(lib().orc_pipeline_fft_bins(self.h, frame, channel),
                                      (nb,)).copy()
 
-    def recordings(self):
-        """[(start, best_channel_original, original clip, best_channel_denoised, denoised clip)]"""
+    def recordings_of(self, which):
+        """clips of one recorder (0 = original audio, 1 = denoised audio): [(start, best_channel, clip)]"""
         out = []
-        for i in range(lib().orc_pipeline_n_recordings(self.h)):
+        for i in range(lib().orc_pipeline_n_recordings(self.h, which)):
             start, length, best = C.c_uint64(), C.c_size_t(), C.c_int()
-            po = lib().orc_pipeline_recording(self.h, 0, i, C.byref(start), C.byref(length), C.byref(best))
-            orig = np.ctypeslib.as_array(po, (length.value,)).copy()
-            bo = best.value
-            pd = lib().orc_pipeline_recording(self.h, 1, i, None, None, C.byref(best))
-            den = np.ctypeslib.as_array(pd, (length.value,)).copy()
-            out.append((start.value, bo, orig, best.value, den))
+            p = lib().orc_pipeline_recording(self.h, which, i, C.byref(start), C.byref(length), C.byref(best))
+            out.append((start.value, best.value, np.ctypeslib.as_array(p, (length.value,)).copy()))
         return out
+
+    def recordings(self):
+        """[(start, best_channel_original, original clip, best_channel_denoised, denoised clip)] -- for configs
+        where both recorders keep every clip (the default: the end margin equals max_speech_gap_sec)"""
+        o, d = self.recordings_of(0), self.recordings_of(1)
+        assert len(o) == len(d) and all(a[0] == b[0] and len(a[2]) == len(b[2]) for a, b in zip(o, d))
+        return [(a[0], a[1], a[2], b[1], b[2]) for a, b in zip(o, d)]
 
     def vad_traces(self):
         n = lib().orc_pipeline_n_fft_frames(self.h)

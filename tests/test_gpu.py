@@ -829,3 +829,54 @@ def test_gpu_against_float64_directly(fv, gpu_ctx, weights7):
     eg, eo = (np.abs(Xg - X64) / scale).max(), (np.abs(Xo - X64) / scale).max()
     assert eg <= max(2 * eo, 4e-7), (eg, eo)
     assert (np.abs(Mg - np.abs(X64)) / scale).max() <= max(2 * eo, 6e-7)
+
+
+# ------------------------------------------------------------------ recorder schedule (MRBRecorder.zig)
+def _burst_stream(pkg, seconds, bursts, seed):
+    """noise floor + harmonic bursts at the given (from, to) seconds"""
+    pcm, _ = pkg.synth.make_stream(seconds, seed=seed, speech=False)
+    x = pcm[0].astype(np.float64)
+    t = np.arange(x.shape[0]) / 48000.0
+    for a, b in bursts:
+        i0, i1 = int(a * 48000), int(b * 48000)
+        tt = t[i0:i1] - t[i0]
+        sig = sum(np.sin(2 * np.pi * k * 150.0 * tt + 0.3 * k) for k in range(4, 9)) / 5.0
+        ramp = np.minimum(1.0, np.minimum(tt, tt[-1] - tt) / 0.02)
+        x[i0:i1] += 0.3 * sig * ramp
+    return np.clip(x, -1, 1).astype(np.float32)[None]
+
+
+@pytest.mark.parametrize("overrides,pushes", [
+    ({"max_speech_gap_sec": 0.5}, (48000,)),                           # the clip's end lies 1.5 s past the processed audio
+    ({"max_speech_gap_sec": 0.5}, (300000, 10**9)),                    # ... and write steps of capacity / 2 inside one push
+    ({"min_consecutive_sec_to_open": 1.0, "max_speech_gap_sec": 0.5}, (24000 * 3 + 17,)),  # starts 3 s before `started`
+    ({}, (7001,)),
+], ids=["gap0.5-1s-pushes", "gap0.5-big-pushes", "open1.0-gap0.5", "defaults-odd-pushes"])
+def test_pipeline_recorder_follows_mrb_schedule(fv, gpu_ctx, weights7, pkg, overrides, pushes):
+    # MRBRecorder keeps end_recording_on_sample and finalises when ITS buffer has the samples (original: before
+    # a later write step; denoised: before a later 0.5 s chunk); a `started` before that drops the pending clip
+    # (MRBRecorder.zig:76-118,160-192).  Bursts 1.1 s apart with max_speech_gap_sec = 0.5 produce exactly that.
+    bursts = [(2.0, 4.0), (5.1, 7.0), (8.1, 9.5), (14.0, 16.0), (21.0, 23.5), (24.6, 26.0)]
+    pcm = _burst_stream(pkg, 34.0, bursts, seed=91)
+    ref = orc.Pipeline(weights7, n_channels=1, keep_denoised=True, vad_overrides=overrides)
+    p = fv.AudioPipeline(gpu_ctx, n_channels=1, record=True, vad_overrides=overrides)
+    pos, i = 0, 0
+    while pos < pcm.shape[1]:
+        nxt = min(pcm.shape[1], pos + pushes[min(i, len(pushes) - 1)])
+        ref.push(pcm[:, pos:nxt])
+        p.push_samples(pcm[:, pos:nxt])
+        pos, i = nxt, i + 1
+    segs = p.segments()
+    assert [(s[0], s[1]) for s in segs] == [(s[0], s[1]) for s in ref.segments()] and len(segs) >= 3
+    ro, rd = ref.recordings_of(0), ref.recordings_of(1)
+    go, gd = p.recordings["original"], p.recordings["denoised"]
+    assert [(a[0], len(a[2])) for a in ro] == [(g[0], len(g[1])) for g in go], "original clips"
+    assert [(a[0], len(a[2])) for a in rd] == [(g[0], len(g[1])) for g in gd], "denoised clips"
+    assert len(ro) >= 2 and len(rd) >= 2
+    for a, g in zip(ro, go):
+        assert np.array_equal(a[2], g[1])
+    for a, g in zip(rd, gd):
+        assert_audio(g[1], a[2], what="denoised clip")
+    if "max_speech_gap_sec" in overrides:
+        # a segment whose clip a restart replaced, or whose end the stream never reached
+        assert len(rd) < len(segs)
