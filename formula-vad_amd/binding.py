@@ -83,7 +83,8 @@ class Lane(C.Structure):
     _fields_ = [("pcm", c_float_p), ("n_samples", sz), ("state", vp), ("denoised", c_float_p),
                 ("band_sum", c_float_p), ("band_sum_capacity", sz),
                 ("chunk_rms", c_float_p), ("chunk_rms_capacity", sz),
-                ("fft_bins", c_float_p), ("spectrogram", c_float_p), ("features", c_float_p),
+                ("fft_bins", c_float_p), ("pcm_i16", C.POINTER(C.c_int16)), ("denoised_i16", C.POINTER(C.c_int16)),
+                ("spectrogram", c_float_p), ("features", c_float_p),
                 ("n_chunks", sz), ("n_fft_frames", sz), ("first_frame_index", C.c_uint64)]
 
 
@@ -185,6 +186,7 @@ SIGNATURES = {
     "fvad_engine_run": (C.c_int, [vp, C.POINTER(Lane), sz, C.POINTER(EngineOpts)]),
     "fvad_engine_enqueue_device": (C.c_int, [vp, vp, sz, sz, sz, vp, vp, vp,
                                              C.POINTER(EngineOpts)]),
+    "fvad_engine_enqueue_device_i16": (C.c_int, [vp, vp, sz, sz, sz, vp, vp, vp, C.POINTER(EngineOpts)]),
     "fvad_nsnet2_forward": (C.c_int, [vp, c_float_p, sz, sz, c_float_p]),
     "fvad_ctx_enable_timing": (C.c_int, [vp, C.c_int]),
     "fvad_ctx_kernel_times": (C.c_int, [vp, C.POINTER(C.c_char_p), c_float_p, sz,
@@ -239,6 +241,9 @@ SIGNATURES = {
     "fvad_wav_read": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(c_float_p)), C.POINTER(sz),
                                 C.POINTER(sz), C.POINTER(sz)]),
     "fvad_wav_free": (None, [C.POINTER(c_float_p), sz]),
+    "fvad_wav_read_i16": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.POINTER(C.c_int16))), C.POINTER(sz),
+                                    C.POINTER(sz), C.POINTER(sz)]),
+    "fvad_wav_free_i16": (None, [C.POINTER(C.POINTER(C.c_int16)), sz]),
 }
 
 _lib = None
@@ -376,13 +381,13 @@ class Context:
         return g
 
     def engine_run(self, lanes_pcm, want_denoised=False, want_bins=False, states=None,
-                   max_chunks_per_launch=0, min_bin=11, max_bin=43, want_taps=False):
-        """lanes_pcm: list of float32 1-D arrays (host). Returns list of dicts."""
+                   max_chunks_per_launch=0, min_bin=11, max_bin=43, want_taps=False, want_denoised_i16=False):
+        """lanes_pcm: list of 1-D host arrays, float32 or int16 (PCM16: converted on the GPU). Returns list of dicts."""
         n = len(lanes_pcm)
         arr = (Lane * n)()
         keep = []
         for i, x in enumerate(lanes_pcm):
-            x = np.ascontiguousarray(x, dtype=np.float32)
+            x = np.ascontiguousarray(x) if np.asarray(x).dtype == np.int16 else np.ascontiguousarray(x, dtype=np.float32)
             n_chunks = x.shape[0] // 24000
             cap_frames = (n_chunks * 24000 + 1024) // 1024 + 1
             band = np.zeros(cap_frames, np.float32)
@@ -391,9 +396,15 @@ class Context:
             bins = np.zeros((cap_frames, 513), np.float32) if want_bins else None
             spec = np.zeros((n_chunks, 50, 161, 2), np.float32) if want_taps else None
             feat = np.zeros((n_chunks, 54, 161), np.float32) if want_taps else None
-            keep.append((x, band, rms, den, bins, spec, feat))
+            den16 = np.zeros(n_chunks * 24000, np.int16) if want_denoised_i16 else None
+            keep.append((x, band, rms, den, bins, spec, feat, den16))
             L = arr[i]
-            L.pcm = fptr(x)
+            if x.dtype == np.int16:
+                L.pcm = None
+                L.pcm_i16 = x.ctypes.data_as(C.POINTER(C.c_int16))
+            else:
+                L.pcm = fptr(x)
+            L.denoised_i16 = den16.ctypes.data_as(C.POINTER(C.c_int16)) if den16 is not None and den16.size else None
             L.n_samples = x.shape[0]
             L.state = states[i] if states else None
             L.denoised = fptr(den) if den is not None and den.size else None
@@ -412,7 +423,7 @@ class Context:
         self._ck(lib().fvad_engine_run(self.h, arr, n, C.byref(opts)), "fvad_engine_run")
         out = []
         for i in range(n):
-            x, band, rms, den, bins, spec, feat = keep[i]
+            x, band, rms, den, bins, spec, feat, den16 = keep[i]
             nf = arr[i].n_fft_frames
             nc = arr[i].n_chunks
             out.append({"n_chunks": nc, "n_fft_frames": nf,
@@ -420,7 +431,7 @@ class Context:
                         "band_sum": band[:nf].copy(), "chunk_rms": rms[:nc].copy(),
                         "denoised": den, "fft_bins": None if bins is None else bins[:nf].copy(),
                         "spectrogram": None if spec is None else spec.view(np.complex64)[..., 0],
-                        "features": feat})
+                        "features": feat, "denoised_i16": den16})
         return out
 
     def host_alloc(self, n_floats):
@@ -745,6 +756,19 @@ def wav_read(path):
         return out, sr.value
     finally:
         lib().fvad_wav_free(pcm, nc.value)
+
+
+def wav_read_i16(path):
+    """PCM16 WAV -> (pcm [n_channels][n_frames] int16, sample_rate) without conversion"""
+    pp = C.POINTER(C.POINTER(C.c_int16))()
+    nch, nfr, sr = sz(), sz(), sz()
+    check(lib().fvad_wav_read_i16(path.encode(), C.byref(pp), C.byref(nch), C.byref(nfr), C.byref(sr)), "fvad_wav_read_i16")
+    try:
+        out = np.stack([np.ctypeslib.as_array(pp[c], shape=(nfr.value,)).copy() for c in range(nch.value)]) \
+            if nfr.value else np.zeros((nch.value, 0), np.int16)
+    finally:
+        lib().fvad_wav_free_i16(pp, nch.value)
+    return out, sr.value
 
 
 def parse_audacity(text):

@@ -475,8 +475,10 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
             if (lj.h_spec || lj.h_feat) taps.push_back({j, c, take, n});
             for (size_t k = 0; k < take; ++k) {
                 ChunkDesc& d = hd[n + (long)k];
-                d.in = lj.d_in + (c + k) * (size_t)kChunk48;
+                d.in = lj.d_in ? lj.d_in + (c + k) * (size_t)kChunk48 : nullptr;
+                d.in16 = lj.d_in16 ? lj.d_in16 + (c + k) * (size_t)kChunk48 : nullptr;
                 d.den = lj.d_den + (c + k) * (size_t)kChunk48;
+                d.den16 = lj.d_den16 ? lj.d_den16 + (c + k) * (size_t)kChunk48 : nullptr;
                 d.carry_in = lj.carry[lj.cur];
                 d.carry_out = lj.carry[lj.cur ^ 1];
                 d.first = (k == 0);
@@ -618,6 +620,7 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     Workspace& ws = ctx->ws;
     if (ws.in) hipFree(ws.in);
     if (ws.den) hipFree(ws.den);
+    if (ws.den16) hipFree(ws.den16);
     if (ws.band) hipFree(ws.band);
     if (ws.bins) hipFree(ws.bins);
     if (ws.carries) hipFree(ws.carries);
@@ -973,12 +976,14 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
     hipStream_t st = ctx->stream;
 
     // ---- sizes and staging layout (every lane region 64-float aligned)
-    size_t in_total = 0, den_total = 0, frames_total = 0, chunks_total = 0;
-    std::vector<size_t> in_off(n_lanes), den_off(n_lanes), band_off(n_lanes), rms_off(n_lanes), n_rem(n_lanes);
+    size_t in_total = 0, den_total = 0, den16_total = 0, frames_total = 0, chunks_total = 0;
+    std::vector<size_t> in_off(n_lanes), den_off(n_lanes), den16_off(n_lanes), band_off(n_lanes), rms_off(n_lanes), n_rem(n_lanes);
     bool want_bins = false;
     for (size_t l = 0; l < n_lanes; ++l) {
         fvad_lane& L = lanes[l];
-        if (!L.pcm && L.n_samples) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "lane without pcm");
+        if (!L.pcm && !L.pcm_i16 && L.n_samples) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "lane without pcm");
+        if (opts.on_device && ((uintptr_t)L.pcm_i16 | (uintptr_t)L.denoised_i16) % 16)
+            return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "device PCM16 buffers must be 16-byte aligned");
         L.n_chunks = L.n_samples / kChunk48;
         n_rem[l] = L.state ? L.state->n_rem : 0;
         const size_t n_den = n_rem[l] + L.n_chunks * kChunk48;
@@ -988,7 +993,10 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
             return set_err(ctx, FVAD_ERR_BUFFER_TOO_SMALL, "band_sum / chunk_rms capacity too small");
         if (L.fft_bins) want_bins = true;
         in_off[l] = in_total;
-        in_total += (L.n_chunks * kChunk48 + 63) / 64 * 64;
+        // staging slots are counted in floats; a PCM16 lane needs half of them
+        in_total += ((L.pcm ? L.n_chunks * kChunk48 : L.n_chunks * kChunk48 / 2) + 63) / 64 * 64;
+        den16_off[l] = den16_total;
+        if (L.denoised_i16 && !opts.on_device) den16_total += (L.n_chunks * kChunk48 / 2 + 63) / 64 * 64;
         den_off[l] = den_total;
         den_total += (kVadFft + L.n_chunks * kChunk48 + 63) / 64 * 64;
         band_off[l] = frames_total;
@@ -999,6 +1007,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
     int rc;
     if (!opts.on_device && (rc = grow(ctx, &ws.in, &ws.in_cap, in_total))) return rc;
     if ((rc = grow(ctx, &ws.den, &ws.den_cap, den_total))) return rc;
+    if (den16_total && (rc = grow(ctx, &ws.den16, &ws.den16_cap, den16_total))) return rc;
     if ((rc = grow(ctx, &ws.band, &ws.band_cap, frames_total + chunks_total + 64))) return rc;
     if (want_bins && (rc = grow(ctx, &ws.bins, &ws.bins_cap, frames_total * kVadBins))) return rc;
     // scratch carries for stateless lanes
@@ -1014,6 +1023,21 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
     }
     if (n_scratch) FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
 
+    // the host-side lane state (remainder length, current carry, counters) is committed only if the whole call
+    // succeeds: a caller that retries after an error must not feed the same audio to an advanced state
+    struct StateGuard {
+        struct Snap { fvad_lane_state* s; int cur; size_t n_rem; uint64_t consumed, next_index; };
+        std::vector<Snap> snaps;
+        bool commit = false;
+        ~StateGuard()
+        {
+            if (commit) return;
+            for (const Snap& x : snaps) { x.s->cur = x.cur; x.s->n_rem = x.n_rem; x.s->samples_consumed = x.consumed; x.s->next_frame_index = x.next_index; }
+        }
+    } guard;
+    for (size_t l = 0; l < n_lanes; ++l)
+        if (lanes[l].state) guard.snaps.push_back({lanes[l].state, lanes[l].state->cur, lanes[l].state->n_rem,
+                                                   lanes[l].state->samples_consumed, lanes[l].state->next_frame_index});
     float* d_rms = ws.band + frames_total;
     std::vector<LaneJob> jobs(n_lanes);
     std::vector<CopySeg> h2d;
@@ -1022,11 +1046,17 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
         fvad_lane& L = lanes[l];
         LaneJob& j = jobs[l];
         const size_t n_in = L.n_chunks * kChunk48;
-        if (opts.on_device) j.d_in = L.pcm;
-        else {
+        const bool pcm16 = !L.pcm;
+        if (opts.on_device) { j.d_in = L.pcm; j.d_in16 = pcm16 ? L.pcm_i16 : nullptr; }
+        else if (pcm16) {
+            if (n_in) h2d.push_back({(void*)L.pcm_i16, ws.in + in_off[l], n_in * sizeof(int16_t)});
+            j.d_in = nullptr;
+            j.d_in16 = reinterpret_cast<const int16_t*>(ws.in + in_off[l]);
+        } else {
             if (n_in) h2d.push_back({(void*)L.pcm, ws.in + in_off[l], n_in * sizeof(float)});
             j.d_in = ws.in + in_off[l];
         }
+        if (L.denoised_i16) j.d_den16 = opts.on_device ? L.denoised_i16 : reinterpret_cast<int16_t*>(ws.den16 + den16_off[l]);
         // denoised region: [1024-float prefix | chunks]; the not-yet-FFT'd remainder of the previous
         // call sits right in front of the new audio so that K4 sees one contiguous signal
         float* den_base = ws.den + den_off[l] + kVadFft;
@@ -1104,6 +1134,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
             if (L.n_chunks) {
                 d2h.push_back({L.chunk_rms, d_rms + rms_off[l], L.n_chunks * sizeof(float)});
                 if (L.denoised && !opts.on_device) d2h.push_back({L.denoised, jobs[l].d_den, L.n_chunks * kChunk48 * sizeof(float)});
+                if (L.denoised_i16 && !opts.on_device) d2h.push_back({L.denoised_i16, jobs[l].d_den16, L.n_chunks * kChunk48 * sizeof(int16_t)});
             }
         }
         return staged_copy(ctx, d2h, false, s_out);
@@ -1135,7 +1166,10 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
         std::vector<CopySeg> in_g;
         for (size_t l = l0; l < l1; ++l) {
             const size_t n_in = lanes[l].n_chunks * kChunk48;
-            if (!opts.on_device && n_in) in_g.push_back({(void*)lanes[l].pcm, ws.in + in_off[l], n_in * sizeof(float)});
+            if (!opts.on_device && n_in) {
+                if (lanes[l].pcm) in_g.push_back({(void*)lanes[l].pcm, ws.in + in_off[l], n_in * sizeof(float)});
+                else in_g.push_back({(void*)lanes[l].pcm_i16, ws.in + in_off[l], n_in * sizeof(int16_t)});
+            }
         }
         if ((rc = staged_copy(ctx, in_g, true, s_in))) return rc;
         if (G > 1) {
@@ -1181,18 +1215,22 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
     } else if ((rc = outputs_of(0, n_lanes))) return rc;
     FVAD_HIP(ctx, hipStreamSynchronize(st));
     FVAD_HIP(ctx, hipGetLastError());
+    guard.commit = true;
     return FVAD_OK;
 }
 
-int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes, size_t lane_stride, size_t n_samples,
-                               float* d_denoised, float* d_band_sum, float* d_chunk_rms, const fvad_engine_opts* opts_in)
+// device-resident batch: f32 or PCM16 input (exactly one of d_pcm / d_pcm16), optional PCM16 copy of the output
+static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t* d_pcm16, size_t n_lanes, size_t lane_stride,
+                               size_t n_samples, float* d_denoised, int16_t* d_den16, float* d_band_sum, float* d_chunk_rms,
+                               const fvad_engine_opts* opts_in)
 {
-    if (!ctx || !d_pcm || !d_band_sum || n_lanes == 0) return FVAD_ERR_INVALID_ARGUMENT;
+    if (!ctx || (!d_pcm && !d_pcm16) || !d_band_sum || n_lanes == 0) return FVAD_ERR_INVALID_ARGUMENT;
     fvad_engine_opts opts;
     if (opts_in) opts = *opts_in; else fvad_engine_opts_default(&opts);
     if (!ctx->dm.loaded) return set_err(ctx, FVAD_ERR_NO_MODEL, "NSNet2 weights not loaded");
-    if (lane_stride % 4) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "lane_stride must be a multiple of 4 floats");
-    if (((uintptr_t)d_pcm | (uintptr_t)d_denoised) % 16) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "device audio buffers must be 16-byte aligned");
+    if (lane_stride % (d_pcm ? 4 : 8)) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "lane_stride must be a multiple of 16 bytes");
+    if (((uintptr_t)d_pcm | (uintptr_t)d_pcm16 | (uintptr_t)d_denoised | (uintptr_t)d_den16) % 16)
+        return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "device audio buffers must be 16-byte aligned");
     hipSetDevice(ctx->device);
     Workspace& ws = ctx->ws;
     hipStream_t st = ctx->stream;
@@ -1234,8 +1272,10 @@ int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes
         if (!capture_descs) FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
         std::vector<LaneJob> jobs(n_lanes);
         for (size_t l = 0; l < n_lanes; ++l) {
-            jobs[l].d_in = d_pcm + l * lane_stride;
+            jobs[l].d_in = d_pcm ? d_pcm + l * lane_stride : nullptr;
+            jobs[l].d_in16 = d_pcm16 ? d_pcm16 + l * lane_stride : nullptr;
             jobs[l].d_den = den + l * n_den;
+            jobs[l].d_den16 = d_den16 ? d_den16 + l * n_den : nullptr;
             jobs[l].n_chunks = n_chunks;
             jobs[l].carry[0] = ws.carries + 2 * l;
             jobs[l].carry[1] = ws.carries + 2 * l + 1;
@@ -1263,7 +1303,8 @@ int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes
         if ((rc = ensure_workspace(ctx, std::min(total, maxc), kRowsPerChunk))) return rc; // no allocation while capturing
         if ((rc = ensure_gru_ws(ctx))) return rc;
         Workspace::GraphCache& gc = ws.graph;
-        const bool hit = gc.valid && gc.pcm == d_pcm && gc.den == den && gc.band == d_band_sum && gc.rms == d_chunk_rms &&
+        const void* pcm_key = d_pcm ? (const void*)d_pcm : (const void*)d_pcm16;
+        const bool hit = gc.valid && gc.pcm == pcm_key && gc.den16 == d_den16 && gc.den == den && gc.band == d_band_sum && gc.rms == d_chunk_rms &&
                          gc.n_lanes == n_lanes && gc.lane_stride == lane_stride && gc.n_samples == n_samples &&
                          gc.min_bin == opts.min_bin && gc.max_bin == opts.max_bin && gc.max_chunks == maxc &&
                          gc.generation == ws.generation;
@@ -1301,7 +1342,7 @@ int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes
             FVAD_HIP(ctx, hipMemcpy(gc.d_descs, gc.h_descs, (size_t)total * sizeof(ChunkDesc), hipMemcpyHostToDevice));
             FVAD_HIP(ctx, hipMemcpy(gc.d_jobs, gc.h_jobs, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice));
             FVAD_HIP(ctx, hipGraphInstantiate(&gc.exec, gc.graph, nullptr, nullptr, 0));
-            gc.pcm = d_pcm; gc.den = den; gc.band = d_band_sum; gc.rms = d_chunk_rms;
+            gc.pcm = pcm_key; gc.den16 = d_den16; gc.den = den; gc.band = d_band_sum; gc.rms = d_chunk_rms;
             gc.n_lanes = n_lanes; gc.lane_stride = lane_stride; gc.n_samples = n_samples;
             gc.min_bin = opts.min_bin; gc.max_bin = opts.max_bin; gc.max_chunks = maxc;
             gc.generation = ws.generation;
@@ -1318,6 +1359,20 @@ int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes
     FVAD_HIP(ctx, hipStreamSynchronize(st)); // the pinned job table is reused by the next call
     FVAD_HIP(ctx, hipGetLastError());
     return FVAD_OK;
+}
+
+int fvad_engine_enqueue_device(fvad_ctx* ctx, const float* d_pcm, size_t n_lanes, size_t lane_stride, size_t n_samples,
+                               float* d_denoised, float* d_band_sum, float* d_chunk_rms, const fvad_engine_opts* opts_in)
+{
+    if (!d_pcm) return FVAD_ERR_INVALID_ARGUMENT;
+    return enqueue_device_impl(ctx, d_pcm, nullptr, n_lanes, lane_stride, n_samples, d_denoised, nullptr, d_band_sum, d_chunk_rms, opts_in);
+}
+
+int fvad_engine_enqueue_device_i16(fvad_ctx* ctx, const int16_t* d_pcm16, size_t n_lanes, size_t lane_stride, size_t n_samples,
+                                   int16_t* d_denoised16, float* d_band_sum, float* d_chunk_rms, const fvad_engine_opts* opts_in)
+{
+    if (!d_pcm16) return FVAD_ERR_INVALID_ARGUMENT;
+    return enqueue_device_impl(ctx, nullptr, d_pcm16, n_lanes, lane_stride, n_samples, nullptr, d_denoised16, d_band_sum, d_chunk_rms, opts_in);
 }
 
 } // extern "C"

@@ -64,6 +64,7 @@ struct Workspace {
     // generic scratch (engine_run staging, denoised audio, band sums)
     float* in = nullptr;  size_t in_cap = 0;
     float* den = nullptr; size_t den_cap = 0;
+    float* den16 = nullptr; size_t den16_cap = 0; // PCM16 denoised staging (int16 pairs in float-sized slots)
     float* band = nullptr; size_t band_cap = 0;
     float* bins = nullptr; size_t bins_cap = 0;
     LaneCarry* carries = nullptr; size_t carries_cap = 0; // scratch carries (2 per lane)
@@ -80,7 +81,7 @@ struct Workspace {
     // call's arguments and the workspace are unchanged
     struct GraphCache {
         bool valid = false;
-        const void *pcm = nullptr, *den = nullptr, *band = nullptr, *rms = nullptr;
+        const void *pcm = nullptr, *den = nullptr, *band = nullptr, *rms = nullptr, *den16 = nullptr;
         size_t n_lanes = 0, lane_stride = 0, n_samples = 0;
         int min_bin = 0, max_bin = 0;
         long max_chunks = 0;
@@ -161,6 +162,8 @@ struct LaneJob {
     float* d_rms;        // device, n_chunks
     float* h_spec = nullptr; // host taps (parity / debug): [n_chunks][50][161][2], [n_chunks][54][161]
     float* h_feat = nullptr;
+    const int16_t* d_in16 = nullptr; // device, PCM16 input instead of d_in (16-bit transport)
+    int16_t* d_den16 = nullptr;      // device, optional PCM16 copy of the denoised audio
 };
 int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, ChunkDesc* capture_descs = nullptr,
                ChunkDesc* capture_dev = nullptr);

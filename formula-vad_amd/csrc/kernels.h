@@ -37,6 +37,12 @@ struct ChunkDesc {
     uint32_t first;     // first chunk of its lane in this launch -> history comes from carry_in
     uint32_t last;      // last chunk of its lane in this launch -> writes carry_out
     float* rms;         // where this chunk's RMS goes (device), or null
+    // 16-bit transport (optional): when in16 != null the chunk's samples are PCM16 and K1 converts them while
+    // loading, x = (float)s * (1 / 32768) -- the decode of AudioFileStream.zig:56-102 / host_io.cpp, exact in
+    // f32 -- so a 48 kHz stream crosses PCIe and HBM at 2 bytes per sample; den16 != null: K3 also writes the
+    // denoised chunk as PCM16, rint(clamp(y * 32768, -32768, 32767))
+    const int16_t* in16;
+    int16_t* den16;
 };
 
 // one lane's worth of 1024-sample frames for K4

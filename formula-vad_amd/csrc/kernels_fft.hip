@@ -300,43 +300,62 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
     float ss = 0.0f;
     {
         const int hist = d.first ? 0 : (kWarmupRows + 1) * kNHop * kDown; // 2400 raw samples
-        const float* src = d.in - hist;
-        const int n4 = (hist + kChunk48) / 4;
         const int dec0 = d.first ? (kWarmupRows + 1) * kNHop : 0;          // 800
-        const f32x4* src4 = reinterpret_cast<const f32x4*>(src);
-        // batches of 9 independent 16-byte loads per thread are issued before any is consumed, so the
-        // chunk's 96-105 KB stream in with ~37 KB per workgroup in flight instead of one L2/HBM round
-        // trip per loop iteration
+        auto take = [&](unsigned s, float x) { // sample s of [history | chunk]
+            const unsigned s3 = s / 3u;
+            if (s3 * 3u == s) dec[dec0 + s3] = x;
+            if ((int)s >= hist) ss += x * x;
+        };
+        // batches of 9 independent loads per thread are issued before any is consumed, so the chunk's
+        // 96-105 KB stream in with ~37 KB per workgroup in flight instead of one L2/HBM round trip per loop
+        // iteration.  PCM16 input takes the same path with 8-byte loads (4 samples), converted exactly like the
+        // host decode; the sample -> thread assignment, and with it the order of the RMS sum, is the same for
+        // both formats, so the two give bit-identical results.
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        const f32x4* src4 = reinterpret_cast<const f32x4*>(d.in - hist);
+        const s16x4* src16 = reinterpret_cast<const s16x4*>(d.in16 - hist);
+        const bool pcm16 = d.in16 != nullptr;
+        const int n4 = (hist + kChunk48) / 4;
         constexpr int LD_BATCH = 9;
         for (int base = 0; base < n4; base += LD_BATCH * K1_THREADS) {
             f32x4 v[LD_BATCH];
+            if (pcm16) {
+                s16x4 r[LD_BATCH];
 #pragma unroll
-            for (int b = 0; b < LD_BATCH; ++b) {
-                const int i4 = base + b * K1_THREADS + tid;
-                v[b] = (i4 < n4) ? src4[i4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int b = 0; b < LD_BATCH; ++b) {
+                    const int i4 = base + b * K1_THREADS + tid;
+                    r[b] = (i4 < n4) ? src16[i4] : (s16x4){0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int b = 0; b < LD_BATCH; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[b][e] = (float)r[b][e] * (1.0f / 32768.0f);
+            } else {
+#pragma unroll
+                for (int b = 0; b < LD_BATCH; ++b) {
+                    const int i4 = base + b * K1_THREADS + tid;
+                    v[b] = (i4 < n4) ? src4[i4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
             }
 #pragma unroll
             for (int b = 0; b < LD_BATCH; ++b) {
                 const int i4 = base + b * K1_THREADS + tid;
                 if (i4 < n4) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned s = 4u * i4 + e;
-                        const unsigned s3 = s / 3u;
-                        if (s3 * 3u == s) dec[dec0 + s3] = v[b][e];
-                        if ((int)s >= hist) ss += v[b][e] * v[b][e];
-                    }
+                    for (int e = 0; e < 4; ++e) take(4u * i4 + e, v[b][e]);
                 }
+            }
+        }
+        if (d.last) {
+            for (int j = tid; j < kNHop * kDown; j += K1_THREADS) {
+                const int i = kChunk48 - kNHop * kDown + j;
+                d.carry_out->in_tail[j] = pcm16 ? (float)d.in16[i] * (1.0f / 32768.0f) : d.in[i];
             }
         }
         if (d.first) {
             // audio_input[0..160) of the reference = decimated tail of the previous call
             const float* tail = d.carry_in->in_tail;
             for (int j = tid; j < kNHop; j += K1_THREADS) dec[dec0 - kNHop + j] = tail[kDown * j];
-        }
-        if (d.last) {
-            for (int j = tid; j < kNHop * kDown; j += K1_THREADS)
-                d.carry_out->in_tail[j] = d.in[kChunk48 - kNHop * kDown + j];
         }
     }
     ss = wave_sum(ss);
@@ -608,6 +627,14 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
         out4[3 * w] = o0;
         out4[3 * w + 1] = o1;
         out4[3 * w + 2] = o2;
+        if (d.den16) { // PCM16 copy of the same 12 samples: three 8-byte stores
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            auto q = [](float y) { return (short)__builtin_rintf(fminf(fmaxf(y * 32768.0f, -32768.0f), 32767.0f)); };
+            s16x4* o16 = reinterpret_cast<s16x4*>(d.den16) + 3 * w;
+            o16[0] = (s16x4){q(o0.x), q(o0.y), q(o0.z), q(o0.w)};
+            o16[1] = (s16x4){q(o1.x), q(o1.y), q(o1.z), q(o1.w)};
+            o16[2] = (s16x4){q(o2.x), q(o2.y), q(o2.z), q(o2.w)};
+        }
     }
 }
 

@@ -211,7 +211,10 @@ def run_plan(plan_path, ctx=None, synth_seed=None, out=sys.stdout, devices=None)
         ctxs = [ctx]
     audio, refs = [], []
     for inst in plan["instances"]:
-        pcm, sr = fv.wav_read(inst["audio_path"])
+        try:    # PCM16 files stay 16-bit all the way to the GPU (half the PCIe / HBM bytes; converted by the kernel
+            pcm, sr = fv.wav_read_i16(inst["audio_path"])   # that reads them, bit-identical to converting first)
+        except fv.FvadError:
+            pcm, sr = fv.wav_read(inst["audio_path"])
         if sr != 48000:
             raise fv.FvadError(-9, f"{inst['name']}: sample rate {sr}")   # VADPipeline.zig:55-58
         audio.append(pcm)

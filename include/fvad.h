@@ -193,7 +193,7 @@ void fvad_lane_state_reset(fvad_lane_state *s);
 void fvad_lane_state_destroy(fvad_lane_state *s);
 
 typedef struct {
-    const float *pcm;        /* n_samples f32 @48 kHz (host or device, see on_device) */
+    const float *pcm;        /* n_samples f32 @48 kHz (host or device, see on_device); NULL: use pcm_i16 */
     size_t n_samples;        /* only floor(n/24000) chunks are consumed */
     fvad_lane_state *state;  /* NULL = fresh stream (zero history), state not kept */
     float *denoised;         /* out, optional: n_chunks*24000 f32 (same memory space as pcm) */
@@ -202,6 +202,11 @@ typedef struct {
     float *chunk_rms;        /* out: one f32 per chunk */
     size_t chunk_rms_capacity;
     float *fft_bins;         /* out, optional (parity/debug): [n_fft_frames][513] magnitudes */
+    /* 16-bit transport: the reference decodes PCM16 files to f32 on the host (AudioFileStream.zig:56-102 through
+     * libsndfile: s / 32768); here the samples can cross PCIe and HBM as PCM16 and are converted by the kernel
+     * that reads them, bit-identical to converting first. */
+    const int16_t *pcm_i16;  /* used when pcm == NULL: n_samples PCM16 samples (same memory space as pcm would be) */
+    int16_t *denoised_i16;   /* out, optional: n_chunks*24000 samples, rint(clamp(y * 32768, -32768, 32767)) */
     float *spectrogram;      /* out, optional (parity/debug, host): [n_chunks][50][161] {r,i} -- NSNet2.calcSpectrogram's
                                 bins before the gain (NSNet2.zig:239-264) */
     float *features;         /* out, optional (parity/debug, host): [n_chunks][54][161] -- the ONNX input rows: 4 warm-up
@@ -233,6 +238,11 @@ int fvad_engine_enqueue_device(fvad_ctx *ctx, const float *d_pcm, size_t n_lanes
                                size_t lane_stride, size_t n_samples, float *d_denoised,
                                float *d_band_sum, float *d_chunk_rms,
                                const fvad_engine_opts *opts);
+/* The same with PCM16 device buffers in (and optionally out): half the HBM footprint and transport. */
+int fvad_engine_enqueue_device_i16(fvad_ctx *ctx, const int16_t *d_pcm16, size_t n_lanes,
+                                   size_t lane_stride, size_t n_samples, int16_t *d_denoised16,
+                                   float *d_band_sum, float *d_chunk_rms,
+                                   const fvad_engine_opts *opts);
 /* NSNet2 graph only: features [n_seq][T][161] -> gains [n_seq][T][161] (host pointers).
  * Replaces onnx_instance.run() (NSNet2.zig:220) for n_seq independent sequences. */
 int fvad_nsnet2_forward(fvad_ctx *ctx, const float *features, size_t n_seq, size_t T,
@@ -422,6 +432,11 @@ int fvad_parse_audacity(const char *txt, size_t len, fvad_segment_sec *out, size
 int fvad_wav_read(const char *path, float ***channel_pcm, size_t *n_channels, size_t *n_frames,
                   size_t *sample_rate);
 void fvad_wav_free(float **channel_pcm, size_t n_channels);
+/* The same for a PCM16 file without the conversion: channel-planar int16 for fvad_lane.pcm_i16
+ * (FVAD_ERR_MODEL_FORMAT if the file is not PCM16).  Free with fvad_wav_free_i16. */
+int fvad_wav_read_i16(const char *path, int16_t ***channel_pcm, size_t *n_channels, size_t *n_frames,
+                      size_t *sample_rate);
+void fvad_wav_free_i16(int16_t **channel_pcm, size_t n_channels);
 
 #ifdef __cplusplus
 }

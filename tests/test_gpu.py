@@ -880,3 +880,55 @@ def test_pipeline_recorder_follows_mrb_schedule(fv, gpu_ctx, weights7, pkg, over
     if "max_speech_gap_sec" in overrides:
         # a segment whose clip a restart replaced, or whose end the stream never reached
         assert len(rd) < len(segs)
+
+
+# ------------------------------------------------------------------ 16-bit transport
+def test_pcm16_input_equals_host_converted_f32(fv, gpu_ctx, pkg):
+    # fvad_lane.pcm_i16: the kernel that reads the samples converts them, x = s / 32768 (AudioFileStream.zig:56-102
+    # via libsndfile; host_io.cpp) -- every output must equal the f32 path on host-converted input bit for bit
+    rng = np.random.default_rng(12)
+    lanes16, lanes32 = [], []
+    for i, n in enumerate((24000 * 5 + 123, 24000, 24000 * 9)):
+        pcm, _ = pkg.synth.make_stream(n / 48000.0 + 0.01, seed=300 + i)
+        s16 = np.clip(np.rint(pcm[0][:n] * 32768.0), -32768, 32767).astype(np.int16)
+        s16[:8] = [-32768, 32767, 0, 1, -1, 12345, -12345, 7]
+        lanes16.append(s16)
+        lanes32.append((s16.astype(np.float32) * np.float32(1.0 / 32768.0)).astype(np.float32))
+    a = gpu_ctx.engine_run(lanes16, want_denoised=True, want_denoised_i16=True)
+    b = gpu_ctx.engine_run(lanes32, want_denoised=True)
+    for x, y in zip(a, b):
+        assert x["n_chunks"] == y["n_chunks"] >= 1
+        assert np.array_equal(x["denoised"], y["denoised"])
+        assert np.array_equal(x["band_sum"], y["band_sum"]) and np.array_equal(x["chunk_rms"], y["chunk_rms"])
+        q = np.rint(np.clip(x["denoised"].astype(np.float32) * np.float32(32768.0), -32768.0, 32767.0)).astype(np.int16)
+        assert np.array_equal(x["denoised_i16"], q)
+    # a stream handed over in pieces (lane state) and split over launches
+    st16, st32 = gpu_ctx.lane_state(), gpu_ctx.lane_state()
+    for lo, hi in ((0, 24000 * 2), (24000 * 2, 24000 * 9)):
+        u = gpu_ctx.engine_run([lanes16[2][lo:hi]], want_denoised=True, states=[st16], max_chunks_per_launch=3)[0]
+        v = gpu_ctx.engine_run([lanes32[2][lo:hi]], want_denoised=True, states=[st32])[0]
+        assert np.array_equal(u["denoised"], v["denoised"]) and np.array_equal(u["band_sum"], v["band_sum"])
+    fv.lib().fvad_lane_state_destroy(st16)
+    fv.lib().fvad_lane_state_destroy(st32)
+    # device-resident form
+    n = 24000 * 9
+    x16 = np.stack([lanes16[2], np.roll(lanes16[2], 4801)])
+    x32 = (x16.astype(np.float32) * np.float32(1.0 / 32768.0)).astype(np.float32)
+    d16, d32 = gpu_ctx.device_alloc(x16.nbytes), gpu_ctx.device_alloc(x32.nbytes)
+    dq = gpu_ctx.device_alloc(x16.nbytes)
+    dden = gpu_ctx.device_alloc(x32.nbytes)
+    db = [gpu_ctx.device_alloc(2 * (n // 1024) * 4) for _ in range(2)]
+    dr = [gpu_ctx.device_alloc(2 * 9 * 4) for _ in range(2)]
+    gpu_ctx.to_device(d16, x16)
+    gpu_ctx.to_device(d32, x32)
+    L = fv.lib()
+    fv.check(L.fvad_engine_enqueue_device_i16(gpu_ctx.h, d16, 2, n, n, dq, db[0], dr[0], None), "enqueue_i16", gpu_ctx.h)
+    gpu_ctx.enqueue_device(d32, 2, n, n, dden, db[1], dr[1])
+    bands = [gpu_ctx.to_host(np.empty((2, n // 1024), np.float32), d) for d in db]
+    rmss = [gpu_ctx.to_host(np.empty((2, 9), np.float32), d) for d in dr]
+    assert np.array_equal(bands[0], bands[1]) and np.array_equal(rmss[0], rmss[1])
+    q = gpu_ctx.to_host(np.empty((2, n), np.int16), dq)
+    den = gpu_ctx.to_host(np.empty((2, n), np.float32), dden)
+    assert np.array_equal(q, np.rint(np.clip(den * np.float32(32768.0), -32768.0, 32767.0)).astype(np.int16))
+    for d in [d16, d32, dq, dden] + db + dr:
+        gpu_ctx.device_free(d)

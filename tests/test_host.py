@@ -492,6 +492,29 @@ def test_cfg4_uneven_21_stream_gather_equals_single_process_aggregate():
         assert f"rank {rank} ok" in out.decode()
 
 
+def test_wav_read_i16_keeps_the_samples(fv, tmp_path):
+    # the 16-bit transport's file side: PCM16 samples come back untouched and planar, and decode to what
+    # fvad_wav_read returns; a float file is refused
+    import struct
+    rng = np.random.default_rng(2)
+    s16 = rng.integers(-32768, 32768, (2, 1000)).astype(np.int16)
+    path = str(tmp_path / "a.wav")
+    data = np.ascontiguousarray(s16.T).tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, 48000, 48000 * 4, 4, 16)
+                + b"data" + struct.pack("<I", len(data)) + data)
+    got, sr = fv.wav_read_i16(path)
+    assert sr == 48000 and got.dtype == np.int16 and np.array_equal(got, s16)
+    f32, _ = fv.wav_read(path)
+    assert np.array_equal(f32, s16.astype(np.float32) * np.float32(1.0 / 32768.0))
+    with open(path, "wb") as f:
+        d = np.zeros(8, np.float32).tobytes()
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(d)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 3, 1, 48000, 48000 * 4, 4, 32)
+                + b"data" + struct.pack("<I", len(d)) + d)
+    with pytest.raises(fv.FvadError):
+        fv.wav_read_i16(path)
+
+
 def test_golden_vad_stream_segments(fv):
     # committed band volumes of a 120 s synthetic stream -> the exact segment list
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden_vad_seed40.npz"))
