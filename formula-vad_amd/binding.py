@@ -182,6 +182,7 @@ SIGNATURES = {
     "fvad_lane_state_create": (C.c_int, [vp, C.POINTER(vp)]),
     "fvad_lane_state_reset": (None, [vp]),
     "fvad_lane_state_destroy": (None, [vp]),
+    "fvad_lane_state_seek": (C.c_int, [vp, C.c_uint64]),
     "fvad_engine_opts_default": (None, [C.POINTER(EngineOpts)]),
     "fvad_engine_run": (C.c_int, [vp, C.POINTER(Lane), sz, C.POINTER(EngineOpts)]),
     "fvad_engine_enqueue_device": (C.c_int, [vp, vp, sz, sz, sz, vp, vp, vp,

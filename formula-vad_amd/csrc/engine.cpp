@@ -829,6 +829,18 @@ void fvad_lane_state_reset(fvad_lane_state* s)
     s->next_frame_index = 0;
 }
 
+int fvad_lane_state_seek(fvad_lane_state* s, uint64_t sample_index)
+{
+    if (!s || sample_index % kChunk48) return FVAD_ERR_INVALID_ARGUMENT;
+    fvad_lane_state_reset(s);
+    // zero history, positioned mid-stream: the FFT-1024 frame grid stays anchored at absolute sample 0, so the first
+    // sample_index % 1024 positions of the first frame are (zero) remainder
+    s->samples_consumed = sample_index;
+    s->n_rem = (size_t)(sample_index % kVadFft);
+    s->next_frame_index = sample_index - s->n_rem;
+    return FVAD_OK;
+}
+
 void fvad_lane_state_destroy(fvad_lane_state* s)
 {
     if (!s) return;

@@ -64,3 +64,51 @@ def gather_stats_native(comm, local_ids, local_stats, n_streams):
     from . import binding as fv
     allst = comm.allgather_stats(list(local_ids), list(local_stats), n_streams)
     return np.stack([fv.single_stats_to_array(s) for s in allst]) if allst else np.zeros((0, N_STAT), np.float32)
+
+
+# ------------------------------------------------------------------ time-split sharding of one long stream
+CHUNK = 24000
+FFT = 1024
+HALO_CHUNKS = 2   # warm-up chunks in front of a rank's range (see fvad_lane_state_seek in include/fvad.h)
+
+
+def split_stream(n_chunks, world):
+    """Contiguous, balanced chunk ranges [(c0, c1)] of one stream for `world` ranks (BASELINE config 5: one long
+    corpus over 8 GPUs)."""
+    base, extra = divmod(n_chunks, world)
+    out, c = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((c, c + n))
+        c += n
+    return out
+
+
+def time_split_job(n_chunks, c0, c1):
+    """What rank (c0, c1) has to process: chunks [start, stop) with start two chunks early (exact state from c0 on:
+    the NSNet2 GRU is reset per chunk, src/NSNet2.zig:71-112,188-203) and one chunk late (the 1024-sample VAD
+    frame that straddles the range's end).  Returns (start, stop)."""
+    return max(c0 - HALO_CHUNKS, 0), min(c1 + 1, n_chunks)
+
+
+def run_time_split_rank(ctx, pcm, c0, c1, want_denoised=True):
+    """One rank's share of a single-channel stream `pcm` (host array, float32 or int16): returns the denoised
+    audio and chunk RMS of chunks [c0, c1) and the band sums of the FFT frames that START inside them, each
+    bit-identical to the unsplit run."""
+    from . import binding as fv
+    n_chunks = pcm.shape[0] // CHUNK
+    start, stop = time_split_job(n_chunks, c0, c1)
+    st = ctx.lane_state()
+    try:
+        fv.check(fv.lib().fvad_lane_state_seek(st, start * CHUNK), "fvad_lane_state_seek")
+        o = ctx.engine_run([pcm[start * CHUNK: stop * CHUNK]], states=[st], want_denoised=want_denoised)[0]
+    finally:
+        fv.lib().fvad_lane_state_destroy(st)
+    first = o["first_frame_index"]                         # absolute sample index of the lane's first frame
+    last_rank = c1 == n_chunks
+    k_lo = -((first - c0 * CHUNK) // FFT) if first < c0 * CHUNK else 0          # first frame starting at >= 24000 c0
+    k_hi = o["n_fft_frames"] if last_rank else -((first - c1 * CHUNK) // FFT)   # first frame starting at >= 24000 c1
+    k_lo, k_hi = max(k_lo, 0), min(k_hi, o["n_fft_frames"])
+    den = o["denoised"][(c0 - start) * CHUNK: (c1 - start) * CHUNK] if want_denoised else None
+    return {"denoised": den, "chunk_rms": o["chunk_rms"][c0 - start: c1 - start],
+            "band_sum": o["band_sum"][k_lo:k_hi], "first_frame_index": first + k_lo * FFT}

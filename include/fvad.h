@@ -191,6 +191,15 @@ typedef struct fvad_lane_state fvad_lane_state; /* cross-call carry of one lane 
 int fvad_lane_state_create(fvad_ctx *ctx, fvad_lane_state **out);
 void fvad_lane_state_reset(fvad_lane_state *s);
 void fvad_lane_state_destroy(fvad_lane_state *s);
+/* Time-split sharding of ONE long stream over several GPUs (BASELINE config 5).  The ONNX
+ * session carries no state across chunks (NSNet2.zig:57-58,71-112), so what crosses a chunk edge is short: the
+ * 160-sample input hop, the 4 warm-up feature rows, the overlap-add tail and the upsampler's last sample
+ * (NSNet2.zig:27-33,188-203), all functions of the previous chunk and of the 4 last frames of the one before.  A
+ * lane that starts TWO chunks early from zero history (this call, sample_index = 24000 * (c0 - 2)) is therefore
+ * bit-identical to the unsplit stream from chunk c0 on; the FFT-1024 frame grid stays anchored at sample 0
+ * (first_frame_index of the next fvad_engine_run says where the lane's first frame starts).  The caller drops
+ * the two warm-up chunks and the frames that start before 24000 * c0.  sample_index: a multiple of 24000. */
+int fvad_lane_state_seek(fvad_lane_state *s, uint64_t sample_index);
 
 typedef struct {
     const float *pcm;        /* n_samples f32 @48 kHz (host or device, see on_device); NULL: use pcm_i16 */

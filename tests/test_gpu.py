@@ -932,3 +932,33 @@ def test_pcm16_input_equals_host_converted_f32(fv, gpu_ctx, pkg):
     assert np.array_equal(q, np.rint(np.clip(den * np.float32(32768.0), -32768.0, 32767.0)).astype(np.int16))
     for d in [d16, d32, dq, dden] + db + dr:
         gpu_ctx.device_free(d)
+
+
+# ------------------------------------------------------------------ time-split sharding of one stream (config 5)
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_time_split_of_one_stream_is_bit_identical(fv, gpu_ctx, weights7, pkg, world):
+    # one long stream cut at chunk boundaries for `world` ranks; every rank starts two chunks early from zero
+    # history and runs one chunk past its end.  Concatenated denoised audio, chunk RMS, band sums and the segments
+    # the host state machine makes of them must equal the unsplit run bit for bit (NSNet2.zig:188-203: what
+    # crosses a chunk edge)
+    pcm, _ = pkg.synth.make_stream(33.0, seed=55)
+    x = pcm[0][: 65 * 24000].copy()
+    whole = gpu_ctx.engine_run([x], want_denoised=True)[0]
+    parts = [pkg.shard.run_time_split_rank(gpu_ctx, x, c0, c1) for c0, c1 in pkg.shard.split_stream(65, world)]
+    assert [p["chunk_rms"].shape[0] for p in parts] == [c1 - c0 for c0, c1 in pkg.shard.split_stream(65, world)]
+    assert np.array_equal(np.concatenate([p["denoised"] for p in parts]), whole["denoised"])
+    assert np.array_equal(np.concatenate([p["chunk_rms"] for p in parts]), whole["chunk_rms"])
+    band = np.concatenate([p["band_sum"] for p in parts])
+    assert np.array_equal(band, whole["band_sum"])
+    pos = 0
+    for p in parts:                                   # the parts tile the frame grid without gaps
+        assert p["first_frame_index"] == 1024 * pos
+        pos += p["band_sum"].shape[0]
+    # loop D on rank 0 over the concatenated band sums == the oracle's segments for the whole stream
+    ratio = np.ones(band.shape[0], np.float32)
+    m = fv.VadMachine()
+    fv.vad_run_many([m], [band[:, None]], [ratio], n_threads=1)
+    ref = orc.Pipeline(weights7, n_channels=1)
+    ref.push(x[None])
+    assert [(s[0], s[1]) for s in m.segments()] == [(s[0], s[1]) for s in ref.segments()] and len(ref.segments()) >= 2
+    m.close()

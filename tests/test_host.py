@@ -515,6 +515,20 @@ def test_wav_read_i16_keeps_the_samples(fv, tmp_path):
         fv.wav_read_i16(path)
 
 
+def test_split_stream_ranges(pkg):
+    # time-split sharding (BASELINE config 5): contiguous balanced chunk ranges, each rank's job starts two
+    # chunks early and runs one chunk late, clipped to the stream
+    sh = pkg.shard
+    assert sh.split_stream(65, 3) == [(0, 22), (22, 44), (44, 65)]
+    assert sh.split_stream(7, 8) == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 7)]
+    for n, w in ((72000, 8), (10, 3), (1, 1)):
+        r = sh.split_stream(n, w)
+        assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        assert max(c1 - c0 for c0, c1 in r) - min(c1 - c0 for c0, c1 in r) <= 1
+    assert sh.time_split_job(65, 0, 22) == (0, 23) and sh.time_split_job(65, 22, 44) == (20, 45)
+    assert sh.time_split_job(65, 44, 65) == (42, 65) and sh.time_split_job(65, 1, 5) == (0, 6)
+
+
 def test_golden_vad_stream_segments(fv):
     # committed band volumes of a 120 s synthetic stream -> the exact segment list
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden_vad_seed40.npz"))
