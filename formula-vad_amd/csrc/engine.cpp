@@ -80,11 +80,23 @@ int upload_model(fvad_ctx* ctx)
     if ((rc = upload(ctx, m.br2, std::vector<float>(w.gru2_b.begin() + 3 * H, w.gru2_b.end())))) return rc;
     pack_gru_r2(w.gru2_r.data(), H, f);
     if ((rc = upload(ctx, m.r2v2, f))) return rc;
-    // large-batch layouts: 1200 = 5 column blocks of 15 tiles
-    pack_panel(w.gru1_w.data(), 1200, 400, 5, 15, 25, f);
+    // large-batch layouts: 1200 = 5 column blocks of 15 tiles, output units in TILE-major order
+    // (new row 48 J + 16 g + u = old row 400 g + 16 J + u): the GEMM then writes gi rows as
+    // [25 J][3 gates][16 units], what gru_rec3_kernel reads 192 contiguous bytes at a time
+    auto tile_major_rows = [&](const float* W, int K) {
+        std::vector<float> out((size_t)3 * H * K);
+        for (int J = 0; J < 25; ++J)
+            for (int g = 0; g < 3; ++g)
+                for (int u = 0; u < 16; ++u)
+                    std::copy(W + (size_t)(g * H + 16 * J + u) * K, W + (size_t)(g * H + 16 * J + u + 1) * K,
+                              out.begin() + (size_t)(48 * J + 16 * g + u) * K);
+        return out;
+    };
+    pack_panel(tile_major_rows(w.gru1_w.data(), 400).data(), 1200, 400, 5, 15, 25, f);
     if ((rc = upload(ctx, m.gi1v2_w, f))) return rc;
-    pack_panel(w.gru2_w.data(), 1200, 400, 5, 15, 25, f);
+    pack_panel(tile_major_rows(w.gru2_w.data(), 400).data(), 1200, 400, 5, 15, 25, f);
     if ((rc = upload(ctx, m.gi2v2_w, f))) return rc;
+    if ((rc = upload(ctx, m.gi1_btm, tile_major_rows(w.gru1_b.data(), 1)))) return rc; // Wb only (unfolded fc1 path)
     {
         // fc1 has no activation (x = fc1(x); x, _ = rnn1(x)), so fc1 followed by GRU1's input
         // projection is one linear map 161 -> 1200: W' = W_ih W_fc1, b' = W_ih b_fc1 + Wb.  Folded
@@ -105,15 +117,16 @@ int upload_model(fvad_ctx* ctx)
             for (int k = 0; k < 161; ++k) wf[(size_t)o * 161 + k] = (float)row[k];
             bf[o] = (float)b;
         }
-        pack_panel(wf.data(), 1200, 161, 5, 15, 11, f);
+        pack_panel(tile_major_rows(wf.data(), 161).data(), 1200, 161, 5, 15, 11, f);
         if ((rc = upload(ctx, m.gi1f_w, f))) return rc;
-        if ((rc = upload(ctx, m.gi1f_b, bf))) return rc;
+        if ((rc = upload(ctx, m.gi1f_b, tile_major_rows(bf.data(), 1)))) return rc;
         // gru_rec3_kernel adds only the n-gate recurrent bias itself: for z and r, Wb + Rb is one constant
         for (int o = 0; o < 2 * H; ++o) bf[o] += w.gru1_b[3 * H + o];
-        if ((rc = upload(ctx, m.gi1f_bzr, bf))) return rc;
+        if ((rc = upload(ctx, m.gi1f_bzr, tile_major_rows(bf.data(), 1)))) return rc;
         std::vector<float> b2(w.gru2_b.begin(), w.gru2_b.begin() + 3 * H);
+        if ((rc = upload(ctx, m.gi2_btm, tile_major_rows(b2.data(), 1)))) return rc;
         for (int o = 0; o < 2 * H; ++o) b2[o] += w.gru2_b[3 * H + o];
-        if ((rc = upload(ctx, m.gi2_bzr, b2))) return rc;
+        if ((rc = upload(ctx, m.gi2_bzr, tile_major_rows(b2.data(), 1)))) return rc;
     }
     // fc2: 400 -> 600 (N padded to 608 = 2 blocks of 19 tiles)
     pack_panel(w.fc2_w.data(), 600, 400, 2, 19, 25, f);
@@ -198,7 +211,7 @@ void time_end(fvad_ctx* ctx)
 // Large batches: the LDS-DMA kernels with 192 / 128 / 64 sequences per workgroup; small batches keep
 // one wavefront (16 sequences) per workgroup so that more CUs take part.
 struct GruChoice {
-    int version; // 2: gru_rec2, 3: gru_rec3 (expects the z/r recurrent biases folded into gi),
+    int version; // 3: gru_rec3 (expects the z/r recurrent biases folded into gi),
                  // 4: gru_lat (16 sequences per workgroup, tiles split over 8 waves),
                  // 5: gru_ws (weights stationary in registers across 25 x G workgroups, kernels_ws.hip)
     int waves;
@@ -255,10 +268,10 @@ static long padded_batch(const fvad_ctx* ctx, long n)
 
 static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, bool allow_v3)
 {
-    const char* force = getenv("FVAD_GRU_KERNEL"); // tuning aid: "v2w8", "v3w12", "v4w8", ...
+    const char* force = getenv("FVAD_GRU_KERNEL"); // tuning aid: "v3w12", "v3w8", "v3w4", "v4w8" (gru_lat), "v5w0" (gru_ws)
     if (force) {
         GruChoice c{force[1] - '0', atoi(force + 3)};
-        if (c.version == 3 && !allow_v3) c.version = 2;
+        if (c.version == 3 && !allow_v3) c = {4, 8}; // gru_rec3 needs the folded biases of the large-batch path
         return c;
     }
     const int cu = ctx->n_cu;
@@ -267,8 +280,8 @@ static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, bool allow_v3)
     if (n_pad % 128 == 0 && gru_cost(n_pad, 8, cu) < gru_cost(n_pad, best, cu)) best = 8;
     if (n_pad % 192 == 0 && gru_cost(n_pad, 12, cu) < gru_cost(n_pad, best, cu)) best = 12;
     if (!allow_v3 && gru_ws_cost(n_pad, cu) < gru_cost(n_pad, best, cu)) return {5, 0}; // small-batch GEMM path only
-    if (best == 0) return {4, 8};
-    return {allow_v3 ? 3 : 2, best};
+    if (best == 0 || !allow_v3) return {4, 8};
+    return {3, best};
 }
 
 // buffers of the weight-stationary recurrence, sized once for the largest batch that kernel takes (2560
@@ -301,9 +314,9 @@ static int prepare_gru_ws(fvad_ctx* ctx, long n_pad)
 }
 
 static int launch_gru(fvad_ctx* ctx, GruChoice c, const float* gi, const DevBuf& r_v2, const float* bR,
-                      float* hout, long n_pad, int T, int layer)
+                      float* hout, long n_pad, int T, int layer, int tile_major)
 {
-    if (c.version == 4) return fvad_launch_gru_lat(gi, r_v2.p, bR, hout, n_pad, T, nullptr, ctx->stream);
+    if (c.version == 4) return fvad_launch_gru_lat(gi, r_v2.p, bR, hout, n_pad, T, nullptr, tile_major, ctx->stream);
     if (c.version == 5) {
         Workspace& ws = ctx->ws;
         unsigned* err = ws.ws_sync + 512;
@@ -319,16 +332,15 @@ static int launch_gru(fvad_ctx* ctx, GruChoice c, const float* gi, const DevBuf&
                 if (!ev) { if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return -1; }
                 else if (hipStreamWaitEvent(ctx->stream, ev, 0) != hipSuccess) return -1;
             }
-            rc = fvad_launch_gru_ws(gi, r_v2.p, bR, hout, ws.hx, ws.ws_sync + 256 * layer, err, n_pad, T, ctx->n_cu, ctx->stream);
+            rc = fvad_launch_gru_ws(gi, r_v2.p, bR, hout, ws.hx, ws.ws_sync + 256 * layer, err, n_pad, T, ctx->n_cu, tile_major, ctx->stream);
             if (serialise && hipEventRecord(g_ws_ev[ctx->device], ctx->stream) != hipSuccess) return -1;
         }
         if (rc) return rc;
         // fallback behind it: returns at once unless a workgroup of the launch above gave up waiting
-        return fvad_launch_gru_lat(gi, r_v2.p, bR, hout, n_pad, T, err, ctx->stream);
+        return fvad_launch_gru_lat(gi, r_v2.p, bR, hout, n_pad, T, err, tile_major, ctx->stream);
     }
     if (c.waves <= 0 || n_pad % (16 * c.waves)) return -1;
     if (c.version == 3) return fvad_launch_gru_rec3(gi, r_v2.p, bR, hout, n_pad, T, c.waves, ctx->stream);
-    if (c.version == 2) return fvad_launch_gru_rec2(gi, r_v2.p, bR, hout, n_pad, T, c.waves, ctx->stream);
     return -1;
 }
 
@@ -341,22 +353,14 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     const long rows = n_pad * T;
     const long rows_out = n_pad * (T - skip);
     int rc = 0;
-    const char* force = getenv("FVAD_GEMM_KERNEL"); // tuning aid: "v1" / "v2" / "v2nofold" / "v3"
+    const char* force = getenv("FVAD_GEMM_KERNEL"); // tuning aid: "v1" (small-batch GEMM) / "v3" / "v3nofold"
     const bool big = force ? force[1] != '1' : (n_pad >= 2048);
     if (big && rows % 256 == 0 && rows_out % 256 == 0) {
-        const char* fw = getenv("FVAD_GEMM_WAVES"); // tuning aid
-        int gw = 8; // 12 (three waves per SIMD) measured no faster than 8 for the GEMMs
-        if (fw) gw = atoi(fw);
-        // The persistent kernel (one workgroup per CU walking all (row panel, column block) items) is
-        // the default where it has an instance: the 15- and 11-tile column blocks.  The 19-tile blocks
-        // of fc2/fc3 leave it no room for its fragment ring in 256 VGPRs and stay on panel_gemm2.
-        const bool allow_v3 = !(force && strstr(force, "v2"));
-        // K is the true reduction length (S super-steps of 16 cover it, zero-padded)
+        // The persistent kernel: one workgroup per CU walking all (row panel, column block) items; 15-, 13- and
+        // 11-tile column blocks.  K is the true reduction length (S super-steps of 16 cover it, zero-padded).
         auto gemm = [&](const float* A, int lda, const float* W, const float* b, float* Cc, int ldc, long r, int nt,
                         int nblk, int S, int K, int act, int valid, int mT, int mskip) {
-            if (allow_v3 && fvad_launch_panel_gemm3(A, lda, W, b, Cc, ldc, r, nt, nblk, S, K, act, valid, mT, mskip, ctx->n_cu, st) == 0)
-                return 0;
-            return fvad_launch_panel_gemm2(A, lda, W, b, Cc, ldc, r, nt, nblk, S, act, valid, mT, mskip, gw, st);
+            return fvad_launch_panel_gemm3(A, lda, W, b, Cc, ldc, r, nt, nblk, S, K, act, valid, mT, mskip, ctx->n_cu, st);
         };
         const bool fold = !(force && strstr(force, "nofold"));
         const GruChoice gc = pick_gru(ctx, n_pad, fold);
@@ -371,26 +375,23 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
             rc |= fvad_launch_panel_gemm(ws.feat, kFeatStride, m.fc1_w.p, m.fc1_b.p, ws.a1, 400, rows, 25, 1, 11, FVAD_ACT_NONE, 0, 0, st);
             time_end(ctx);
             time_begin(ctx, "gru1_in_gemm");
-            rc |= gemm(ws.a1, 400, m.gi1v2_w.p, m.gi1_b.p, ws.gi, 1200, rows, 15, 5, 25, 400, FVAD_ACT_NONE, 75, 0, 0);
+            rc |= gemm(ws.a1, 400, m.gi1v2_w.p, m.gi1_btm.p, ws.gi, 1200, rows, 15, 5, 25, 400, FVAD_ACT_NONE, 75, 0, 0);
             time_end(ctx);
         }
         time_begin(ctx, "gru1_rec");
-        rc |= launch_gru(ctx, gc, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T, 0);
+        rc |= launch_gru(ctx, gc, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T, 0, 1);
         time_end(ctx);
         time_begin(ctx, "gru2_in_gemm");
-        rc |= gemm(ws.h1, 400, m.gi2v2_w.p, bzr ? m.gi2_bzr.p : m.gi2_b.p, ws.gi, 1200, rows, 15, 5, 25, 400, FVAD_ACT_NONE, 75, 0, 0);
+        rc |= gemm(ws.h1, 400, m.gi2v2_w.p, bzr ? m.gi2_bzr.p : m.gi2_btm.p, ws.gi, 1200, rows, 15, 5, 25, 400, FVAD_ACT_NONE, 75, 0, 0);
         time_end(ctx);
         time_begin(ctx, "gru2_rec");
-        rc |= launch_gru(ctx, gc, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T, 1);
+        rc |= launch_gru(ctx, gc, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T, 1, 1);
         time_end(ctx);
         time_begin(ctx, "fc2_gemm");
-        const bool fc13 = allow_v3 && !(force && strstr(force, "fc19"));
-        if (fc13) rc |= gemm(ws.h2, 400, m.fc2v3_w.p, m.fc2v3_b.p, ws.f2, 608, rows_out, 13, 3, 25, 400, FVAD_ACT_RELU, 38, skip ? T : 0, skip);
-        else rc |= gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, 400, FVAD_ACT_RELU, 38, skip ? T : 0, skip);
+        rc |= gemm(ws.h2, 400, m.fc2v3_w.p, m.fc2v3_b.p, ws.f2, 608, rows_out, 13, 3, 25, 400, FVAD_ACT_RELU, 38, skip ? T : 0, skip);
         time_end(ctx);
         time_begin(ctx, "fc3_gemm");
-        if (fc13) rc |= gemm(ws.f2, 608, m.fc3v3_w.p, m.fc3v3_b.p, ws.f3, 608, rows_out, 13, 3, 38, 600, FVAD_ACT_RELU, 38, 0, 0);
-        else rc |= gemm(ws.f2, 608, m.fc3_w.p, m.fc3_b.p, ws.f3, 608, rows_out, 19, 2, 38, 600, FVAD_ACT_RELU, 38, 0, 0);
+        rc |= gemm(ws.f2, 608, m.fc3v3_w.p, m.fc3v3_b.p, ws.f3, 608, rows_out, 13, 3, 38, 600, FVAD_ACT_RELU, 38, 0, 0);
         time_end(ctx);
         time_begin(ctx, "fc4_gemm");
         rc |= gemm(ws.f3, 608, m.fc4_w.p, m.fc4_b.p, ws.gains, kFeatStride, rows_out, 11, 1, 38, 600, FVAD_ACT_SIGMOID, 11, 0, 0);
@@ -408,13 +409,13 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     const GruChoice gcs = pick_gru(ctx, n_pad, false);
     if (gcs.version == 5 && (rc = prepare_gru_ws(ctx, n_pad))) return rc;
     time_begin(ctx, "gru1_rec");
-    rc |= launch_gru(ctx, gcs, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T, 0);
+    rc |= launch_gru(ctx, gcs, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T, 0, 0);
     time_end(ctx);
     time_begin(ctx, "gru2_in_gemm");
     rc |= fvad_launch_panel_gemm(ws.h1, 400, m.gi2_w.p, m.gi2_b.p, ws.gi, 1200, rows, 25, 3, 25, FVAD_ACT_NONE, 0, 0, st);
     time_end(ctx);
     time_begin(ctx, "gru2_rec");
-    rc |= launch_gru(ctx, gcs, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T, 1);
+    rc |= launch_gru(ctx, gcs, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T, 1, 0);
     time_end(ctx);
     time_begin(ctx, "fc2_gemm");
     rc |= fvad_launch_panel_gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, skip ? T : 0, skip, st);
@@ -645,7 +646,7 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     if (ws.h_fft_jobs) hipHostFree(ws.h_fft_jobs);
     DeviceModel& m = ctx->dm;
     DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.gi1_w, &m.gi1_b, &m.br1, &m.gi2_w, &m.gi2_b, &m.br2,
-                      &m.fc2_w, &m.fc2_b, &m.fc3_w, &m.fc3_b, &m.fc4_w, &m.fc4_b, &m.r1v2, &m.r2v2, &m.gi1f_w, &m.gi1f_b, &m.gi1v2_w, &m.gi2v2_w, &m.gi1f_bzr, &m.gi2_bzr, &m.fc2v3_w, &m.fc3v3_w, &m.fc2v3_b, &m.fc3v3_b};
+                      &m.fc2_w, &m.fc2_b, &m.fc3_w, &m.fc3_b, &m.fc4_w, &m.fc4_b, &m.r1v2, &m.r2v2, &m.gi1f_w, &m.gi1f_b, &m.gi1v2_w, &m.gi2v2_w, &m.gi1f_bzr, &m.gi2_bzr, &m.gi1_btm, &m.gi2_btm, &m.fc2v3_w, &m.fc3v3_w, &m.fc2v3_b, &m.fc3v3_b};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (ctx->d_tables) hipFree(ctx->d_tables);
     for (auto& kt : ctx->times) { hipEventDestroy(kt.e0); hipEventDestroy(kt.e1); }

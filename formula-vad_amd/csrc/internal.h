@@ -48,7 +48,8 @@ struct DeviceModel {
     DevBuf fc1_w, fc1_b, gi1_w, gi1_b, br1, gi2_w, gi2_b, br2, fc2_w, fc2_b, fc3_w, fc3_b,
         fc4_w, fc4_b, r1v2, r2v2, gi1f_w, gi1f_b, gi1v2_w, gi2v2_w,
         fc2v3_w, fc3v3_w, fc2v3_b, fc3v3_b, // fc2/fc3 as 3 column blocks of 13 tiles for panel_gemm3
-        gi1f_bzr, gi2_bzr; // input-projection biases with the recurrent z/r biases folded in (gru_rec3)
+        gi1f_bzr, gi2_bzr, // input-projection biases with the recurrent z/r biases folded in (gru_rec3)
+        gi1_btm, gi2_btm;  // plain input-projection biases in tile-major unit order (large-batch GEMM without the fold)
     bool loaded = false;
 };
 

@@ -68,17 +68,13 @@ struct FftTables {
 int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
                            int ldc, long rows, int nt, int n_blocks, int S_steps, int act,
                            int map_T, int map_skip, hipStream_t stream);
-int fvad_launch_panel_gemm2(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
-                            int ldc, long rows, int nt, int n_blocks, int S_steps, int act,
-                            int n_valid_tiles, int map_T, int map_skip, int waves, hipStream_t stream);
 int fvad_launch_panel_gemm3(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
                             int ldc, long rows, int nt, int n_blocks, int S_steps, int K, int act,
                             int n_valid_tiles, int map_T, int map_skip, int n_wg, hipStream_t stream);
-int fvad_launch_gru_rec2(const float* gi, const float* R2frag, const float* bR, float* hout,
-                         long n_seq_pad, int T, int waves, hipStream_t stream);
 // guard != nullptr: the kernel returns at once unless *guard != 0 (fallback behind fvad_launch_gru_ws)
+// tile_major: gi rows are [25 J][3 gates][16] (large-batch GEMM) instead of [3 gates][400] (small-batch GEMM)
 int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, float* hout,
-                        long n_seq_pad, int T, const unsigned* guard, hipStream_t stream);
+                        long n_seq_pad, int T, const unsigned* guard, int tile_major, hipStream_t stream);
 // small batches: recurrent weights stationary in registers across 25 x G workgroups, h exchanged per step
 // (kernels_ws.hip).  hx: fvad_gru_ws_exchange_floats(n_seq_pad) floats; flags: 256 zeroed words per launch;
 // err: one zeroed word shared by the launches of a network pass.  Returns -1 when the batch is too large.
@@ -86,7 +82,7 @@ void fvad_launch_zero_words(unsigned* p, int n, hipStream_t stream);
 bool fvad_gru_ws_shape(long n_seq_pad, int n_cu, int* RT, int* G);
 size_t fvad_gru_ws_exchange_floats(long n_seq_pad);
 int fvad_launch_gru_ws(const float* gi, const float* R2frag, const float* bR, float* hout, float* hx, unsigned* flags,
-                       unsigned* err, long n_seq_pad, int T, int n_cu, hipStream_t stream);
+                       unsigned* err, long n_seq_pad, int T, int n_cu, int tile_major, hipStream_t stream);
 int fvad_launch_gru_rec3(const float* gi, const float* R2frag, const float* bR, float* hout,
                          long n_seq_pad, int T, int waves, hipStream_t stream);
 

@@ -158,148 +158,8 @@ int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const fl
     return -1;
 }
 
-// ------------------------------------------------------------------ panel GEMM, v2
-// Same operand convention; restructured like gru_rec2_kernel for large batches:
-//   * 8 wavefronts per workgroup, RT row tiles (16 rows each) per wavefront -> 128*RT rows share
-//     every weight fragment block that is staged, and each block read from LDS feeds RT MFMA groups;
-//   * weights arrive by LDS-DMA (global_load_lds_dwordx4), SP super-steps (NT*SP KB) per phase,
-//     double-buffered: one barrier per SP*NT*RT*4 MFMAs per wavefront;
-//   * 1-D grid with the column block as the fastest index, so the workgroups that re-read the
-//     same activation rows run next to each other and hit in L2.
-// n_valid_tiles guards the store when the last column block is padded beyond ldc.
-template <int NT, int RT, int ACT, int SP, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void panel_gemm2_kernel(
-    const float* __restrict__ A, int lda, const float* __restrict__ Wfrag,
-    const float* __restrict__ bias, float* __restrict__ C, int ldc, int S_steps, int n_blocks,
-    int n_valid_tiles, int row_map_T, int row_map_skip)
-{
-    __shared__ __attribute__((aligned(16))) float slab[2][NT * SP * 256];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int m = lane & 15;
-    const int q = lane >> 4;
-    // all index arithmetic in 32 bits (rows < 2^31): 64-bit integer division is a several-hundred-
-    // instruction software routine on the GPU and this runs once per workgroup
-    // XCD-major renumbering (see panel_gemm3_kernel): the column blocks of a row panel share one L2
-    const unsigned vb = (gridDim.x % 8u == 0u) ? (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u : blockIdx.x;
-    const unsigned nblk = vb % (unsigned)n_blocks;
-    const unsigned panel = vb / (unsigned)n_blocks;
-
-    const float* a_ptr[RT];
-    unsigned c_row[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const unsigned row = ((panel * WAVES + wave) * RT + rt) * 16 + m;
-        unsigned a_row = row;
-        if (row_map_T > 0) {
-            const unsigned per = (unsigned)(row_map_T - row_map_skip);
-            const unsigned qd = row / per;
-            a_row = qd * (unsigned)row_map_T + (unsigned)row_map_skip + (row - qd * per);
-        }
-        a_ptr[rt] = A + (size_t)a_row * (size_t)lda + 4 * q;
-        c_row[rt] = row;
-    }
-    const float* w_src = Wfrag + (size_t)nblk * S_steps * (NT * 256);
-
-    f32x4 acc[RT][NT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int P = (S_steps + SP - 1) / SP;
-    auto issue = [&](int p, float* dst) {
-        const int s0 = p * SP;
-        const int cnt = (S_steps - s0 < SP) ? (S_steps - s0) : SP;
-        const float* src = w_src + (size_t)s0 * (NT * 256);
-        const int nb = NT * cnt;
-        for (int b = wave; b < nb; b += WAVES)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + b * 256 + lane * 4),
-                                             (__attribute__((address_space(3))) void*)(dst + b * 256), 16, 0, 0);
-    };
-    issue(0, slab[0]);
-    f32x4 a_cur[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a_cur[rt] = *reinterpret_cast<const f32x4*>(a_ptr[rt]);
-    __syncthreads();
-
-    int buf = 0;
-    for (int p = 0; p < P; ++p) {
-        const int s0 = p * SP;
-        const int cnt = (S_steps - s0 < SP) ? (S_steps - s0) : SP;
-        if (p + 1 < P) issue(p + 1, slab[buf ^ 1]);
-        for (int s = 0; s < cnt; ++s) {
-            const int sg = s0 + s;
-            f32x4 a_next[RT];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-                a_next[rt] = (sg + 1 < S_steps) ? *reinterpret_cast<const f32x4*>(a_ptr[rt] + 16 * (sg + 1)) : a_cur[rt];
-            const f32x4* wl = reinterpret_cast<const f32x4*>(slab[buf]) + (s * NT) * 64 + lane;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const f32x4 w4 = wl[t * 64];
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w4.x, a_cur[rt].x, acc[rt][t]);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w4.y, a_cur[rt].y, acc[rt][t]);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w4.z, a_cur[rt].z, acc[rt][t]);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w4.w, a_cur[rt].w, acc[rt][t]);
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) a_cur[rt] = a_next[rt];
-        }
-        __syncthreads(); // next phase's weights landed (vmcnt drained); this buffer is free again
-        buf ^= 1;
-    }
-
-    const float* b_ptr = bias + nblk * (NT * 16) + 4 * q;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (nblk * NT + t < n_valid_tiles) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(b_ptr + 16 * t);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                f32x4 v = acc[rt][t] + b4;
-                if (ACT == FVAD_ACT_RELU) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                } else if (ACT == FVAD_ACT_SIGMOID) {
-                    v.x = act_sigmoid(v.x); v.y = act_sigmoid(v.y); v.z = act_sigmoid(v.z); v.w = act_sigmoid(v.w);
-                }
-                *reinterpret_cast<f32x4*>(C + (size_t)c_row[rt] * (size_t)ldc + nblk * (NT * 16) + 4 * q + 16 * t) = v;
-            }
-        }
-    }
-}
-
-// rows must be a multiple of 32 * waves (RT = 2); waves = 8 or 12 (12: three wavefronts per SIMD,
-// only for the variants whose register budget allows it).
-int fvad_launch_panel_gemm2(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
-                            int ldc, long rows, int nt, int n_blocks, int S_steps, int act,
-                            int n_valid_tiles, int map_T, int map_skip, int waves, hipStream_t stream)
-{
-#define CASE2(NT_, ACT_, SP_, W_)                                                                    \
-    if (nt == NT_ && act == ACT_ && waves == W_) {                                                   \
-        const unsigned grid = (unsigned)((rows / (32 * W_)) * n_blocks);                             \
-        hipLaunchKernelGGL((panel_gemm2_kernel<NT_, 2, ACT_, SP_, W_>), dim3(grid), dim3(64 * W_), 0, \
-                           stream, A, lda, Wfrag, bias, C, ldc, S_steps, n_blocks, n_valid_tiles,    \
-                           map_T, map_skip);                                                         \
-        return 0;                                                                                    \
-    }
-    CASE2(15, FVAD_ACT_NONE, 5, 8)
-    CASE2(15, FVAD_ACT_NONE, 5, 12)
-    CASE2(19, FVAD_ACT_RELU, 3, 8)
-    CASE2(11, FVAD_ACT_SIGMOID, 6, 8)
-    CASE2(11, FVAD_ACT_SIGMOID, 6, 12)
-#undef CASE2
-    return -1;
-}
-
 // ------------------------------------------------------------------ panel GEMM, v3 (persistent)
-// Device timestamps (s_memtime) of panel_gemm2 showed where its missing ~20 % went:
+// Device timestamps (s_memtime) of a plain double-buffered LDS-DMA version showed where its missing ~20 % went:
 //   * the compiler guards every ds_read behind s_waitcnt vmcnt(0) while an LDS-DMA is in flight (it
 //     cannot prove the DMA targets the *other* slab buffer), so the first super-step of each phase
 //     stalled for the whole next-slab DMA and the first super-step after an epilogue stalled until
@@ -543,7 +403,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
 }
 
 // rows must be a multiple of 256; grid = one persistent workgroup per CU.  Returns -1 when there is no
-// instance for (nt, act): the caller falls back to panel_gemm2.
+// instance for (nt, act).
 int fvad_launch_panel_gemm3(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
                             int ldc, long rows, int nt, int n_blocks, int S_steps, int K, int act,
                             int n_valid_tiles, int map_T, int map_skip, int n_wg, hipStream_t stream)
@@ -581,135 +441,18 @@ int fvad_launch_panel_gemm3(const float* A, int lda, const float* Wfrag, const f
 // recurrence is the MFMA itself.
 // (GRU_H, GRU_J, GRU2_SLAB and the gate nonlinearities live in nn_device.h)
 
-// ------------------------------------------------------------------ GRU recurrence, v2
-// Large batches: every weight slab is shared by the wavefronts of a workgroup through LDS:
-//   * 8 wavefronts (128 sequences) per workgroup = 2 waves per SIMD, so one wave's LDS / global /
-//     epilogue latency is covered by the other wave's MFMAs;
-//   * the whole weight slab of one unit tile (3 gates x 25 super-steps = 75 KB) is staged per
-//     phase by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write), double-buffered in
-//     150 KB of the CU's 160 KB LDS -> 25 barriers per step instead of 125;
-//   * gate nonlinearities on v_exp_f32 / v_rcp_f32.
-// R2frag: [25 J][3 g][25 S][64][4].
-
-template <int WAVES>
-__device__ __forceinline__ void gru2_issue_slab(const float* __restrict__ src, float* lds_dst, int wave, int lane)
-{
-    // one global_load_lds_dwordx4 moves one 1 KB fragment block: LDS address = uniform base + lane*16
-#pragma unroll
-    for (int b = wave; b < 3 * GRU_J; b += WAVES) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + b * 256 + lane * 4),
-                                         (__attribute__((address_space(3))) void*)(lds_dst + b * 256), 16, 0, 0);
-    }
-}
-
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void gru_rec2_kernel(const float* __restrict__ gi,
-                                                              const float* __restrict__ R2frag,
-                                                              const float* __restrict__ bR,
-                                                              float* hout, int T)
-{
-    __shared__ __attribute__((aligned(16))) float slab[2][GRU2_SLAB];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int m = lane & 15;
-    const int q = lane >> 4;
-    const long seq = (long)(blockIdx.x * WAVES + wave) * 16 + m;
-
-    const float* gi_seq = gi + seq * T * (3 * GRU_H) + 4 * q;
-    float* h_seq = hout + seq * T * GRU_H + 4 * q;
-    const float* bR_q = bR + 4 * q;
-
-    // weights of unit tile 0 start streaming while t = 0 is computed
-    gru2_issue_slab<WAVES>(R2frag, slab[0], wave, lane);
-
-    // ---- t = 0: h_{-1} = 0, so R h + Rb = Rb
-    for (int J = 0; J < GRU_J; ++J) {
-        const f32x4 giz = *reinterpret_cast<const f32x4*>(gi_seq + 16 * J);
-        const f32x4 gir = *reinterpret_cast<const f32x4*>(gi_seq + GRU_H + 16 * J);
-        const f32x4 gin = *reinterpret_cast<const f32x4*>(gi_seq + 2 * GRU_H + 16 * J);
-        const f32x4 bz = *reinterpret_cast<const f32x4*>(bR_q + 16 * J);
-        const f32x4 br = *reinterpret_cast<const f32x4*>(bR_q + GRU_H + 16 * J);
-        const f32x4 bn = *reinterpret_cast<const f32x4*>(bR_q + 2 * GRU_H + 16 * J);
-        f32x4 h;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float z = fast_sigmoid(giz[r] + bz[r]);
-            const float rr = fast_sigmoid(gir[r] + br[r]);
-            const float n = fast_tanh(gin[r] + rr * bn[r]);
-            h[r] = (1.0f - z) * n + z * 0.0f;
-        }
-        *reinterpret_cast<f32x4*>(h_seq + 16 * J) = h;
-    }
-    __syncthreads(); // drains the LDS-DMA (vmcnt) and publishes slab 0
-    int buf = 0;
-
-    for (int t = 1; t < T; ++t) {
-        const float* gi_t = gi_seq + (long)t * (3 * GRU_H);
-        const float* h_prev = h_seq + (long)(t - 1) * GRU_H;
-        float* h_out = h_seq + (long)t * GRU_H;
-
-        f32x4 hreg[GRU_J];
-#pragma unroll
-        for (int S = 0; S < GRU_J; ++S) hreg[S] = *reinterpret_cast<const f32x4*>(h_prev + 16 * S);
-
-        for (int J = 0; J < GRU_J; ++J) {
-            const int nJ = (J + 1 == GRU_J) ? 0 : J + 1;
-            gru2_issue_slab<WAVES>(R2frag + (size_t)nJ * GRU2_SLAB, slab[buf ^ 1], wave, lane);
-
-            const f32x4 giz = *reinterpret_cast<const f32x4*>(gi_t + 16 * J);
-            const f32x4 gir = *reinterpret_cast<const f32x4*>(gi_t + GRU_H + 16 * J);
-            const f32x4 gin = *reinterpret_cast<const f32x4*>(gi_t + 2 * GRU_H + 16 * J);
-            const f32x4 hp = *reinterpret_cast<const f32x4*>(h_prev + 16 * J);
-            const f32x4 bz = *reinterpret_cast<const f32x4*>(bR_q + 16 * J);
-            const f32x4 br = *reinterpret_cast<const f32x4*>(bR_q + GRU_H + 16 * J);
-            const f32x4 bn = *reinterpret_cast<const f32x4*>(bR_q + 2 * GRU_H + 16 * J);
-
-            f32x4 az = (f32x4){0.f, 0.f, 0.f, 0.f};
-            f32x4 ar = az, an = az;
-            const f32x4* wl = reinterpret_cast<const f32x4*>(slab[buf]) + lane;
-#pragma unroll
-            for (int S = 0; S < GRU_J; ++S) {
-                const f32x4 hv = hreg[S];
-                const f32x4 wz = wl[(0 * GRU_J + S) * 64];
-                const f32x4 wr = wl[(1 * GRU_J + S) * 64];
-                const f32x4 wn = wl[(2 * GRU_J + S) * 64];
-                az = MFMA16(wz.x, hv.x, az);
-                ar = MFMA16(wr.x, hv.x, ar);
-                an = MFMA16(wn.x, hv.x, an);
-                az = MFMA16(wz.y, hv.y, az);
-                ar = MFMA16(wr.y, hv.y, ar);
-                an = MFMA16(wn.y, hv.y, an);
-                az = MFMA16(wz.z, hv.z, az);
-                ar = MFMA16(wr.z, hv.z, ar);
-                an = MFMA16(wn.z, hv.z, an);
-                az = MFMA16(wz.w, hv.w, az);
-                ar = MFMA16(wr.w, hv.w, ar);
-                an = MFMA16(wn.w, hv.w, an);
-            }
-            f32x4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float z = fast_sigmoid(giz[r] + (az[r] + bz[r]));
-                const float rr = fast_sigmoid(gir[r] + (ar[r] + br[r]));
-                const float n = fast_tanh(gin[r] + rr * (an[r] + bn[r]));
-                h[r] = (1.0f - z) * n + z * hp[r];
-            }
-            *reinterpret_cast<f32x4*>(h_out + 16 * J) = h;
-            __syncthreads(); // next slab landed (vmcnt drained) and everyone is done with this one
-            buf ^= 1;
-        }
-    }
-}
-
 // ------------------------------------------------------------------ GRU recurrence, v3
-// gru_rec2_kernel with the two stalls its device timeline showed removed (same cure as panel_gemm3):
+// A plain LDS-DMA double-buffered recurrence with the two stalls its device timeline showed removed (same cure as panel_gemm3):
 //   * fragment reads are inline ds_read_b128 with explicit lgkmcnt waits, two super-steps of (z, r, n)
 //     blocks in flight, so the compiler no longer puts s_waitcnt vmcnt(0) (= "next slab's DMA has
 //     landed") in front of the first LDS read of every unit tile;
 //   * gi already contains Wb + Rb for the z and r gates (folded on the host), only the n gate's Rb is
 //     added here: two loads and eight registers less per unit tile;
+//   * gi is TILE-major here, gi[row][25 J][3 gates][16 units] (the host permutes the rows of the input
+//     projection's weights, so the GEMM writes this order by itself): a unit tile's z, r, n operands are 192
+//     contiguous bytes of the row.  In gate-major order they are three 64-byte segments 1600 bytes apart, each
+//     in a 128-byte line whose other half belongs to the neighbouring tile, ~32k cycles away -- by then out
+//     of L2, so every gi byte was fetched from HBM twice (tools/fetch_calib.hip + the PMC passes);
 //   * the end-of-tile barrier waits with vmcnt(1): everything up to the slab DMA, but not the h store
 //     issued just before it (__syncthreads() would wait for that store's acknowledgement too).
 // wave must be wave-uniform (SGPR): the DMA then addresses global memory as scalar base + lane * 16
@@ -762,9 +505,9 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec3_kernel(const float* __res
 
     // ---- t = 0: h_{-1} = 0, so R h + Rb = Rb
     for (int J = 0; J < GRU_J; ++J) {
-        const f32x4 giz = ld4(gi_w + 64 * J, gi_off);
-        const f32x4 gir = ld4(gi_w + 64 * J + 4 * GRU_H, gi_off);
-        const f32x4 gin = ld4(gi_w + 64 * J + 8 * GRU_H, gi_off);
+        const f32x4 giz = ld4(gi_w + 192 * J, gi_off);
+        const f32x4 gir = ld4(gi_w + 192 * J + 64, gi_off);
+        const f32x4 gin = ld4(gi_w + 192 * J + 128, gi_off);
         const f32x4 bn = ld4(bR_b + 64 * J + 8 * GRU_H, b_off);
         f32x4 h;
 #pragma unroll
@@ -841,9 +584,9 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec3_kernel(const float* __res
             // last super-steps) but still several thousand cycles before the gate math needs them.
             constexpr int LOAD_AT = 18;
             StaticFor<0, LOAD_AT>::run(super_step);
-            const f32x4 giz = ld4(gi_t + 64 * J, gi_off);
-            const f32x4 gir = ld4(gi_t + 64 * J + 4 * GRU_H, gi_off);
-            const f32x4 gin = ld4(gi_t + 64 * J + 8 * GRU_H, gi_off);
+            const f32x4 giz = ld4(gi_t + 192 * J, gi_off);
+            const f32x4 gir = ld4(gi_t + 192 * J + 64, gi_off);
+            const f32x4 gin = ld4(gi_t + 192 * J + 128, gi_off);
             const f32x4 hp = ld4(h_prev + 64 * J, h_off);
             const f32x4 bn = ld4(bR_b + 64 * J + 8 * GRU_H, b_off);
             StaticFor<LOAD_AT, GRU_J>::run(super_step);
@@ -879,13 +622,16 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec3_kernel(const float* __res
 //   * h_t is exchanged through LDS in operand layout hs[S][lane] (the float4 a lane writes for unit
 //     tile J is the float4 the same lane index reads as super-step S = J), double-buffered, one
 //     barrier per step.
-// gi holds Wx + Wb; Rb is added here (the convention of gru_rec2_kernel).
+// gi holds Wx + Wb; Rb is added here.
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __restrict__ gi,
                                                              const float* __restrict__ R2frag,
                                                              const float* __restrict__ bR,
-                                                             float* hout, int T, const unsigned* guard)
+                                                             float* hout, int T, const unsigned* guard,
+                                                             int gi_js, int gi_gs)
 {
+    // gi_js / gi_gs: floats between unit tiles / between gates in a gi row (16, 400: gate-major rows of the
+    // small-batch GEMM; 48, 16: the tile-major rows of the large-batch GEMM)
     __shared__ __attribute__((aligned(16))) float hs[2][GRU_J * 256];
     typedef const __attribute__((address_space(1))) f32x4* gptr4;
     constexpr int D = 5;
@@ -904,9 +650,9 @@ __global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __rest
 
     // ---- t = 0: h_{-1} = 0, so R h + Rb = Rb
     for (int J = wave; J < GRU_J; J += WAVES) {
-        const f32x4 giz = *reinterpret_cast<const f32x4*>(gi_seq + 16 * J);
-        const f32x4 gir = *reinterpret_cast<const f32x4*>(gi_seq + GRU_H + 16 * J);
-        const f32x4 gin = *reinterpret_cast<const f32x4*>(gi_seq + 2 * GRU_H + 16 * J);
+        const f32x4 giz = *reinterpret_cast<const f32x4*>(gi_seq + gi_js * J);
+        const f32x4 gir = *reinterpret_cast<const f32x4*>(gi_seq + gi_gs + gi_js * J);
+        const f32x4 gin = *reinterpret_cast<const f32x4*>(gi_seq + 2 * gi_gs + gi_js * J);
         const f32x4 bz = *reinterpret_cast<const f32x4*>(bR_q + 16 * J);
         const f32x4 br = *reinterpret_cast<const f32x4*>(bR_q + GRU_H + 16 * J);
         const f32x4 bn = *reinterpret_cast<const f32x4*>(bR_q + 2 * GRU_H + 16 * J);
@@ -982,9 +728,9 @@ __global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __rest
                     wn[k] = *frag(Jn, 2, S + D - GRU_J);
                 }
                 if (S == 15) {
-                    giz = *reinterpret_cast<const f32x4*>(gi_t + 16 * J);
-                    gir = *reinterpret_cast<const f32x4*>(gi_t + GRU_H + 16 * J);
-                    gin = *reinterpret_cast<const f32x4*>(gi_t + 2 * GRU_H + 16 * J);
+                    giz = *reinterpret_cast<const f32x4*>(gi_t + gi_js * J);
+                    gir = *reinterpret_cast<const f32x4*>(gi_t + gi_gs + gi_js * J);
+                    gin = *reinterpret_cast<const f32x4*>(gi_t + 2 * gi_gs + gi_js * J);
                     bz = *reinterpret_cast<const f32x4*>(bR_q + 16 * J);
                     br = *reinterpret_cast<const f32x4*>(bR_q + GRU_H + 16 * J);
                     bn = *reinterpret_cast<const f32x4*>(bR_q + 2 * GRU_H + 16 * J);
@@ -1008,25 +754,11 @@ __global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __rest
 }
 
 int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, float* hout,
-                        long n_seq_pad, int T, const unsigned* guard, hipStream_t stream)
+                        long n_seq_pad, int T, const unsigned* guard, int tile_major, hipStream_t stream)
 {
     if (n_seq_pad % 16) return -1;
-    hipLaunchKernelGGL((gru_lat_kernel<8>), dim3((unsigned)(n_seq_pad / 16)), dim3(512), 0, stream, gi, R2frag, bR, hout, T, guard);
-    return 0;
-}
-
-int fvad_launch_gru_rec2(const float* gi, const float* R2frag, const float* bR, float* hout,
-                         long n_seq_pad, int T, int waves, hipStream_t stream)
-{
-    if (waves == 12) {
-        hipLaunchKernelGGL((gru_rec2_kernel<12>), dim3((unsigned)(n_seq_pad / 192)), dim3(768), 0, stream, gi, R2frag, bR, hout, T);
-    } else if (waves == 8) {
-        hipLaunchKernelGGL((gru_rec2_kernel<8>), dim3((unsigned)(n_seq_pad / 128)), dim3(512), 0, stream, gi, R2frag, bR, hout, T);
-    } else if (waves == 4) {
-        hipLaunchKernelGGL((gru_rec2_kernel<4>), dim3((unsigned)(n_seq_pad / 64)), dim3(256), 0, stream, gi, R2frag, bR, hout, T);
-    } else {
-        return -1;
-    }
+    hipLaunchKernelGGL((gru_lat_kernel<8>), dim3((unsigned)(n_seq_pad / 16)), dim3(512), 0, stream, gi, R2frag, bR, hout, T, guard,
+                       tile_major ? 48 : 16, tile_major ? 16 : GRU_H);
     return 0;
 }
 

@@ -40,8 +40,10 @@ constexpr int WS_AUX_SC1 = 16;                            // buffer cache-policy
 template <int OWN>
 __global__ __launch_bounds__(256) void gru_ws_kernel(const float* __restrict__ gi, const float* __restrict__ R2frag,
                                                      const float* __restrict__ bR, float* __restrict__ hout,
-                                                     float* hx, unsigned* flags, unsigned* err, int T, int RT, int n_rt)
+                                                     float* hx, unsigned* flags, unsigned* err, int T, int RT, int n_rt,
+                                                     int gi_js, int gi_gs)
 {
+    // gi_js / gi_gs: floats between unit tiles / between gates in a gi row (16, 400 gate-major; 48, 16 tile-major)
     // dynamic LDS only (a static array would shift the 16-byte alignment of the dynamic base):
     // hbuf[2][25][64] float4 (h_{t-1} of a row tile, double-buffered), xch[RT][3 gates][64] float4, one int
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -108,10 +110,10 @@ __global__ __launch_bounds__(256) void gru_ws_kernel(const float* __restrict__ g
 #pragma unroll
     for (int o = 0; o < OWN; ++o) {
         if (!own_ok[o]) continue;
-        const float* gp = gi + (own_row[o] * T) * (3 * GRU_H) + 16 * J + 4 * q;
+        const float* gp = gi + (own_row[o] * T) * (3 * GRU_H) + gi_js * J + 4 * q;
         const f32x4 giz = *reinterpret_cast<const f32x4*>(gp);
-        const f32x4 gir = *reinterpret_cast<const f32x4*>(gp + GRU_H);
-        const f32x4 gin = *reinterpret_cast<const f32x4*>(gp + 2 * GRU_H);
+        const f32x4 gir = *reinterpret_cast<const f32x4*>(gp + gi_gs);
+        const f32x4 gin = *reinterpret_cast<const f32x4*>(gp + 2 * gi_gs);
         f32x4 h;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -133,10 +135,10 @@ __global__ __launch_bounds__(256) void gru_ws_kernel(const float* __restrict__ g
 #pragma unroll
         for (int o = 0; o < OWN; ++o) {
             if (own_ok[o]) {
-                const float* gp = gi + (own_row[o] * T + t) * (3 * GRU_H) + 16 * J + 4 * q;
+                const float* gp = gi + (own_row[o] * T + t) * (3 * GRU_H) + gi_js * J + 4 * q;
                 giz[o] = *reinterpret_cast<const f32x4*>(gp);
-                gir[o] = *reinterpret_cast<const f32x4*>(gp + GRU_H);
-                gin[o] = *reinterpret_cast<const f32x4*>(gp + 2 * GRU_H);
+                gir[o] = *reinterpret_cast<const f32x4*>(gp + gi_gs);
+                gin[o] = *reinterpret_cast<const f32x4*>(gp + 2 * gi_gs);
             }
         }
         // ---- wait until every workgroup of the group has published h_{t-1} (flag >= t)
@@ -262,8 +264,9 @@ bool fvad_gru_ws_shape(long n_seq_pad, int n_cu, int* RT, int* G)
 size_t fvad_gru_ws_exchange_floats(long n_seq_pad) { return (size_t)2 * (size_t)(n_seq_pad / 16) * GRU_J * 256; }
 
 int fvad_launch_gru_ws(const float* gi, const float* R2frag, const float* bR, float* hout, float* hx, unsigned* flags,
-                       unsigned* err, long n_seq_pad, int T, int n_cu, hipStream_t stream)
+                       unsigned* err, long n_seq_pad, int T, int n_cu, int tile_major, hipStream_t stream)
 {
+    const int gi_js = tile_major ? 48 : 16, gi_gs = tile_major ? 16 : GRU_H;
     int RT = 0, G = 0;
     if (!fvad_gru_ws_shape(n_seq_pad, n_cu, &RT, &G)) return -1;
     const int n_rt = (int)(n_seq_pad / 16);
@@ -275,7 +278,7 @@ int fvad_launch_gru_ws(const float* gi, const float* R2frag, const float* bR, fl
         if (hipFuncSetAttribute((const void*)gru_ws_kernel<OWN_>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                 (int)lds) != hipSuccess) return -2;                                                 \
         hipLaunchKernelGGL((gru_ws_kernel<OWN_>), dim3((unsigned)(G * GRU_J)), dim3(256), lds, stream, gi, R2frag,  \
-                           bR, hout, hx, flags, err, T, RT, n_rt);                                                  \
+                           bR, hout, hx, flags, err, T, RT, n_rt, gi_js, gi_gs);                                    \
         return 0;                                                                                                   \
     }
     if (RT <= 4) WS_CASE(1)

@@ -196,8 +196,7 @@ def test_nsnet2_forward_matches_oracle(fv, gpu_ctx, weights7):
 
 @pytest.mark.parametrize("env", [
     {}, {"FVAD_GRU_KERNEL": "v3w12"}, {"FVAD_GRU_KERNEL": "v3w8"}, {"FVAD_GRU_KERNEL": "v3w4"},
-    {"FVAD_GRU_KERNEL": "v2w12"}, {"FVAD_GRU_KERNEL": "v2w8"}, {"FVAD_GEMM_KERNEL": "v2"},
-    {"FVAD_GEMM_KERNEL": "v2nofold"}, {"FVAD_GEMM_KERNEL": "v1"}, {"FVAD_GRU_KERNEL": "v4w8"},
+    {"FVAD_GEMM_KERNEL": "v3nofold"}, {"FVAD_GEMM_KERNEL": "v1"}, {"FVAD_GRU_KERNEL": "v4w8"},
     {"FVAD_GRU_KERNEL": "v5w0"},
 ], ids=lambda e: "-".join(e.values()) or "default")
 def test_nsnet2_large_batch_kernels_match_oracle(fv, gpu_ctx, weights7, env, monkeypatch):
