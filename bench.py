@@ -762,7 +762,7 @@ def side_measurements(pkg, fv, ctx, torch, dev):
     except Exception as e:
         extra["hipgraph_replay"] = {"error": repr(e)}
     extra["cfg3_82_chunks_4100_frames"] = {"ms": dt * 1e3, "frames_per_s": 4100 / dt,
-                                           "note": "latency-bound: 54 dependent GRU steps x 2 layers over only 82 sequences (gru_lat_kernel: one 16-sequence workgroup per CU, unit tiles split over 8 waves)"}
+                                           "note": "latency-bound: 54 dependent GRU steps x 2 layers over only 82 sequences (gru_ws_kernel: recurrent weights stationary in registers across 150 workgroups, h exchanged per step)"}
     return extra
 
 
