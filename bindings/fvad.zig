@@ -78,6 +78,38 @@ pub extern "c" fn fvad_nsnet2_destroy(d: ?*NSNet2) void;
 pub extern "c" fn fvad_nsnet2_chunk_size(in_sample_rate: usize) usize;
 pub extern "c" fn fvad_nsnet2_denoise(d: *NSNet2, first: [*]const f32, n_first: usize, second: ?[*]const f32, n_second: usize, denoised: [*]f32, n_result: usize) c_int;
 
+// ---- multi-GPU leg (one thread or process per GPU; stream i of the plan on rank i % world): the per-stream
+// SingleStats of every rank, all-gathered over RCCL in plan order, ready for statistics.aggregate
+// (src/Evaluator/statistics.zig:116-172) -- replaces the join of simulator.zig:221-232's per-file threads.
+pub const Comm = opaque {};
+pub const comm_id_bytes = 128;
+pub const SingleStats = extern struct { // == statistics.SingleStats (statistics.zig:8-37)
+    total_positives_sec: f32,
+    true_positives_sec: f32,
+    false_positives_sec: f32,
+    false_negatives_sec: f32,
+    true_positive_rate: f32,
+    false_negative_rate: f32,
+    false_discovery_rate: f32,
+    precision: f32,
+    fm_index: f32,
+    f_score: f32,
+    f_score_beta: f32,
+};
+pub extern "c" fn fvad_comm_unique_id(id: [*]u8, n_bytes: usize) c_int; // rank 0; hand the bytes to the other ranks
+pub extern "c" fn fvad_comm_create(ctx: *Ctx, id: [*]const u8, n_bytes: usize, world: c_int, rank: c_int, out: *?*Comm) c_int;
+pub extern "c" fn fvad_comm_destroy(c: ?*Comm) void;
+pub extern "c" fn fvad_stats_allgather(c: *Comm, local_ids: [*]const u32, local_stats: [*]const SingleStats, n_local: usize, n_streams: usize, out: [*]SingleStats) c_int;
+
+// ---- device memory and 16-bit transport for hosts that keep audio resident on the GPU
+pub extern "c" fn fvad_device_alloc(ctx: *Ctx, bytes: usize, out: *?*anyopaque) c_int;
+pub extern "c" fn fvad_device_free(ctx: *Ctx, p: ?*anyopaque) void;
+pub extern "c" fn fvad_ctx_copy_to_device(ctx: *Ctx, dst_device: *anyopaque, src_host: *const anyopaque, bytes: usize) c_int;
+pub extern "c" fn fvad_ctx_copy_to_host(ctx: *Ctx, dst_host: *anyopaque, src_device: *const anyopaque, bytes: usize) c_int;
+pub extern "c" fn fvad_ctx_synchronize(ctx: *Ctx) c_int;
+pub extern "c" fn fvad_engine_enqueue_device(ctx: *Ctx, d_pcm: [*]const f32, n_lanes: usize, lane_stride: usize, n_samples: usize, d_denoised: ?[*]f32, d_band_sum: [*]f32, d_chunk_rms: ?[*]f32, opts: ?*const anyopaque) c_int;
+pub extern "c" fn fvad_engine_enqueue_device_i16(ctx: *Ctx, d_pcm16: [*]const i16, n_lanes: usize, lane_stride: usize, n_samples: usize, d_denoised16: ?[*]i16, d_band_sum: [*]f32, d_chunk_rms: ?[*]f32, opts: ?*const anyopaque) c_int;
+
 /// The reference's error names, recovered from the negative status codes of fvad.h.
 pub const Error = error{
     InvalidFFTSize,

@@ -18,6 +18,7 @@ sz = C.c_size_t
 
 FVAD_OK = 0
 FVAD_ERR_NO_DEVICE = -101
+FVAD_ERR_INVALID_ARGUMENT = -100
 
 
 class FvadError(RuntimeError):
@@ -209,6 +210,12 @@ SIGNATURES = {
     "fvad_vad_run_many": (C.c_int, [C.POINTER(vp), sz, C.POINTER(c_float_p),
                                     C.POINTER(c_float_p), C.POINTER(sz), sz,
                                     C.POINTER(C.c_uint64), sz, C.c_int]),
+    "fvad_vad_batch_create": (C.c_int, [C.POINTER(VadConfig), sz, sz, sz, sz, C.POINTER(vp)]),
+    "fvad_vad_batch_destroy": (None, [vp]),
+    "fvad_vad_batch_run": (C.c_int, [vp, c_float_p, sz, sz, c_float_p, sz, sz, sz, C.c_int]),
+    "fvad_vad_batch_total_segments": (sz, [vp]),
+    "fvad_vad_batch_segments": (C.c_int, [vp, C.POINTER(SpeechSegment), sz, C.POINTER(sz)]),
+    "fvad_vad_batch_audit": (C.c_int, [vp, sz, C.POINTER(VadAudit)]),
     "fvad_ra_create": (C.c_int, [sz, C.c_int, C.c_double, C.POINTER(vp)]),
     "fvad_ra_destroy": (None, [vp]),
     "fvad_ra_push": (C.c_double, [vp, C.c_float]),
@@ -726,6 +733,44 @@ class VadMachine:
             self.close()
         except Exception:
             pass
+
+
+class VadBatch:
+    """fvad_vad_batch: the host stage (frame metadata + VAD state machines) for many streams in one call"""
+
+    def __init__(self, n_streams, n_channels=1, sample_rate=48000, fft_size=1024, overrides=None):
+        cfg = VadConfig()
+        lib().fvad_vad_config_default(C.byref(cfg))
+        for k, v in (overrides or {}).items():
+            setattr(cfg, k, v)
+        self.h = vp()
+        check(lib().fvad_vad_batch_create(C.byref(cfg), sample_rate, n_channels, fft_size, n_streams, C.byref(self.h)),
+              "fvad_vad_batch_create")
+        self.n_streams, self.n_channels = n_streams, n_channels
+
+    def run(self, band, chunk_rms, n_threads=1, chunk_size=24000):
+        """band [n_streams * n_channels][n_frames], chunk_rms [n_streams * n_channels][n_chunks] (float32, C order)
+        -> list of per-stream segment lists [(from, to, avg_ratio, vad_met_sec)]"""
+        assert band.dtype == np.float32 and chunk_rms.dtype == np.float32 and band.flags["C_CONTIGUOUS"] and chunk_rms.flags["C_CONTIGUOUS"]
+        assert band.shape[0] == chunk_rms.shape[0] == self.n_streams * self.n_channels
+        check(lib().fvad_vad_batch_run(self.h, fptr(band), band.shape[1], band.shape[1], fptr(chunk_rms), chunk_rms.shape[1],
+                                       chunk_rms.shape[1], chunk_size, n_threads), "fvad_vad_batch_run")
+        n = lib().fvad_vad_batch_total_segments(self.h)
+        arr = (SpeechSegment * max(n, 1))()
+        offs = (sz * (self.n_streams + 1))()
+        check(lib().fvad_vad_batch_segments(self.h, arr, max(n, 1), offs), "fvad_vad_batch_segments")
+        flat = [(a.sample_from, a.sample_to, a.avg_channel_vol_ratio, a.vad_met_sec) for a in arr[:n]]
+        return [flat[offs[s]:offs[s + 1]] for s in range(self.n_streams)]
+
+    def audit(self, stream):
+        a = VadAudit()
+        check(lib().fvad_vad_batch_audit(self.h, stream, C.byref(a)), "fvad_vad_batch_audit")
+        return a.min_rel_threshold_margin, a.min_abs_ratio_margin, a.n_frames
+
+    def close(self):
+        if self.h:
+            lib().fvad_vad_batch_destroy(self.h)
+            self.h = vp()
 
 
 def vad_run_many(machines, bands, ratios, first_index=None, fft_size=1024, n_threads=1):

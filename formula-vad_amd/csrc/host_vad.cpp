@@ -478,4 +478,103 @@ int fvad_ra_last_avg(const fvad_rolling_average* ra, double* out)
     return ra->ra.has_last_avg ? 1 : 0;
 }
 
+// ------------------------------------------------------------------ host stage for a whole batch
+// What VADPipeline does between the kernels' outputs and the segment list, for many streams at once and
+// straight from the engine's lane-major buffers: per-chunk volume ratio (BufferedVolumeAnalyzer.zig:48-69) ->
+// the two metadata hand-overs (BufferedVolumeAnalyzer.zig:33-45, BufferedDenoiser.zig:83-86,115) -> the
+// sample-weighted ratio of every FFT frame (BufferedFFT.zig:137-140,153) -> VADMachine.run per frame
+// (VADMachine.zig:138-239).  Streams are dealt to threads like simulator.zig:221-232 deals files.
+struct fvad_vad_batch {
+    fvad_vad_config cfg;
+    size_t sample_rate, n_channels, fft_size, n_streams;
+    std::vector<std::vector<fvad_speech_segment>> segs;
+    std::vector<fvad_vad_audit> audits;
+};
+
+int fvad_vad_batch_create(const fvad_vad_config* cfg, size_t sample_rate, size_t n_channels, size_t fft_size, size_t n_streams,
+                          fvad_vad_batch** out)
+{
+    if (!cfg || !out || n_channels == 0 || fft_size == 0 || sample_rate == 0 || n_streams == 0) return FVAD_ERR_INVALID_ARGUMENT;
+    if ((size_t)(((float)sample_rate / (float)fft_size) * cfg->channel_vol_ratio_avg_sec) == 0) return FVAD_ERR_INVALID_ARGUMENT;
+    auto* b = new (std::nothrow) fvad_vad_batch();
+    if (!b) return FVAD_ERR_ALLOC_FAILED;
+    b->cfg = *cfg; b->sample_rate = sample_rate; b->n_channels = n_channels; b->fft_size = fft_size; b->n_streams = n_streams;
+    b->segs.resize(n_streams);
+    b->audits.resize(n_streams);
+    *out = b;
+    return FVAD_OK;
+}
+void fvad_vad_batch_destroy(fvad_vad_batch* b) { delete b; }
+
+int fvad_vad_batch_run(fvad_vad_batch* b, const float* band, size_t band_stride, size_t n_frames, const float* chunk_rms,
+                       size_t rms_stride, size_t n_chunks, size_t chunk_size, int n_threads)
+{
+    if (!b || (n_frames && !band) || (n_chunks && !chunk_rms) || chunk_size == 0) return FVAD_ERR_INVALID_ARGUMENT;
+    if (n_frames * b->fft_size > n_chunks * chunk_size) return FVAD_ERR_INVALID_ARGUMENT; // a frame without its chunk's ratio
+    const size_t C = b->n_channels;
+    auto run_stream = [&](size_t s) {
+        fvad::VadMachine m(b->cfg, b->sample_rate, C, b->fft_size);
+        std::vector<float> ratio(n_chunks), ch(C), vols(C);
+        for (size_t k = 0; k < n_chunks; ++k) {
+            for (size_t c = 0; c < C; ++c) ch[c] = chunk_rms[(s * C + c) * rms_stride + k];
+            const fvad::MetaResult va = fvad::analyse_volume(ch.data(), C);
+            fvad::Metadata m1; m1.push(va, (float)chunk_size);
+            const fvad::MetaResult r1 = m1.to_result();
+            fvad::Metadata m2; m2.push(r1, (float)chunk_size);
+            ratio[k] = m2.to_result().volume_ratio;
+        }
+        for (size_t f = 0; f < n_frames; ++f) {
+            fvad::Metadata md;
+            const uint64_t from = (uint64_t)f * b->fft_size, to = from + b->fft_size;
+            for (uint64_t c = from / chunk_size; c * chunk_size < to; ++c) {
+                const uint64_t lo = std::max<uint64_t>(from, c * chunk_size), hi = std::min<uint64_t>(to, (c + 1) * chunk_size);
+                fvad::MetaResult r;
+                r.has_ratio = true;
+                r.volume_ratio = ratio[(size_t)c];
+                md.push(r, (float)(hi - lo));
+            }
+            const fvad::MetaResult fr = md.to_result();
+            for (size_t c = 0; c < C; ++c) vols[c] = band[(s * C + c) * band_stride + f];
+            m.run(from, vols.data(), fr.has_ratio, fr.volume_ratio);
+        }
+        b->segs[s] = std::move(m.segments);
+        b->audits[s] = m.audit;
+    };
+    const int nt = (int)std::min<size_t>((size_t)std::max(n_threads, 1), b->n_streams);
+    if (nt <= 1) { for (size_t s = 0; s < b->n_streams; ++s) run_stream(s); return FVAD_OK; }
+    std::vector<std::thread> th;
+    std::atomic<size_t> next{0};
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= b->n_streams) break; run_stream(i); } });
+    for (auto& t : th) t.join();
+    return FVAD_OK;
+}
+
+size_t fvad_vad_batch_total_segments(const fvad_vad_batch* b)
+{
+    size_t n = 0;
+    if (b) for (const auto& v : b->segs) n += v.size();
+    return n;
+}
+
+int fvad_vad_batch_segments(const fvad_vad_batch* b, fvad_speech_segment* out, size_t cap, size_t* offsets)
+{
+    if (!b || !offsets) return FVAD_ERR_INVALID_ARGUMENT;
+    size_t n = 0;
+    for (size_t s = 0; s < b->n_streams; ++s) { offsets[s] = n; n += b->segs[s].size(); }
+    offsets[b->n_streams] = n;
+    if (cap < n) return FVAD_ERR_BUFFER_TOO_SMALL;
+    if (n && !out) return FVAD_ERR_INVALID_ARGUMENT;
+    for (size_t s = 0; s < b->n_streams; ++s)
+        if (!b->segs[s].empty()) memcpy(out + offsets[s], b->segs[s].data(), b->segs[s].size() * sizeof(fvad_speech_segment));
+    return FVAD_OK;
+}
+
+int fvad_vad_batch_audit(const fvad_vad_batch* b, size_t stream, fvad_vad_audit* out)
+{
+    if (!b || !out || stream >= b->n_streams) return FVAD_ERR_INVALID_ARGUMENT;
+    *out = b->audits[stream];
+    return FVAD_OK;
+}
+
 } // extern "C"

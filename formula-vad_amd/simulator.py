@@ -173,24 +173,20 @@ def _run_instances(ctx, plan, audio):
     min_bin = int(np.round(np.float32(vm.get("speech_min_freq", 500.0)) / bin_w))
     max_bin = int(np.round(np.float32(vm.get("speech_max_freq", 2000.0)) / bin_w))
     res = ctx.engine_run(lanes, min_bin=min_bin, max_bin=max_bin)
-    machines, bands, ratios = [], [], []
+    # host stage: the library's batched form (frame metadata + VAD state machine), one call per instance
+    # (instances differ in length and channel count)
+    out = []
     k = 0
     for pcm in audio:
         C_ = pcm.shape[0]
         r = res[k:k + C_]
         k += C_
-        band = np.stack([x["band_sum"] for x in r], axis=1)
-        rms = np.stack([x["chunk_rms"] for x in r], axis=1)
-        ratios.append(frame_ratios(rms, band.shape[0], plan["fft_size"]))
-        bands.append(band)
-        machines.append(fv.VadMachine(n_channels=C_, fft_size=plan["fft_size"], overrides=vm))
-    for nch in sorted({m.n_channels for m in machines}):      # the batched driver wants one channel count
-        idx = [i for i, m in enumerate(machines) if m.n_channels == nch]
-        fv.vad_run_many([machines[i] for i in idx], [bands[i] for i in idx], [ratios[i] for i in idx],
-                        fft_size=plan["fft_size"], n_threads=min(16, len(idx)))
-    out = [(m.segments(), m.audit()) for m in machines]
-    for m in machines:
-        m.close()
+        band = np.ascontiguousarray(np.stack([x["band_sum"] for x in r]))      # [channel][frame]
+        rms = np.ascontiguousarray(np.stack([x["chunk_rms"] for x in r]))
+        vb = fv.VadBatch(1, n_channels=C_, fft_size=plan["fft_size"], overrides=vm)
+        segs = vb.run(band, rms)[0] if band.shape[1] else []
+        out.append((segs, vb.audit(0)))
+        vb.close()
     return out
 
 

@@ -318,6 +318,26 @@ int fvad_vad_run_many(fvad_vad *const *vads, size_t n_streams, const float *cons
                       const float *const *ratio, const size_t *n_frames, size_t n_channels,
                       const uint64_t *first_index, size_t fft_size, int n_threads);
 
+/* The host stage of a whole batch in one call, straight from the engine's lane-major outputs (lane = stream *
+ * n_channels + channel): per-chunk volume ratio (BufferedVolumeAnalyzer.zig:48-69), the metadata hand-overs
+ * (BufferedVolumeAnalyzer.zig:33-45, BufferedDenoiser.zig:83-86,115), the sample-weighted ratio of every FFT
+ * frame (BufferedFFT.zig:137-140,153), then VADMachine.run per frame on fresh machines (VADMachine.zig:138-239),
+ * streams dealt to n_threads host threads.  band: lane l's n_frames sums at band + l * band_stride; chunk_rms:
+ * lane l's n_chunks values at chunk_rms + l * rms_stride; chunk_size = 24000 at 48 kHz (NSNet2.zig:157-159).
+ * Bit-identical to fvad_pipeline_* / fvad_vad_run on the same numbers. */
+typedef struct fvad_vad_batch fvad_vad_batch;
+int fvad_vad_batch_create(const fvad_vad_config *cfg, size_t sample_rate, size_t n_channels,
+                          size_t fft_size, size_t n_streams, fvad_vad_batch **out);
+void fvad_vad_batch_destroy(fvad_vad_batch *b);
+int fvad_vad_batch_run(fvad_vad_batch *b, const float *band, size_t band_stride, size_t n_frames,
+                       const float *chunk_rms, size_t rms_stride, size_t n_chunks, size_t chunk_size,
+                       int n_threads);
+size_t fvad_vad_batch_total_segments(const fvad_vad_batch *b);
+/* all segments, stream after stream; offsets[s] .. offsets[s + 1] are stream s's (offsets has n_streams + 1 entries) */
+int fvad_vad_batch_segments(const fvad_vad_batch *b, fvad_speech_segment *out, size_t cap,
+                            size_t *offsets);
+int fvad_vad_batch_audit(const fvad_vad_batch *b, size_t stream, fvad_vad_audit *out);
+
 /* RollingAverage.zig:11-56 exposed for parity tests */
 typedef struct fvad_rolling_average fvad_rolling_average;
 int fvad_ra_create(size_t count, int has_initial, double initial_val, fvad_rolling_average **out);

@@ -961,3 +961,29 @@ def test_time_split_of_one_stream_is_bit_identical(fv, gpu_ctx, weights7, pkg, w
     ref.push(x[None])
     assert [(s[0], s[1]) for s in m.segments()] == [(s[0], s[1]) for s in ref.segments()] and len(ref.segments()) >= 2
     m.close()
+
+
+def test_new_entry_points_reject_bad_arguments(fv, gpu_ctx):
+    L = fv.lib()
+    st = gpu_ctx.lane_state()
+    assert L.fvad_lane_state_seek(st, 24000 * 3 + 1) == fv.FVAD_ERR_INVALID_ARGUMENT     # chunk boundaries only
+    assert L.fvad_lane_state_seek(st, 24000 * 3) == 0
+    L.fvad_lane_state_destroy(st)
+    d = gpu_ctx.device_alloc(24000 * 2 * 2 + 64)
+    db = gpu_ctx.device_alloc(4096)
+    # PCM16 device buffers must be 16-byte aligned, the lane stride a multiple of 8 samples
+    assert L.fvad_engine_enqueue_device_i16(gpu_ctx.h, d + 2, 1, 24000, 24000, None, db, None, None) == fv.FVAD_ERR_INVALID_ARGUMENT
+    assert L.fvad_engine_enqueue_device_i16(gpu_ctx.h, d, 2, 24004, 24000, None, db, None, None) == fv.FVAD_ERR_INVALID_ARGUMENT
+    assert L.fvad_engine_enqueue_device(gpu_ctx.h, None, 1, 24000, 24000, None, db, None, None) == fv.FVAD_ERR_INVALID_ARGUMENT
+    # fewer samples than one chunk: nothing to do, not an error
+    assert L.fvad_engine_enqueue_device_i16(gpu_ctx.h, d, 1, 24000, 23999, None, db, None, None) == 0
+    gpu_ctx.device_free(d)
+    gpu_ctx.device_free(db)
+    with pytest.raises(fv.FvadError):
+        fv.AudioPipeline(gpu_ctx, vad_overrides={"channel_vol_ratio_avg_sec": 0.01})      # zero-length ratio ring
+    with pytest.raises(fv.FvadError):
+        fv.AudioPipeline(gpu_ctx, alt_configs=[{"channel_vol_ratio_avg_sec": 0.0}])
+    # a lane with neither pcm nor pcm_i16
+    arr = (fv.Lane * 1)()
+    arr[0].n_samples = 24000
+    assert L.fvad_engine_run(gpu_ctx.h, arr, 1, None) == fv.FVAD_ERR_INVALID_ARGUMENT

@@ -529,6 +529,52 @@ def test_split_stream_ranges(pkg):
     assert sh.time_split_job(65, 44, 65) == (42, 65) and sh.time_split_job(65, 1, 5) == (0, 6)
 
 
+def test_new_abi_argument_errors_without_a_device(fv):
+    # entry points added in ABI version 2 reject bad arguments before touching a device
+    L = fv.lib()
+    assert L.fvad_comm_unique_id(None, 128) == fv.FVAD_ERR_INVALID_ARGUMENT
+    buf = (C.c_uint8 * 64)()
+    assert L.fvad_comm_unique_id(buf, 64) == fv.FVAD_ERR_INVALID_ARGUMENT           # needs 128 bytes
+    h = C.c_void_p()
+    big = (C.c_uint8 * 128)()
+    assert L.fvad_comm_create(None, big, 128, 1, 0, C.byref(h)) == fv.FVAD_ERR_INVALID_ARGUMENT
+    assert L.fvad_stats_allgather(None, None, None, 0, 1, None) == fv.FVAD_ERR_INVALID_ARGUMENT
+    assert L.fvad_comm_world(None) == 0 and L.fvad_comm_rank(None) == -1
+    assert L.fvad_lane_state_seek(None, 0) == fv.FVAD_ERR_INVALID_ARGUMENT
+    assert L.fvad_device_alloc(None, 16, C.byref(h)) == fv.FVAD_ERR_INVALID_ARGUMENT
+    assert L.fvad_pipeline_enable_trace(None, 1) == fv.FVAD_ERR_INVALID_ARGUMENT
+    assert L.fvad_engine_enqueue_device_i16(None, None, 1, 8, 24000, None, None, None, None) == fv.FVAD_ERR_INVALID_ARGUMENT
+
+
+def test_vad_batch_equals_oracle_pipeline(fv, pkg):
+    # fvad_vad_batch: per-chunk ratio -> metadata hand-overs -> per-frame ratio -> state machines, for several
+    # streams at once from lane-major band sums / chunk RMS.  Fed with the oracle pipeline's own band sums and RMS
+    # it must give the oracle's segments, mono and stereo
+    W = fv.synth_weights(7)
+    for nch, seeds in ((1, (40, 44)), (2, (41,))):
+        bands, rmss, want = [], [], []
+        for seed in seeds:
+            pcm, _ = pkg.synth.make_stream(80.0, seed=seed, n_channels=nch)
+            p = orc.Pipeline(W, n_channels=nch)
+            p.push(pcm)
+            bands.append(p.band_volumes().T.copy())      # [channel][frame]
+            rmss.append(p.chunk_rms().T.copy())
+            want.append([(s[0], s[1], s[2], s[3]) for s in p.segments()])
+        b = fv.VadBatch(len(seeds), n_channels=nch)
+        got = b.run(np.ascontiguousarray(np.concatenate(bands)), np.ascontiguousarray(np.concatenate(rmss)), n_threads=2)
+        assert sum(len(w) for w in want) >= 2
+        for g, w in zip(got, want):
+            assert [(x[0], x[1]) for x in g] == [(x[0], x[1]) for x in w]
+            assert all(abs(x[2] - y[2]) <= 1e-6 and x[3] == y[3] for x, y in zip(g, w))
+        assert b.audit(0)[2] == bands[0].shape[1]
+        b.close()
+    # a frame beyond the chunks that carry its ratio is refused
+    b = fv.VadBatch(1)
+    with pytest.raises(fv.FvadError):
+        b.run(np.zeros((1, 100), np.float32), np.ones((1, 1), np.float32))
+    b.close()
+
+
 def test_golden_vad_stream_segments(fv):
     # committed band volumes of a 120 s synthetic stream -> the exact segment list
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden_vad_seed40.npz"))
