@@ -987,3 +987,41 @@ def test_new_entry_points_reject_bad_arguments(fv, gpu_ctx):
     arr = (fv.Lane * 1)()
     arr[0].n_samples = 24000
     assert L.fvad_engine_run(gpu_ctx.h, arr, 1, None) == fv.FVAD_ERR_INVALID_ARGUMENT
+
+
+def test_nsnet2_saturated_gates_match_oracle(fv, weights7):
+    # The seed-7 weights keep the GRU gates in their linear range; a trained model does not.  Scaled-up INPUT
+    # weights and biases drive sigmoid / tanh deep into saturation (gate pre-activations of +-40), where the GPU's
+    # v_exp_f32 / v_rcp_f32 gate formulas must still agree with the oracle's expf / tanhf -- on the weight-
+    # stationary, the low-latency and the 12-wave recurrence.  (The recurrent matrices are left alone: scaled
+    # up they make the GRU a chaotic map in which ANY two f32 evaluations drift apart, the oracle and float64
+    # included -- that would test conditioning, not the kernels.)
+    w = {k: v.copy() for k, v in weights7.items()}
+    for k in ("gru1_w", "gru2_w"):
+        w[k] *= np.float32(8.0)
+    for k in ("gru1_b", "gru2_b"):
+        w[k] = (w[k] * np.float32(4.0) + np.float32(0.5)).astype(np.float32)
+    ctx = fv.Context(0)
+    ctx.load_weights(w)
+    rng = np.random.default_rng(31)
+    f = rng.uniform(-11, 2, (2050, 54, 161)).astype(np.float32)
+    pick = [0, 1, 2047, 2049]
+    ref = np.stack([orc.nsnet2_forward(w, f[i]) for i in pick])
+    g64 = np.stack([_nsnet2_float64(w, f[i]) for i in pick])
+    e_orc = np.abs(ref - g64).max()
+    for env in ({}, {"FVAD_GRU_KERNEL": "v4w8"}, {"FVAD_GRU_KERNEL": "v5w0"}):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            g_small = ctx.nsnet2_forward(f[:2])
+            g_big = ctx.nsnet2_forward(f)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert_rel(g_small, ref[:2], 1e-4, floor=1e-2, what=f"saturated gains, small batch {env}")
+        assert_rel(g_big[pick], ref, 1e-4, floor=1e-2, what=f"saturated gains, large batch {env}")
+        assert np.abs(g_big[pick] - g64).max() <= max(3 * e_orc, 5e-6), (env, np.abs(g_big[pick] - g64).max(), e_orc)
+    # the regime is really saturated: input pre-activations of the gates are far outside [-4, 4]
+    x = f[0] @ w["fc1_w"].T + w["fc1_b"]
+    assert np.abs(x @ w["gru1_w"].T).max() > 20
+    ctx.close()
