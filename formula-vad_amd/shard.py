@@ -54,7 +54,18 @@ def native_comm(ctx, dist):
     id, broadcast_object_list carries it (any backend), every rank joins with its context's device."""
     from . import binding as fv
     rank, world = dist.get_rank(), dist.get_world_size()
-    box = [fv.comm_unique_id() if rank == 0 else None]
+    # communicator creation is collective: make sure EVERY rank can open RCCL before any rank enters it (a rank
+    # that raised while the others wait in ncclCommInitRank would hang the job)
+    try:
+        my_id, err = fv.comm_unique_id(), None
+    except Exception as e:  # librccl missing / not loadable on this rank
+        my_id, err = None, repr(e)
+    oks = [None] * world
+    dist.all_gather_object(oks, err)
+    bad = [(r, e) for r, e in enumerate(oks) if e is not None]
+    if bad:
+        raise RuntimeError(f"RCCL unavailable on rank(s) {bad}")
+    box = [my_id if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     return fv.Comm(ctx, box[0], world, rank)
 
