@@ -91,7 +91,7 @@ class Lane(C.Structure):
 
 class EngineOpts(C.Structure):
     _fields_ = [("on_device", C.c_int32), ("min_bin", C.c_int32), ("max_bin", C.c_int32),
-                ("max_chunks_per_launch", C.c_int32)]
+                ("max_chunks_per_launch", C.c_int32), ("fft_size", C.c_int32)]
 
 
 class AudioBuffer(C.Structure):
@@ -183,7 +183,7 @@ SIGNATURES = {
     "fvad_lane_state_create": (C.c_int, [vp, C.POINTER(vp)]),
     "fvad_lane_state_reset": (None, [vp]),
     "fvad_lane_state_destroy": (None, [vp]),
-    "fvad_lane_state_seek": (C.c_int, [vp, C.c_uint64]),
+    "fvad_lane_state_seek": (C.c_int, [vp, C.c_uint64, sz]),
     "fvad_engine_opts_default": (None, [C.POINTER(EngineOpts)]),
     "fvad_engine_run": (C.c_int, [vp, C.POINTER(Lane), sz, C.POINTER(EngineOpts)]),
     "fvad_engine_enqueue_device": (C.c_int, [vp, vp, sz, sz, sz, vp, vp, vp,
@@ -389,7 +389,7 @@ class Context:
         return g
 
     def engine_run(self, lanes_pcm, want_denoised=False, want_bins=False, states=None,
-                   max_chunks_per_launch=0, min_bin=11, max_bin=43, want_taps=False, want_denoised_i16=False):
+                   max_chunks_per_launch=0, min_bin=11, max_bin=43, want_taps=False, want_denoised_i16=False, fft_size=1024):
         """lanes_pcm: list of 1-D host arrays, float32 or int16 (PCM16: converted on the GPU). Returns list of dicts."""
         n = len(lanes_pcm)
         arr = (Lane * n)()
@@ -397,11 +397,11 @@ class Context:
         for i, x in enumerate(lanes_pcm):
             x = np.ascontiguousarray(x) if np.asarray(x).dtype == np.int16 else np.ascontiguousarray(x, dtype=np.float32)
             n_chunks = x.shape[0] // 24000
-            cap_frames = (n_chunks * 24000 + 1024) // 1024 + 1
+            cap_frames = (n_chunks * 24000 + fft_size) // fft_size + 1
             band = np.zeros(cap_frames, np.float32)
             rms = np.zeros(max(n_chunks, 1), np.float32)
             den = np.zeros(n_chunks * 24000, np.float32) if want_denoised else None
-            bins = np.zeros((cap_frames, 513), np.float32) if want_bins else None
+            bins = np.zeros((cap_frames, fft_size // 2 + 1), np.float32) if want_bins else None
             spec = np.zeros((n_chunks, 50, 161, 2), np.float32) if want_taps else None
             feat = np.zeros((n_chunks, 54, 161), np.float32) if want_taps else None
             den16 = np.zeros(n_chunks * 24000, np.int16) if want_denoised_i16 else None
@@ -428,6 +428,7 @@ class Context:
         opts.max_chunks_per_launch = max_chunks_per_launch
         opts.min_bin = min_bin
         opts.max_bin = max_bin
+        opts.fft_size = fft_size
         self._ck(lib().fvad_engine_run(self.h, arr, n, C.byref(opts)), "fvad_engine_run")
         out = []
         for i in range(n):

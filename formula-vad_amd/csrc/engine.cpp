@@ -527,6 +527,31 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
     return FVAD_OK;
 }
 
+// BufferedFFT.init's window and norm (BufferedFFT.zig:95-99; window_fn.zig:22-28,8-16) plus kissfft's tables for an
+// n-point real transform, evaluated on the host in double like kissfft does, uploaded once per context and size
+int get_vad_plan(fvad_ctx* ctx, size_t n, VadFftPlan* out)
+{
+    if (!(n == 512 || n == 1024 || n == 2048))
+        return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "the VAD-side FFT has kernels for fft_size 512, 1024 (the reference default) and 2048");
+    auto it = ctx->vad_plans.find((int)n);
+    if (it == ctx->vad_plans.end()) {
+        std::vector<float> win(n), tw, st, all;
+        hann_window_periodic(win.data(), n);
+        make_twiddles((int)n / 2, tw);
+        make_super_twiddles((int)n / 2, st);
+        auto put = [&](const std::vector<float>& v) { const size_t o = all.size(); all.insert(all.end(), v.begin(), v.end()); all.resize((all.size() + 63) / 64 * 64); return o; };
+        const size_t o_w = put(win), o_tw = put(tw), o_st = put(st);
+        fvad_ctx::VadPlanDev pd;
+        FVAD_HIP(ctx, hipMalloc((void**)&pd.d, all.size() * sizeof(float)));
+        FVAD_HIP(ctx, hipMemcpy(pd.d, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
+        pd.plan = VadFftPlan{(int)n, pd.d + o_w, pd.d + o_tw, pd.d + o_st, window_norm_factor(win.data(), n) / (float)n};
+        it = ctx->vad_plans.emplace((int)n, pd).first;
+        ctx->ws.generation++;
+    }
+    *out = it->second.plan;
+    return FVAD_OK;
+}
+
 } // namespace fvad
 
 using namespace fvad;
@@ -580,21 +605,16 @@ int fvad_ctx_create(int device, fvad_ctx** out)
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return FVAD_ERR_HIP; }
 
     // constant tables: one device allocation, sub-ranges 64-float aligned
-    std::vector<float> win320(320), win320n(320), win1024(1024), tw160, st320, tw512, st1024;
+    std::vector<float> win320(320), win320n(320), tw160, st320;
     nsnet2_window(win320.data());
     const float vol_norm_factor = 1 / (float)kNFft; // NSNet2.zig:323
     for (int i = 0; i < 320; ++i) win320n[i] = win320[i] * vol_norm_factor;
-    hann_window_periodic(win1024.data(), 1024);
     make_twiddles(160, tw160);
     make_super_twiddles(160, st320);
-    make_twiddles(512, tw512);
-    make_super_twiddles(512, st1024);
     ctx->h_win320 = win320;
-    ctx->h_win1024 = win1024;
     std::vector<float> all;
     auto put = [&](const std::vector<float>& v) { const size_t o = all.size(); all.insert(all.end(), v.begin(), v.end()); all.resize((all.size() + 63) / 64 * 64); return o; };
-    const size_t o_w320 = put(win320), o_w320n = put(win320n), o_tw160 = put(tw160), o_st320 = put(st320),
-                 o_w1024 = put(win1024), o_tw512 = put(tw512), o_st1024 = put(st1024);
+    const size_t o_w320 = put(win320), o_w320n = put(win320n), o_tw160 = put(tw160), o_st320 = put(st320);
     if (hipMalloc((void**)&ctx->d_tables, all.size() * sizeof(float)) != hipSuccess ||
         hipMemcpy(ctx->d_tables, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         fvad_ctx_destroy(ctx);
@@ -604,10 +624,8 @@ int fvad_ctx_create(int device, fvad_ctx** out)
     ctx->tb.win320n = ctx->d_tables + o_w320n;
     ctx->tb.tw160 = ctx->d_tables + o_tw160;
     ctx->tb.st320 = ctx->d_tables + o_st320;
-    ctx->tb.win1024 = ctx->d_tables + o_w1024;
-    ctx->tb.tw512 = ctx->d_tables + o_tw512;
-    ctx->tb.st1024 = ctx->d_tables + o_st1024;
-    ctx->tb.norm1024 = window_norm_factor(win1024.data(), 1024) / (float)1024; // BufferedFFT.zig:99
+    VadFftPlan pl;
+    if (get_vad_plan(ctx, kVadFft, &pl) != FVAD_OK) { fvad_ctx_destroy(ctx); return FVAD_ERR_HIP; }
     *out = ctx;
     return FVAD_OK;
 }
@@ -617,6 +635,7 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->vad_plans) if (kv.second.d) hipFree(kv.second.d);
     free_workspace_nn(ctx->ws);
     Workspace& ws = ctx->ws;
     if (ws.in) hipFree(ws.in);
@@ -810,7 +829,7 @@ int fvad_lane_state_create(fvad_ctx* ctx, fvad_lane_state** out)
     s->ctx = ctx;
     for (int i = 0; i < 2; ++i)
         if (hipMalloc((void**)&s->carry[i], sizeof(LaneCarry)) != hipSuccess) { fvad_lane_state_destroy(s); return FVAD_ERR_HIP; }
-    if (hipMalloc((void**)&s->den_rem, kVadFft * sizeof(float)) != hipSuccess) { fvad_lane_state_destroy(s); return FVAD_ERR_HIP; }
+    if (hipMalloc((void**)&s->den_rem, kVadFftMax * sizeof(float)) != hipSuccess) { fvad_lane_state_destroy(s); return FVAD_ERR_HIP; }
     fvad_lane_state_reset(s);
     *out = s;
     return FVAD_OK;
@@ -822,22 +841,25 @@ void fvad_lane_state_reset(fvad_lane_state* s)
     hipSetDevice(s->ctx->device);
     // zero history == the reference's freshly initialised NSNet2 (NSNet2.zig:79,116,120,33)
     for (int i = 0; i < 2; ++i) hipMemsetAsync(s->carry[i], 0, sizeof(LaneCarry), s->ctx->stream);
-    hipMemsetAsync(s->den_rem, 0, kVadFft * sizeof(float), s->ctx->stream);
+    hipMemsetAsync(s->den_rem, 0, kVadFftMax * sizeof(float), s->ctx->stream);
     hipStreamSynchronize(s->ctx->stream);
     s->cur = 0;
     s->n_rem = 0;
+    s->fft_size = kVadFft;
     s->samples_consumed = 0;
     s->next_frame_index = 0;
 }
 
-int fvad_lane_state_seek(fvad_lane_state* s, uint64_t sample_index)
+int fvad_lane_state_seek(fvad_lane_state* s, uint64_t sample_index, size_t fft_size)
 {
-    if (!s || sample_index % kChunk48) return FVAD_ERR_INVALID_ARGUMENT;
+    if (fft_size == 0) fft_size = kVadFft;
+    if (!s || sample_index % kChunk48 || !(fft_size == 512 || fft_size == 1024 || fft_size == 2048)) return FVAD_ERR_INVALID_ARGUMENT;
     fvad_lane_state_reset(s);
-    // zero history, positioned mid-stream: the FFT-1024 frame grid stays anchored at absolute sample 0, so the first
-    // sample_index % 1024 positions of the first frame are (zero) remainder
+    // zero history, positioned mid-stream: the VAD FFT's frame grid stays anchored at absolute sample 0, so the
+    // first sample_index % fft_size positions of the first frame are (zero) remainder
     s->samples_consumed = sample_index;
-    s->n_rem = (size_t)(sample_index % kVadFft);
+    s->fft_size = fft_size;
+    s->n_rem = (size_t)(sample_index % fft_size);
     s->next_frame_index = sample_index - s->n_rem;
     return FVAD_OK;
 }
@@ -856,6 +878,7 @@ void fvad_engine_opts_default(fvad_engine_opts* o)
     o->min_bin = 11; // FFT.freqToBin(500) at 48 kHz / 1024 (FFT.zig:156-167)
     o->max_bin = 43; // FFT.freqToBin(2000)
     o->max_chunks_per_launch = 0;
+    o->fft_size = 0; // 1024
 }
 
 static int grow(fvad_ctx* ctx, float** p, size_t* cap, size_t need)
@@ -982,9 +1005,16 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
     if (!ctx || (n_lanes && !lanes)) return FVAD_ERR_INVALID_ARGUMENT;
     fvad_engine_opts opts;
     if (opts_in) opts = *opts_in; else fvad_engine_opts_default(&opts);
-    if (opts.min_bin < 0 || opts.max_bin > 512 || opts.max_bin < opts.min_bin) return set_err(ctx, FVAD_ERR_OUT_OF_RANGE, "band bins out of range");
+    const size_t F = opts.fft_size ? (size_t)opts.fft_size : (size_t)kVadFft; // VAD FFT frame length
     if (!ctx->dm.loaded) return set_err(ctx, FVAD_ERR_NO_MODEL, "NSNet2 weights not loaded");
     hipSetDevice(ctx->device);
+    VadFftPlan plan;
+    {
+        const int prc = get_vad_plan(ctx, F, &plan);
+        if (prc) return prc;
+    }
+    const size_t NB = F / 2 + 1;
+    if (opts.min_bin < 0 || opts.max_bin > (int)(F / 2) || opts.max_bin < opts.min_bin) return set_err(ctx, FVAD_ERR_OUT_OF_RANGE, "band bins out of range");
     Workspace& ws = ctx->ws;
     hipStream_t st = ctx->stream;
 
@@ -998,9 +1028,13 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
         if (opts.on_device && ((uintptr_t)L.pcm_i16 | (uintptr_t)L.denoised_i16) % 16)
             return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "device PCM16 buffers must be 16-byte aligned");
         L.n_chunks = L.n_samples / kChunk48;
+        if (L.state && L.state->fft_size != F) {
+            if (L.state->n_rem || L.state->samples_consumed) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "lane state was used with another fft_size");
+            L.state->fft_size = F;
+        }
         n_rem[l] = L.state ? L.state->n_rem : 0;
         const size_t n_den = n_rem[l] + L.n_chunks * kChunk48;
-        L.n_fft_frames = n_den / kVadFft;
+        L.n_fft_frames = n_den / F;
         L.first_frame_index = L.state ? L.state->next_frame_index : 0;
         if (L.n_fft_frames > L.band_sum_capacity || L.n_chunks > L.chunk_rms_capacity)
             return set_err(ctx, FVAD_ERR_BUFFER_TOO_SMALL, "band_sum / chunk_rms capacity too small");
@@ -1011,7 +1045,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
         den16_off[l] = den16_total;
         if (L.denoised_i16 && !opts.on_device) den16_total += (L.n_chunks * kChunk48 / 2 + 63) / 64 * 64;
         den_off[l] = den_total;
-        den_total += (kVadFft + L.n_chunks * kChunk48 + 63) / 64 * 64;
+        den_total += (kVadFftMax + L.n_chunks * kChunk48 + 63) / 64 * 64;
         band_off[l] = frames_total;
         frames_total += L.n_fft_frames;
         rms_off[l] = chunks_total;
@@ -1022,7 +1056,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
     if ((rc = grow(ctx, &ws.den, &ws.den_cap, den_total))) return rc;
     if (den16_total && (rc = grow(ctx, &ws.den16, &ws.den16_cap, den16_total))) return rc;
     if ((rc = grow(ctx, &ws.band, &ws.band_cap, frames_total + chunks_total + 64))) return rc;
-    if (want_bins && (rc = grow(ctx, &ws.bins, &ws.bins_cap, frames_total * kVadBins))) return rc;
+    if (want_bins && (rc = grow(ctx, &ws.bins, &ws.bins_cap, frames_total * NB))) return rc;
     // scratch carries for stateless lanes
     size_t n_scratch = 0;
     for (size_t l = 0; l < n_lanes; ++l) if (!lanes[l].state) n_scratch += 2;
@@ -1072,7 +1106,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
         if (L.denoised_i16) j.d_den16 = opts.on_device ? L.denoised_i16 : reinterpret_cast<int16_t*>(ws.den16 + den16_off[l]);
         // denoised region: [1024-float prefix | chunks]; the not-yet-FFT'd remainder of the previous
         // call sits right in front of the new audio so that K4 sees one contiguous signal
-        float* den_base = ws.den + den_off[l] + kVadFft;
+        float* den_base = ws.den + den_off[l] + kVadFftMax;
         j.d_den = den_base;
         j.n_chunks = L.n_chunks;
         j.d_rms = d_rms + rms_off[l];
@@ -1130,7 +1164,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
         for (size_t l = 0; l < n_lanes; ++l) {
             const fvad_lane& L = lanes[l];
             ws.h_fft_jobs[l] = {jobs[l].d_den - n_rem[l], ws.band + band_off[l],
-                                L.fft_bins ? ws.bins + band_off[l] * kVadBins : nullptr, (long)L.n_fft_frames};
+                                L.fft_bins ? ws.bins + band_off[l] * NB : nullptr, (long)L.n_fft_frames};
             max_frames = std::max(max_frames, (long)L.n_fft_frames);
         }
         if (max_frames) FVAD_HIP(ctx, hipMemcpyAsync(ws.fft_jobs, ws.h_fft_jobs, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice, st));
@@ -1142,7 +1176,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
             fvad_lane& L = lanes[l];
             if (L.n_fft_frames) {
                 d2h.push_back({L.band_sum, ws.band + band_off[l], L.n_fft_frames * sizeof(float)});
-                if (L.fft_bins) d2h.push_back({L.fft_bins, ws.bins + band_off[l] * kVadBins, L.n_fft_frames * kVadBins * sizeof(float)});
+                if (L.fft_bins) d2h.push_back({L.fft_bins, ws.bins + band_off[l] * NB, L.n_fft_frames * NB * sizeof(float)});
             }
             if (L.n_chunks) {
                 d2h.push_back({L.chunk_rms, d_rms + rms_off[l], L.n_chunks * sizeof(float)});
@@ -1197,7 +1231,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
         for (size_t l = l0; l < l1; ++l) mf = std::max(mf, (long)lanes[l].n_fft_frames);
         if (mf) {
             time_begin(ctx, "fft1024_bandsum");
-            fvad_launch_vadfft_jobs(ws.fft_jobs + l0, (int)(l1 - l0), mf, ctx->tb, opts.min_bin, opts.max_bin, st);
+            fvad_launch_vadfft_jobs(ws.fft_jobs + l0, (int)(l1 - l0), mf, plan, opts.min_bin, opts.max_bin, st);
             time_end(ctx);
         }
         for (size_t l = l0; l < l1; ++l) {
@@ -1207,12 +1241,12 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
                 FVAD_HIP(ctx, hipMemcpyAsync(L.denoised, jobs[l].d_den, L.n_chunks * kChunk48 * sizeof(float), hipMemcpyDeviceToDevice, st));
             if (L.state) {
                 const size_t n_den = n_rem[l] + L.n_chunks * kChunk48;
-                const size_t rem = n_den - L.n_fft_frames * kVadFft;
-                if (rem) FVAD_HIP(ctx, hipMemcpyAsync(L.state->den_rem, den_start + L.n_fft_frames * kVadFft, rem * sizeof(float), hipMemcpyDeviceToDevice, st));
+                const size_t rem = n_den - L.n_fft_frames * F;
+                if (rem) FVAD_HIP(ctx, hipMemcpyAsync(L.state->den_rem, den_start + L.n_fft_frames * F, rem * sizeof(float), hipMemcpyDeviceToDevice, st));
                 L.state->n_rem = rem;
                 L.state->cur = jobs[l].cur;
                 L.state->samples_consumed += L.n_chunks * kChunk48;
-                L.state->next_frame_index += L.n_fft_frames * (uint64_t)kVadFft;
+                L.state->next_frame_index += L.n_fft_frames * (uint64_t)F;
             }
         }
         if (G > 1) {
@@ -1249,9 +1283,13 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
     hipStream_t st = ctx->stream;
     const size_t n_chunks = n_samples / kChunk48;
     const size_t n_den = n_chunks * kChunk48;
-    const size_t n_frames = n_den / kVadFft;
+    const size_t F = opts.fft_size ? (size_t)opts.fft_size : (size_t)kVadFft;
+    VadFftPlan plan;
+    int rc = get_vad_plan(ctx, F, &plan);
+    if (rc) return rc;
+    if (opts.min_bin < 0 || opts.max_bin > (int)(F / 2) || opts.max_bin < opts.min_bin) return set_err(ctx, FVAD_ERR_OUT_OF_RANGE, "band bins out of range");
+    const size_t n_frames = n_den / F;
     if (n_chunks == 0) return FVAD_OK;
-    int rc;
     float* den = d_denoised;
     if (!den) {
         if ((rc = grow(ctx, &ws.den, &ws.den_cap, n_lanes * n_den))) return rc;
@@ -1301,7 +1339,7 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
         for (size_t l = 0; l < n_lanes; ++l) h_jobs[l] = {den + l * n_den, d_band_sum + l * n_frames, nullptr, (long)n_frames};
         if (!capture_descs) FVAD_HIP(ctx, hipMemcpyAsync(d_jobs, h_jobs, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice, st));
         time_begin(ctx, "fft1024_bandsum");
-        fvad_launch_vadfft_jobs(d_jobs, (int)n_lanes, (long)n_frames, ctx->tb, opts.min_bin, opts.max_bin, st);
+        fvad_launch_vadfft_jobs(d_jobs, (int)n_lanes, (long)n_frames, plan, opts.min_bin, opts.max_bin, st);
         time_end(ctx);
         return FVAD_OK;
     };
@@ -1319,7 +1357,7 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
         const void* pcm_key = d_pcm ? (const void*)d_pcm : (const void*)d_pcm16;
         const bool hit = gc.valid && gc.pcm == pcm_key && gc.den16 == d_den16 && gc.den == den && gc.band == d_band_sum && gc.rms == d_chunk_rms &&
                          gc.n_lanes == n_lanes && gc.lane_stride == lane_stride && gc.n_samples == n_samples &&
-                         gc.min_bin == opts.min_bin && gc.max_bin == opts.max_bin && gc.max_chunks == maxc &&
+                         gc.min_bin == opts.min_bin && gc.max_bin == opts.max_bin && gc.max_chunks == maxc && gc.fft_size == F &&
                          gc.generation == ws.generation;
         if (!hit) {
             hipStreamSynchronize(st);
@@ -1357,7 +1395,7 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
             FVAD_HIP(ctx, hipGraphInstantiate(&gc.exec, gc.graph, nullptr, nullptr, 0));
             gc.pcm = pcm_key; gc.den16 = d_den16; gc.den = den; gc.band = d_band_sum; gc.rms = d_chunk_rms;
             gc.n_lanes = n_lanes; gc.lane_stride = lane_stride; gc.n_samples = n_samples;
-            gc.min_bin = opts.min_bin; gc.max_bin = opts.max_bin; gc.max_chunks = maxc;
+            gc.min_bin = opts.min_bin; gc.max_bin = opts.max_bin; gc.max_chunks = maxc; gc.fft_size = F;
             gc.generation = ws.generation;
             gc.valid = true;
         }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -86,6 +87,7 @@ struct Workspace {
         size_t n_lanes = 0, lane_stride = 0, n_samples = 0;
         int min_bin = 0, max_bin = 0;
         long max_chunks = 0;
+        size_t fft_size = 0;
         unsigned generation = 0;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
@@ -116,7 +118,10 @@ struct fvad_ctx {
     // constant tables
     float* d_tables = nullptr;
     FftTables tb{};
-    std::vector<float> h_win320, h_win1024;
+    std::vector<float> h_win320;
+    // VAD-side FFT tables per size (512 / 1024 / 2048), built on first use
+    struct VadPlanDev { float* d = nullptr; VadFftPlan plan{}; };
+    std::map<int, VadPlanDev> vad_plans;
     // model
     fvad::HostWeights hw;
     fvad::DeviceModel dm;
@@ -132,8 +137,9 @@ struct fvad_lane_state {
     fvad_ctx* ctx = nullptr;
     LaneCarry* carry[2] = {nullptr, nullptr}; // device, double-buffered
     int cur = 0;
-    float* den_rem = nullptr; // device, 1024 floats: denoised samples not yet FFT'd
+    float* den_rem = nullptr; // device, kVadFftMax floats: denoised samples not yet FFT'd
     size_t n_rem = 0;
+    size_t fft_size = kVadFft; // frame length the remainder / frame index refer to
     uint64_t samples_consumed = 0; // raw samples consumed so far (multiple of 24000)
     uint64_t next_frame_index = 0; // absolute index of the next FFT frame's first sample
 };
@@ -150,6 +156,8 @@ int hip_fail(const fvad_ctx* ctx, hipError_t e, const char* what);
 int upload_model(fvad_ctx* ctx);
 int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T);
 int ensure_gru_ws(fvad_ctx* ctx);
+// tables of the n-point VAD FFT (n = 512 / 1024 / 2048), cached per context
+int get_vad_plan(fvad_ctx* ctx, size_t n, VadFftPlan* out);
 // NSNet2 on ws.feat -> ws.gains for n_chunks sequences of T rows; gains rows skip..T-1 only
 int run_nn(fvad_ctx* ctx, long n_chunks_pad, int T, int skip);
 

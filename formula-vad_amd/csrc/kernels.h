@@ -16,8 +16,8 @@ constexpr int kNBins = 161;
 constexpr int kFeatStride = 176;               // 161 padded to 11 x 16 (zero-filled tail)
 constexpr int kDown = 3;                       // 48 kHz -> 16 kHz
 constexpr int kChunk48 = kFramesPerChunk * kNHop * kDown; // 24000
-constexpr int kVadFft = 1024;
-constexpr int kVadBins = 513;
+constexpr int kVadFft = 1024;               // VADPipeline.Config.fft_size default (VADPipeline.zig:21)
+constexpr int kVadFftMax = 2048;            // sizes with a kernel: 512, 1024, 2048
 
 // cross-call carry of one lane (all device floats); mirrors NSNet2.zig:27-33 state
 struct LaneCarry {
@@ -49,7 +49,7 @@ struct ChunkDesc {
 struct VadFftJob {
     const float* den;   // first frame's first sample (device, 8-byte aligned)
     float* band_sum;    // [n_frames]
-    float* bins;        // [n_frames][513] or null
+    float* bins;        // [n_frames][n_fft/2 + 1] or null
     long n_frames;
 };
 
@@ -59,10 +59,15 @@ struct FftTables {
     const float* win320n;    // win320 * (1/320)  (NSNet2.zig:323,335)
     const float* tw160;      // [160][2] exp(-2 pi i j / 160)
     const float* st320;      // [80][2]  exp(-i pi ((k+1)/160 + 1/2))  real-FFT un-mixing
-    const float* win1024;    // periodic Hann, window_fn.zig:22-28
-    const float* tw512;      // [512][2]
-    const float* st1024;     // [256][2]
-    float norm1024;          // windowNormFactor / 1024, BufferedFFT.zig:99
+};
+
+// tables of the VAD-side real FFT of n = 512 / 1024 / 2048 samples (device), built like FftTables
+struct VadFftPlan {
+    int n;
+    const float* win;        // periodic Hann, window_fn.zig:22-28
+    const float* tw;         // [n/2][2] exp(-2 pi i j / (n/2))
+    const float* st;         // [n/4][2] real-FFT un-mixing
+    float norm;              // windowNormFactor / n, BufferedFFT.zig:99
 };
 
 int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
@@ -93,15 +98,15 @@ void fvad_launch_stft(const ChunkDesc* descs, int n_chunks, FftTables tb, float*
 void fvad_launch_istft(const ChunkDesc* descs, int n_chunks, FftTables tb, const float* spec,
                        const float* gains, int gains_rows_per_chunk, int gains_row0,
                        hipStream_t stream);
-// K4: 1024-point periodic-Hann rFFT magnitude + band sum over [min_bin, max_bin]
-void fvad_launch_vadfft(const float* den, long n_frames, FftTables tb, int min_bin, int max_bin,
+// K4: n-point periodic-Hann rFFT magnitude + band sum over [min_bin, max_bin], n = pl.n
+void fvad_launch_vadfft(const float* den, long n_frames, VadFftPlan pl, int min_bin, int max_bin,
                         float* band_sum, float* bins_or_null, hipStream_t stream);
 // all lanes in one launch: jobs is a device array of n_jobs entries, max_frames = max n_frames
-void fvad_launch_vadfft_jobs(const VadFftJob* jobs, int n_jobs, long max_frames, FftTables tb,
+void fvad_launch_vadfft_jobs(const VadFftJob* jobs, int n_jobs, long max_frames, VadFftPlan pl,
                              int min_bin, int max_bin, hipStream_t stream);
-// batched FFT.fft for B3 / BASELINE config 2: n_fft in {320, 1024}
+// batched FFT.fft for B3 / BASELINE config 2: n_fft in {320, 512, 1024, 2048} (pl is used for n_fft != 320)
 void fvad_launch_rfft_batch(const float* frames, long n_frames, int n_fft, const float* window,
-                            FftTables tb, float* bins_or_null, float* mag_or_null,
+                            FftTables tb, VadFftPlan pl, float* bins_or_null, float* mag_or_null,
                             hipStream_t stream);
 void fvad_launch_irfft_batch(const float* bins, long n_frames, FftTables tb, float* out,
                              hipStream_t stream);

@@ -93,9 +93,47 @@ template <bool INV> __device__ __forceinline__ void dft8(cpx (&v)[8])
     v[1] = b0; v[3] = b1; v[5] = b2; v[7] = b3;
 }
 
+// 16 points as 4 x 4: X[k1 + 4 k2] = sum_n2 W4^{n2 k2} ( W16^{n2 k1} sum_n1 x[4 n1 + n2] W4^{n1 k1} )
+template <bool INV> __device__ __forceinline__ void dft16(cpx (&v)[16])
+{
+    // W16^m = (cos, -+sin)(2 pi m / 16), constants rounded from double
+    const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+    auto w16 = [&](int m) -> cpx {
+        cpx w;
+        switch (m) {
+        case 1: w = {c1, -s1}; break;
+        case 2: w = {h, -h}; break;
+        case 3: w = {s1, -c1}; break;
+        case 4: w = {0.0f, -1.0f}; break;
+        case 6: w = {-h, -h}; break;
+        default: w = {-c1, s1}; break; // m = 9
+        }
+        return INV ? cconj(w) : w;
+    };
+    cpx t[4][4];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) {
+        cpx a = v[n2], b = v[4 + n2], c = v[8 + n2], d = v[12 + n2];
+        dft4<INV>(a, b, c, d);
+        t[n2][0] = a; t[n2][1] = b; t[n2][2] = c; t[n2][3] = d;
+    }
+#pragma unroll
+    for (int n2 = 1; n2 < 4; ++n2)
+#pragma unroll
+        for (int k1 = 1; k1 < 4; ++k1) t[n2][k1] = (n2 * k1 == 4) ? mul_mi<INV>(t[n2][k1]) : cmul(t[n2][k1], w16(n2 * k1));
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+        cpx a = t[0][k1], b = t[1][k1], c = t[2][k1], d = t[3][k1];
+        dft4<INV>(a, b, c, d);
+        v[k1] = a; v[k1 + 4] = b; v[k1 + 8] = c; v[k1 + 12] = d;
+    }
+}
+
 template <int R, bool INV> __device__ __forceinline__ void reg_dft(cpx (&v)[R])
 {
     if constexpr (R == 5) dft5<INV>(v);
+    else if constexpr (R == 4) dft4<INV>(v[0], v[1], v[2], v[3]);
+    else if constexpr (R == 16) dft16<INV>(v);
     else dft8<INV>(v);
 }
 
@@ -646,58 +684,65 @@ void fvad_launch_istft(const ChunkDesc* descs, int n_chunks, FftTables tb, const
                        gains_rows_per_chunk, gains_row0);
 }
 
-// ============================================================================ K4 / rfft-1024
-// One wavefront per 1024-sample frame.  mode: band sum only, or full 513 magnitudes / bins too.
-__device__ __forceinline__ void rfft1024_wave(const float* __restrict__ x, const float* __restrict__ win,
-                                              const FftTables& tb, float* zl /*LDS [1024]*/, int lane)
+// ============================================================================ K4 / rfft-N, N = 128 R
+// One wavefront per frame of N = 512 / 1024 / 2048 samples (VADPipeline.Config.fft_size, VADPipeline.zig:21; the
+// reference default is 1024): complex transform of length N/2 = R x 64 lanes, R = 4 / 8 / 16.
+// mode: band sum only, or full N/2 + 1 magnitudes / bins too.
+template <int R>
+__device__ __forceinline__ void rfftN_wave(const float* __restrict__ x, const float* __restrict__ win,
+                                           const VadFftPlan& pl, float* zl /*LDS [128 R]*/, int lane)
 {
-    LaneTw<8, 64> tw;
-    lane_tw_load<8, 64, false>(tw, tb.tw512, lane);
-    cpx v[8];
+    LaneTw<R, 64> tw;
+    lane_tw_load<R, 64, false>(tw, pl.tw, lane);
+    cpx v[R];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < R; ++j) {
         const int n = 2 * (lane + 64 * j);
         const float2 xv = *reinterpret_cast<const float2*>(x + n);
         const float2 wv = *reinterpret_cast<const float2*>(win + n);
         v[j] = {xv.x * wv.x, xv.y * wv.y};
     }
-    wave_fft<8, 64, false>(v, tw, lane);
+    wave_fft<R, 64, false>(v, tw, lane);
     const int k2 = bitrev_lane<64>(lane);
 #pragma unroll
-    for (int k1 = 0; k1 < 8; ++k1) {
-        const int k = k1 + 8 * k2;
+    for (int k1 = 0; k1 < R; ++k1) {
+        const int k = k1 + R * k2;
         zl[2 * k] = v[k1].r;
         zl[2 * k + 1] = v[k1].i;
     }
 }
 
-// X[k], 0 <= k <= 512, from the complex transform in LDS
-__device__ __forceinline__ cpx rfft1024_bin(const float* zl, const float* st, int k)
+// X[k], 0 <= k <= N/2, from the complex transform (length NC = N/2) in LDS
+template <int R>
+__device__ __forceinline__ cpx rfftN_bin(const float* zl, const float* st, int k)
 {
+    constexpr int NC = 64 * R;
     if (k == 0) return {zl[0] + zl[1], 0.0f};
-    if (k == 512) return {zl[0] - zl[1], 0.0f};
-    const int kk = k <= 256 ? k : 512 - k;
+    if (k == NC) return {zl[0] - zl[1], 0.0f};
+    const int kk = k <= NC / 2 ? k : NC - k;
     cpx xk, xnk;
-    unmix_fwd({zl[2 * kk], zl[2 * kk + 1]}, {zl[2 * (512 - kk)], zl[2 * (512 - kk) + 1]},
+    unmix_fwd({zl[2 * kk], zl[2 * kk + 1]}, {zl[2 * (NC - kk)], zl[2 * (NC - kk) + 1]},
               {st[2 * (kk - 1)], st[2 * (kk - 1) + 1]}, xk, xnk);
-    return (k < 256) ? xk : xnk; // k == 256: the X[ncfft-k] form is written last in kissfft
+    return (k < NC / 2) ? xk : xnk; // k == NC/2: the X[ncfft-k] form is written last in kissfft
 }
 
+template <int R>
 __device__ __forceinline__ void vadfft_body(const float* __restrict__ den, long n_frames, long frame,
-                                            const FftTables& tb, int min_bin, int max_bin,
+                                            const VadFftPlan& pl, int min_bin, int max_bin,
                                             float* __restrict__ band_sum, float* __restrict__ bins_out,
-                                            float (*zl)[1024], float (*mag)[64])
+                                            float (*zl)[128 * R], float (*mag)[64])
 {
+    constexpr int N = 128 * R, NB = N / 2 + 1;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const bool active = frame < n_frames;
-    if (active) rfft1024_wave(den + frame * kVadFft, tb.win1024, tb, zl[wave], lane);
+    if (active) rfftN_wave<R>(den + frame * N, pl.win, pl, zl[wave], lane);
     __syncthreads();
-    const float norm = tb.norm1024;
+    const float norm = pl.norm;
     if (active && bins_out) {
-        for (int k = lane; k < kVadBins; k += 64) {
-            const cpx xk = rfft1024_bin(zl[wave], tb.st1024, k);
-            bins_out[frame * kVadBins + k] = sqrtf(xk.r * xk.r + xk.i * xk.i) * norm; // FFT.zig:16-18
+        for (int k = lane; k < NB; k += 64) {
+            const cpx xk = rfftN_bin<R>(zl[wave], pl.st, k);
+            bins_out[frame * NB + k] = sqrtf(xk.r * xk.r + xk.i * xk.i) * norm; // FFT.zig:16-18
         }
     }
     const int nb = max_bin - min_bin + 1;
@@ -706,7 +751,7 @@ __device__ __forceinline__ void vadfft_body(const float* __restrict__ den, long 
     for (int base = 0; base < nb; base += 64) {
         const int k = min_bin + base + lane;
         if (active && base + lane < nb) {
-            const cpx xk = rfft1024_bin(zl[wave], tb.st1024, k);
+            const cpx xk = rfftN_bin<R>(zl[wave], pl.st, k);
             mag[wave][lane] = sqrtf(xk.r * xk.r + xk.i * xk.i) * norm;
         }
         __syncthreads();
@@ -719,63 +764,75 @@ __device__ __forceinline__ void vadfft_body(const float* __restrict__ den, long 
     if (active && lane == 0) band_sum[frame] = acc;
 }
 
+template <int R>
 __global__ __launch_bounds__(256) void vadfft_kernel(const float* __restrict__ den, long n_frames,
-                                                     FftTables tb, int min_bin, int max_bin,
+                                                     VadFftPlan pl, int min_bin, int max_bin,
                                                      float* __restrict__ band_sum,
                                                      float* __restrict__ bins_out)
 {
-    __shared__ __attribute__((aligned(16))) float zl[4][1024];
+    __shared__ __attribute__((aligned(16))) float zl[4][128 * R];
     __shared__ float mag[4][64];
     const long frame = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    vadfft_body(den, n_frames, frame, tb, min_bin, max_bin, band_sum, bins_out, zl, mag);
+    vadfft_body<R>(den, n_frames, frame, pl, min_bin, max_bin, band_sum, bins_out, zl, mag);
 }
 
-__global__ __launch_bounds__(256) void vadfft_jobs_kernel(const VadFftJob* __restrict__ jobs, FftTables tb,
+template <int R>
+__global__ __launch_bounds__(256) void vadfft_jobs_kernel(const VadFftJob* __restrict__ jobs, VadFftPlan pl,
                                                           int min_bin, int max_bin)
 {
-    __shared__ __attribute__((aligned(16))) float zl[4][1024];
+    __shared__ __attribute__((aligned(16))) float zl[4][128 * R];
     __shared__ float mag[4][64];
     const VadFftJob j = jobs[blockIdx.y];
     if ((long)blockIdx.x * 4 >= j.n_frames) return; // whole workgroup past this lane's frames
     const long frame = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    vadfft_body(j.den, j.n_frames, frame, tb, min_bin, max_bin, j.band_sum, j.bins, zl, mag);
+    vadfft_body<R>(j.den, j.n_frames, frame, pl, min_bin, max_bin, j.band_sum, j.bins, zl, mag);
 }
 
-void fvad_launch_vadfft(const float* den, long n_frames, FftTables tb, int min_bin, int max_bin,
+#define VADFFT_DISPATCH(n, CALL)            \
+    switch (n) {                            \
+    case 512: { constexpr int R = 4; CALL; break; }   \
+    case 1024: { constexpr int R = 8; CALL; break; }  \
+    case 2048: { constexpr int R = 16; CALL; break; } \
+    default: break;                         \
+    }
+
+void fvad_launch_vadfft(const float* den, long n_frames, VadFftPlan pl, int min_bin, int max_bin,
                         float* band_sum, float* bins_or_null, hipStream_t stream)
 {
     if (n_frames <= 0) return;
-    hipLaunchKernelGGL(vadfft_kernel, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0, stream, den,
-                       n_frames, tb, min_bin, max_bin, band_sum, bins_or_null);
+    VADFFT_DISPATCH(pl.n, hipLaunchKernelGGL(vadfft_kernel<R>, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0, stream, den,
+                                              n_frames, pl, min_bin, max_bin, band_sum, bins_or_null))
 }
 
-void fvad_launch_vadfft_jobs(const VadFftJob* jobs, int n_jobs, long max_frames, FftTables tb,
+void fvad_launch_vadfft_jobs(const VadFftJob* jobs, int n_jobs, long max_frames, VadFftPlan pl,
                              int min_bin, int max_bin, hipStream_t stream)
 {
     if (n_jobs <= 0 || max_frames <= 0) return;
-    hipLaunchKernelGGL(vadfft_jobs_kernel, dim3((unsigned)((max_frames + 3) / 4), (unsigned)n_jobs), dim3(256), 0,
-                       stream, jobs, tb, min_bin, max_bin);
+    VADFFT_DISPATCH(pl.n, hipLaunchKernelGGL(vadfft_jobs_kernel<R>, dim3((unsigned)((max_frames + 3) / 4), (unsigned)n_jobs), dim3(256), 0,
+                                              stream, jobs, pl, min_bin, max_bin))
 }
 
 // ============================================================================ batched FFT.fft
-__global__ __launch_bounds__(256) void rfft1024_batch_kernel(const float* __restrict__ frames,
-                                                             long n_frames,
-                                                             const float* __restrict__ window,
-                                                             FftTables tb, float* __restrict__ bins,
-                                                             float* __restrict__ mag)
+template <int R>
+__global__ __launch_bounds__(256) void rfftN_batch_kernel(const float* __restrict__ frames,
+                                                          long n_frames,
+                                                          const float* __restrict__ window,
+                                                          VadFftPlan pl, float* __restrict__ bins,
+                                                          float* __restrict__ mag)
 {
-    __shared__ __attribute__((aligned(16))) float zl[4][1024];
+    constexpr int N = 128 * R, NB = N / 2 + 1;
+    __shared__ __attribute__((aligned(16))) float zl[4][N];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const long frame = (long)blockIdx.x * 4 + wave;
     const bool active = frame < n_frames;
-    if (active) rfft1024_wave(frames + frame * kVadFft, window, tb, zl[wave], lane);
+    if (active) rfftN_wave<R>(frames + frame * N, window, pl, zl[wave], lane);
     __syncthreads();
     if (!active) return;
-    for (int k = lane; k < kVadBins; k += 64) {
-        const cpx xk = rfft1024_bin(zl[wave], tb.st1024, k);
-        if (bins) { bins[(frame * kVadBins + k) * 2] = xk.r; bins[(frame * kVadBins + k) * 2 + 1] = xk.i; }
-        if (mag) mag[frame * kVadBins + k] = sqrtf(xk.r * xk.r + xk.i * xk.i);
+    for (int k = lane; k < NB; k += 64) {
+        const cpx xk = rfftN_bin<R>(zl[wave], pl.st, k);
+        if (bins) { bins[(frame * NB + k) * 2] = xk.r; bins[(frame * NB + k) * 2 + 1] = xk.i; }
+        if (mag) mag[frame * NB + k] = sqrtf(xk.r * xk.r + xk.i * xk.i);
     }
 }
 
@@ -924,13 +981,13 @@ __global__ __launch_bounds__(256, RB_OCC) void rfft320_batch_kernel(const float*
 }
 
 void fvad_launch_rfft_batch(const float* frames, long n_frames, int n_fft, const float* window,
-                            FftTables tb, float* bins_or_null, float* mag_or_null,
+                            FftTables tb, VadFftPlan pl, float* bins_or_null, float* mag_or_null,
                             hipStream_t stream)
 {
     if (n_frames <= 0) return;
-    if (n_fft == kVadFft) {
-        hipLaunchKernelGGL(rfft1024_batch_kernel, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0,
-                           stream, frames, n_frames, window, tb, bins_or_null, mag_or_null);
+    if (n_fft != kNFft) {
+        VADFFT_DISPATCH(n_fft, hipLaunchKernelGGL(rfftN_batch_kernel<R>, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0,
+                                                  stream, frames, n_frames, window, pl, bins_or_null, mag_or_null))
     } else {
         long groups = (n_frames + 15) / 16; // 4 wavefronts x 4 frames per workgroup and iteration
         if (groups > 2048) groups = 2048;

@@ -24,6 +24,7 @@ struct fvad_fft {
     float* d_win = nullptr;  // n_fft
     float* d_out = nullptr;  // (n_fft/2+1)*2
     std::vector<float> h_in;
+    VadFftPlan plan{};       // tables of the 512 / 1024 / 2048-point transform (unused for 320)
 };
 
 extern "C" {
@@ -32,12 +33,17 @@ int fvad_fft_create(fvad_ctx* ctx, size_t n_fft, size_t sample_rate, int mode_in
 {
     if (!ctx || !out) return FVAD_ERR_INVALID_ARGUMENT;
     if (n_fft == 0 || n_fft % 2 != 0) return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "n_fft must be even and non-zero"); // FFT.zig:41-43
-    if (!(n_fft == 320 || (n_fft == 1024 && !mode_inverse)))
-        return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "gfx950 kernels exist for the sizes the pipeline uses: 320 (fwd/inv) and 1024 (fwd)");
+    const bool vad_size = n_fft == 512 || n_fft == 1024 || n_fft == 2048;
+    if (!(n_fft == 320 || (vad_size && !mode_inverse)))
+        return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "gfx950 kernels exist for the sizes the pipeline uses: 320 (fwd/inv) and 512 / 1024 / 2048 (fwd)");
     hipSetDevice(ctx->device);
     auto* f = new (std::nothrow) fvad_fft();
     if (!f) return FVAD_ERR_ALLOC_FAILED;
     f->ctx = ctx; f->n_fft = n_fft; f->sample_rate = sample_rate; f->inverse = mode_inverse != 0;
+    if (vad_size) {
+        const int prc = get_vad_plan(ctx, n_fft, &f->plan);
+        if (prc) { delete f; return prc; }
+    }
     f->h_in.resize(n_fft);
     if (hipMalloc((void**)&f->d_in, n_fft * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&f->d_win, n_fft * sizeof(float)) != hipSuccess ||
@@ -96,7 +102,7 @@ int fvad_fft_forward(fvad_fft* f, const float* first, size_t n_first, const floa
     hipStream_t st = ctx->stream;
     FVAD_HIP(ctx, hipMemcpyAsync(f->d_in, f->h_in.data(), f->n_fft * sizeof(float), hipMemcpyHostToDevice, st));
     FVAD_HIP(ctx, hipMemcpyAsync(f->d_win, window, f->n_fft * sizeof(float), hipMemcpyHostToDevice, st));
-    fvad_launch_rfft_batch(f->d_in, 1, (int)f->n_fft, f->d_win, ctx->tb, f->d_out, nullptr, st);
+    fvad_launch_rfft_batch(f->d_in, 1, (int)f->n_fft, f->d_win, ctx->tb, f->plan, f->d_out, nullptr, st);
     FVAD_HIP(ctx, hipMemcpyAsync(bins, f->d_out, n_bins * sizeof(fvad_complex), hipMemcpyDeviceToHost, st));
     FVAD_HIP(ctx, hipStreamSynchronize(st));
     return FVAD_OK;
@@ -130,7 +136,7 @@ int fvad_fft_forward_batch(fvad_fft* f, const float* frames, size_t n_frames, co
     hipStream_t st = ctx->stream;
     const size_t nb = fvad_fft_bin_count(f);
     if (on_device) {
-        fvad_launch_rfft_batch(frames, (long)n_frames, (int)f->n_fft, window, ctx->tb, (float*)bins, magnitudes, st);
+        fvad_launch_rfft_batch(frames, (long)n_frames, (int)f->n_fft, window, ctx->tb, f->plan, (float*)bins, magnitudes, st);
         FVAD_HIP(ctx, hipGetLastError());
         return FVAD_OK;
     }
@@ -145,7 +151,7 @@ int fvad_fft_forward_batch(fvad_fft* f, const float* frames, size_t n_frames, co
     }
     hipMemcpyAsync(d_fr, frames, n_frames * f->n_fft * sizeof(float), hipMemcpyHostToDevice, st);
     hipMemcpyAsync(f->d_win, window, f->n_fft * sizeof(float), hipMemcpyHostToDevice, st);
-    fvad_launch_rfft_batch(d_fr, (long)n_frames, (int)f->n_fft, f->d_win, ctx->tb, d_bins, d_mag, st);
+    fvad_launch_rfft_batch(d_fr, (long)n_frames, (int)f->n_fft, f->d_win, ctx->tb, f->plan, d_bins, d_mag, st);
     if (bins) hipMemcpyAsync(bins, d_bins, n_frames * nb * 2 * sizeof(float), hipMemcpyDeviceToHost, st);
     if (magnitudes) hipMemcpyAsync(magnitudes, d_mag, n_frames * nb * sizeof(float), hipMemcpyDeviceToHost, st);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) rc = set_err(ctx, FVAD_ERR_HIP, "batched FFT failed");
@@ -361,7 +367,8 @@ int fvad_pipeline_create(fvad_ctx* ctx, const fvad_pipeline_config* cfg, const f
     if (!ctx || !cfg || !out) return FVAD_ERR_INVALID_ARGUMENT;
     if (cfg->sample_rate != 48000) return set_err(ctx, FVAD_ERR_INVALID_SAMPLE_RATE, "VADPipeline needs 48000 Hz"); // VADPipeline.zig:55-58
     if (cfg->fft_size == 0 || cfg->fft_size % 2 != 0) return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "fft_size must be even"); // FFT.zig:41-43
-    if (cfg->fft_size != 1024) return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "the VAD-side kernel is built for fft_size = 1024 (the reference default)");
+    if (!(cfg->fft_size == 512 || cfg->fft_size == 1024 || cfg->fft_size == 2048))
+        return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "the VAD-side kernel exists for fft_size 512, 1024 (the reference default) and 2048");
     if (cfg->n_channels == 0) return FVAD_ERR_INVALID_ARGUMENT;
     if (!ctx->dm.loaded) return set_err(ctx, FVAD_ERR_NO_MODEL, "load the NSNet2 model into the context first");
     auto p = std::unique_ptr<fvad_pipeline>(new (std::nothrow) fvad_pipeline());
@@ -462,6 +469,7 @@ int fvad_pipeline_push_samples(fvad_pipeline* p, const float* const* channel_pcm
         fvad_engine_opts_default(&opts);
         opts.min_bin = (int32_t)p->min_bin;
         opts.max_bin = (int32_t)p->max_bin;
+        opts.fft_size = (int32_t)p->cfg.fft_size;
         const int rc = fvad_engine_run(ctx, lanes.data(), C, &opts);
         if (rc) { // nothing was consumed: the lane states only advance when the call succeeds
             for (size_t c = 0; c < C; ++c) p->pending[c].resize(p->pending[c].size() - n_samples);

@@ -111,7 +111,7 @@ def run_time_split_rank(ctx, pcm, c0, c1, want_denoised=True):
     start, stop = time_split_job(n_chunks, c0, c1)
     st = ctx.lane_state()
     try:
-        fv.check(fv.lib().fvad_lane_state_seek(st, start * CHUNK), "fvad_lane_state_seek")
+        fv.check(fv.lib().fvad_lane_state_seek(st, start * CHUNK, FFT), "fvad_lane_state_seek")
         o = ctx.engine_run([pcm[start * CHUNK: stop * CHUNK]], states=[st], want_denoised=want_denoised)[0]
     finally:
         fv.lib().fvad_lane_state_destroy(st)

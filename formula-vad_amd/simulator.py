@@ -172,7 +172,7 @@ def _run_instances(ctx, plan, audio):
     bin_w = np.float32(48000) / np.float32(plan["fft_size"])  # band edges: FFT.freqToBin (FFT.zig:156-167)
     min_bin = int(np.round(np.float32(vm.get("speech_min_freq", 500.0)) / bin_w))
     max_bin = int(np.round(np.float32(vm.get("speech_max_freq", 2000.0)) / bin_w))
-    res = ctx.engine_run(lanes, min_bin=min_bin, max_bin=max_bin)
+    res = ctx.engine_run(lanes, min_bin=min_bin, max_bin=max_bin, fft_size=plan["fft_size"])
     # host stage: the library's batched form (frame metadata + VAD state machine), one call per instance
     # (instances differ in length and channel count)
     out = []

@@ -138,7 +138,8 @@ void fvad_weights_free(void *owner);
 typedef struct { float r, i; } fvad_complex; /* FFT.zig:12-14 */
 typedef struct fvad_fft fvad_fft;
 
-/* FFT.init(allocator, n_fft, sample_rate, mode_inverse)  FFT.zig:35-76.  GPU sizes: 320, 1024. */
+/* FFT.init(allocator, n_fft, sample_rate, mode_inverse)  FFT.zig:35-76.  GPU sizes: 320 (forward and inverse: NSNet2's
+ * STFT) and 512 / 1024 / 2048 (forward: the VAD-side transform, VADPipeline.Config.fft_size). */
 int fvad_fft_create(fvad_ctx *ctx, size_t n_fft, size_t sample_rate, int mode_inverse,
                     fvad_fft **out);
 void fvad_fft_destroy(fvad_fft *fft);                                   /* FFT.deinit :78-83 */
@@ -196,10 +197,10 @@ void fvad_lane_state_destroy(fvad_lane_state *s);
  * 160-sample input hop, the 4 warm-up feature rows, the overlap-add tail and the upsampler's last sample
  * (NSNet2.zig:27-33,188-203), all functions of the previous chunk and of the 4 last frames of the one before.  A
  * lane that starts TWO chunks early from zero history (this call, sample_index = 24000 * (c0 - 2)) is therefore
- * bit-identical to the unsplit stream from chunk c0 on; the FFT-1024 frame grid stays anchored at sample 0
+ * bit-identical to the unsplit stream from chunk c0 on; the VAD FFT's frame grid stays anchored at sample 0
  * (first_frame_index of the next fvad_engine_run says where the lane's first frame starts).  The caller drops
  * the two warm-up chunks and the frames that start before 24000 * c0.  sample_index: a multiple of 24000. */
-int fvad_lane_state_seek(fvad_lane_state *s, uint64_t sample_index);
+int fvad_lane_state_seek(fvad_lane_state *s, uint64_t sample_index, size_t fft_size /* 0 = 1024 */);
 
 typedef struct {
     const float *pcm;        /* n_samples f32 @48 kHz (host or device, see on_device); NULL: use pcm_i16 */
@@ -232,6 +233,9 @@ typedef struct {
     int32_t min_bin;         /* band edges, inclusive; default 11..43 = freqToBin(500/2000) */
     int32_t max_bin;
     int32_t max_chunks_per_launch; /* 0 = default (49152) */
+    int32_t fft_size;        /* frame length of the VAD-side FFT (VADPipeline.Config.fft_size, VADPipeline.zig:21):
+                                512, 1024 or 2048; 0 = 1024.  min_bin / max_bin index that transform's bins and
+                                fft_bins rows have fft_size / 2 + 1 entries */
 } fvad_engine_opts;
 void fvad_engine_opts_default(fvad_engine_opts *o);
 
@@ -377,7 +381,7 @@ typedef struct {
     size_t n_channels;
     size_t buffer_length;                     /* 0 = sample_rate * 10 (:46) */
     int32_t skip_processing;
-    size_t fft_size;                          /* VADPipeline.Config.fft_size = 1024 (:21) */
+    size_t fft_size;                          /* VADPipeline.Config.fft_size = 1024 (:21); 512 and 2048 also have kernels */
     fvad_vad_config vad_machine_config;       /* :22 */
     const fvad_vad_config *alt_vad_machine_configs; /* :24 */
     size_t n_alt_vad_machine_configs;

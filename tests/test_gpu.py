@@ -625,6 +625,9 @@ def test_pipeline_errors_and_skip_processing(fv, gpu_ctx):
     with pytest.raises(fv.FvadError) as e:
         fv.AudioPipeline(gpu_ctx, fft_size=1023)
     assert e.value.status == -1
+    with pytest.raises(fv.FvadError) as e:
+        fv.AudioPipeline(gpu_ctx, fft_size=4096)   # even, but no kernel: 512 / 1024 / 2048 only
+    assert e.value.status == -1
     p = fv.AudioPipeline(gpu_ctx, skip_processing=True)
     assert p.push_samples(np.zeros((1, 50000), np.float32)) == 0
     assert p.push_samples(np.zeros((1, 10), np.float32)) == 50000
@@ -966,8 +969,8 @@ def test_time_split_of_one_stream_is_bit_identical(fv, gpu_ctx, weights7, pkg, w
 def test_new_entry_points_reject_bad_arguments(fv, gpu_ctx):
     L = fv.lib()
     st = gpu_ctx.lane_state()
-    assert L.fvad_lane_state_seek(st, 24000 * 3 + 1) == fv.FVAD_ERR_INVALID_ARGUMENT     # chunk boundaries only
-    assert L.fvad_lane_state_seek(st, 24000 * 3) == 0
+    assert L.fvad_lane_state_seek(st, 24000 * 3 + 1, 0) == fv.FVAD_ERR_INVALID_ARGUMENT     # chunk boundaries only
+    assert L.fvad_lane_state_seek(st, 24000 * 3, 1024) == 0 and L.fvad_lane_state_seek(st, 0, 1000) == fv.FVAD_ERR_INVALID_ARGUMENT
     L.fvad_lane_state_destroy(st)
     d = gpu_ctx.device_alloc(24000 * 2 * 2 + 64)
     db = gpu_ctx.device_alloc(4096)
@@ -1025,3 +1028,41 @@ def test_nsnet2_saturated_gates_match_oracle(fv, weights7):
     x = f[0] @ w["fc1_w"].T + w["fc1_b"]
     assert np.abs(x @ w["gru1_w"].T).max() > 20
     ctx.close()
+
+
+# ------------------------------------------------------------------ VADPipeline.Config.fft_size (VADPipeline.zig:21)
+@pytest.mark.parametrize("fft_size", [512, 2048])
+def test_pipeline_other_fft_sizes_match_oracle(fv, gpu_ctx, weights7, pkg, fft_size):
+    # fft_size is a user field of the reference's VADPipeline.Config: besides the default 1024 the VAD-side
+    # transform has kernels for 512 and 2048 (band edges, frame indices, metadata weights and the state machine's
+    # ring lengths all follow it).  Stereo stream, uneven pushes, segments bit-identical to the oracle.
+    pcm, _ = pkg.synth.make_stream(70.0, seed=48, n_channels=2)
+    ref = orc.Pipeline(weights7, n_channels=2, fft_size=fft_size)
+    ref.push(pcm)
+    p = fv.AudioPipeline(gpu_ctx, n_channels=2, fft_size=fft_size)
+    pos = 0
+    for step in (30000, 1000, 500000, 10**9):
+        nxt = min(pcm.shape[1], pos + step)
+        assert p.push_samples(pcm[:, pos:nxt]) == pos
+        pos = nxt
+    band, ratio = p.trace()
+    assert band.shape == ref.band_volumes().shape and band.shape[0] == (pcm.shape[1] // 24000 * 24000) // fft_size
+    assert_rel(band, ref.band_volumes(), 1e-4, what=f"band volumes fft {fft_size}")
+    assert_rel(ratio, ref.frame_vol_ratio(), 1e-4, what="volume ratio")
+    segs, segs_ref = p.segments(), ref.segments()
+    assert len(segs_ref) >= 2 and [(s[0], s[1]) for s in segs] == [(s[0], s[1]) for s in segs_ref]
+    # the FFT object of that size (B3) and the engine's full-spectrum tap
+    f = fv.FFT(gpu_ctx, fft_size, 48000)
+    wp = orc.hann_periodic(fft_size)
+    x = np.random.default_rng(5).uniform(-1, 1, (9, fft_size)).astype(np.float32)
+    b, m = f.fft_batch(x, wp)
+    assert_bins_close(b, np.stack([orc.rfft(r * wp) for r in x]), f"rfft{fft_size} batch")
+    assert_bins_close(f.fft(x[0], wp), orc.rfft(x[0] * wp), f"rfft{fft_size}")
+    f.close()
+    lane = pcm[0][: 3 * 24000].copy()
+    o = gpu_ctx.engine_run([lane], want_bins=True, fft_size=fft_size, min_bin=5, max_bin=20)[0]
+    r1 = orc.Pipeline(weights7, n_channels=1, keep_denoised=True, fft_size=fft_size)
+    r1.push(lane[None])
+    bins_ref = np.stack([r1.fft_bins(k) for k in range(o["n_fft_frames"])])
+    assert o["fft_bins"].shape == bins_ref.shape == (72000 // fft_size, fft_size // 2 + 1)
+    assert_rel(o["fft_bins"], bins_ref, 1e-4, floor=1e-3 * bins_ref.max(), what="|X| tap")

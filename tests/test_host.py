@@ -540,7 +540,7 @@ def test_new_abi_argument_errors_without_a_device(fv):
     assert L.fvad_comm_create(None, big, 128, 1, 0, C.byref(h)) == fv.FVAD_ERR_INVALID_ARGUMENT
     assert L.fvad_stats_allgather(None, None, None, 0, 1, None) == fv.FVAD_ERR_INVALID_ARGUMENT
     assert L.fvad_comm_world(None) == 0 and L.fvad_comm_rank(None) == -1
-    assert L.fvad_lane_state_seek(None, 0) == fv.FVAD_ERR_INVALID_ARGUMENT
+    assert L.fvad_lane_state_seek(None, 0, 0) == fv.FVAD_ERR_INVALID_ARGUMENT
     assert L.fvad_device_alloc(None, 16, C.byref(h)) == fv.FVAD_ERR_INVALID_ARGUMENT
     assert L.fvad_pipeline_enable_trace(None, 1) == fv.FVAD_ERR_INVALID_ARGUMENT
     assert L.fvad_engine_enqueue_device_i16(None, None, 1, 8, 24000, None, None, None, None) == fv.FVAD_ERR_INVALID_ARGUMENT
