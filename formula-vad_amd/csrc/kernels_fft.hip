@@ -881,7 +881,6 @@ __global__ __launch_bounds__(256, RB_OCC) void rfft320_batch_kernel(const float*
     float* in = s_in[wave];
     float* tmag = s_mag[wave];
     float* tbin = s_bin[wave];
-    constexpr int N4 = RB_WF * kNFft / 4; // 320 float4 per group = 5 per lane
     // this lane's five float4 of the group starting at `base` (lanes past the end of the batch re-read the last
     // valid float4: the loads stay unconditional, their values are never used)
     auto fetch = [&](long base, f32x4 (&r)[5]) {

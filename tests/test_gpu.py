@@ -719,8 +719,13 @@ def test_bench_cfg4_one_rank_equals_two_rank_rehearsal():
     one = subprocess.run([sys.executable] + base, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-3000:]
     a = json.loads(one.stdout.strip().splitlines()[-1])
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533"] + base + ["--gpus", "2", "--dist-backend", "gloo"],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port)] + base + ["--gpus", "2", "--dist-backend", "gloo"],
                          capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-3000:]
     b = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
