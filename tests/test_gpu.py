@@ -1071,3 +1071,34 @@ def test_pipeline_other_fft_sizes_match_oracle(fv, gpu_ctx, weights7, pkg, fft_s
     bins_ref = np.stack([r1.fft_bins(k) for k in range(o["n_fft_frames"])])
     assert o["fft_bins"].shape == bins_ref.shape == (72000 // fft_size, fft_size // 2 + 1)
     assert_rel(o["fft_bins"], bins_ref, 1e-4, floor=1e-3 * bins_ref.max(), what="|X| tap")
+
+
+def test_weight_stationary_handoff_is_deterministic_under_load(fv, gpu_ctx, weights7):
+    # gru_ws_kernel exchanges h_t between workgroups inside one launch (write-through stores, flags, sc1 loads).
+    # A stale or torn read would change bits from run to run, most likely while other work competes for the CUs:
+    # repeat small batches while a second context keeps launching large ones; every repetition must be bit-identical
+    # (tools/ws_stress.py is the long form: 1800 repetitions)
+    import threading
+    bg = fv.Context(0)
+    bg.load_weights(weights7)
+    stop = []
+    big = np.random.default_rng(1).uniform(-11, 2, (4096, 54, 161)).astype(np.float32)
+
+    def background():
+        while not stop:
+            bg.nsnet2_forward(big)
+
+    th = threading.Thread(target=background)
+    th.start()
+    try:
+        for n_seq in (1, 82, 330):
+            f = np.random.default_rng(n_seq).uniform(-11, 2, (n_seq, 54, 161)).astype(np.float32)
+            ref = gpu_ctx.nsnet2_forward(f)
+            for _ in range(40):
+                assert np.array_equal(gpu_ctx.nsnet2_forward(f), ref), n_seq
+            want = np.stack([orc.nsnet2_forward(weights7, s) for s in f[:2]])
+            assert_rel(ref[:2], want, 1e-4, floor=1e-2, what="gains under load")
+    finally:
+        stop.append(1)
+        th.join()
+        bg.close()
