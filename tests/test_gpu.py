@@ -1102,3 +1102,34 @@ def test_weight_stationary_handoff_is_deterministic_under_load(fv, gpu_ctx, weig
         stop.append(1)
         th.join()
         bg.close()
+
+
+_WS_FALLBACK_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_package
+pkg = load_package(); fv = pkg.binding
+import orc
+ctx = fv.Context(0); ctx.load_synth(7)
+W = ctx.weights()
+f = np.random.default_rng(3).uniform(-11, 2, (100, 54, 161)).astype(np.float32)
+g = ctx.nsnet2_forward(f)                       # FVAD_WS_SPIN_TICKS=0: the waits give up, gru_lat redoes both layers
+os.environ["FVAD_GRU_KERNEL"] = "v4w8"
+lat = ctx.nsnet2_forward(f)                     # the low-latency kernel directly
+assert np.array_equal(g, lat), np.abs(g - lat).max()
+ref = np.stack([orc.nsnet2_forward(W, s) for s in f[:3]])
+assert (np.abs(g[:3] - ref) / np.maximum(np.abs(ref), 1e-2)).max() <= 1e-4
+print("FALLBACK_OK")
+"""
+
+
+def test_weight_stationary_timeout_falls_back_to_gru_lat():
+    # every spin of gru_ws_kernel is bounded; a workgroup that gives up raises the error word and the guarded
+    # gru_lat launch behind it redoes the layer.  With a zero deadline the very first wait that is not already
+    # satisfied gives up: the result must be gru_lat's, bit for bit (its own process: the deadline is read once)
+    import subprocess
+    import sys
+    env = dict(os.environ, FVAD_WS_SPIN_TICKS="0")
+    r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + _WS_FALLBACK_SCRIPT], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stderr[-3000:]
