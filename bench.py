@@ -66,20 +66,22 @@ def parse():
 
 
 def make_inputs(pkg, rank, lanes, seconds):
-    """lanes x seconds of synthetic 48 kHz mono: a 64 s seeded pattern per lane, tiled"""
+    """lanes x seconds of synthetic 48 kHz mono, every lane different: 32 seeded 64 s patterns per rank, lane l =
+    pattern l % 32 rotated by (l // 32) * 4801 samples (a rotation is a different stream: other chunk phases,
+    other burst times) and tiled to the requested length"""
     base_sec = min(64, seconds)
     out = np.empty((lanes, seconds * 48000), np.float32)
     labels = []
     cache = {}
+    reps = (seconds + base_sec - 1) // base_sec
     for lane in range(lanes):
-        key = lane % 32                      # 32 distinct seeded streams per rank, reused round-robin
+        key = lane % 32
         if key not in cache:
             cache[key] = pkg.synth.make_stream(float(base_sec), seed=1000 * rank + key)
         pcm, lab = cache[key]
-        reps = (seconds + base_sec - 1) // base_sec
-        out[lane] = np.tile(pcm[0], reps)[: seconds * 48000]
-        labels.append([(a + base_sec * r, b + base_sec * r) for r in range(reps) for a, b in lab
-                       if b + base_sec * r <= seconds])
+        shift = 4801 * (lane // 32)
+        out[lane] = np.tile(np.roll(pcm[0], shift), reps)[: seconds * 48000]
+        labels.append([(a, b) for a, b in roll_labels(lab, shift / 48000.0, float(base_sec), reps) if b <= seconds])
     return out, labels
 
 
@@ -495,7 +497,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic 48 kHz mono (seeded noise floor + 500-2000 Hz harmonic bursts), random-init NSNet2 weights seed 7",
+            "data": "synthetic 48 kHz mono (seeded noise floor + 500-2000 Hz harmonic bursts; every lane a different stream), random-init NSNet2 weights seed 7",
             "config": {"workload": f"full pipeline (window->STFT->NSNet2->iSTFT->FFT1024 band->VAD decision), "
                                    f"{lanes} streams x {seconds} s per GPU per step = {lanes * n_chunks} chunks = "
                                    f"{frames_per_step} frames; BASELINE config 3 pipeline at a saturating batch "
