@@ -252,6 +252,7 @@ SIGNATURES = {
     "fvad_wav_read_i16": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.POINTER(C.c_int16))), C.POINTER(sz),
                                     C.POINTER(sz), C.POINTER(sz)]),
     "fvad_wav_free_i16": (None, [C.POINTER(C.POINTER(C.c_int16)), sz]),
+    "fvad_wav_write": (C.c_int, [C.c_char_p, C.POINTER(c_float_p), sz, sz, sz, C.c_int]),
 }
 
 _lib = None
@@ -803,6 +804,13 @@ def wav_read(path):
         return out, sr.value
     finally:
         lib().fvad_wav_free(pcm, nc.value)
+
+
+def wav_write(path, pcm, sample_rate=48000, pcm16=False):
+    """pcm [n_channels][n_frames] float32 -> WAV file (float32 or PCM16)"""
+    pcm = np.ascontiguousarray(np.atleast_2d(pcm), dtype=np.float32)
+    ptrs = (c_float_p * pcm.shape[0])(*[fptr(pcm[c]) for c in range(pcm.shape[0])])
+    check(lib().fvad_wav_write(path.encode(), ptrs, pcm.shape[0], pcm.shape[1], sample_rate, 1 if pcm16 else 0), "fvad_wav_write")
 
 
 def wav_read_i16(path):

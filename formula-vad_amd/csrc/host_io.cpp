@@ -4,6 +4,7 @@
 // part of this build; this reader covers what the simulator harness needs: PCM16 and IEEE float32
 // WAV, any channel count, de-interleaved to channel-planar f32.  PCM16 is scaled by 1/32768 like
 // libsndfile's normalised float read.
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -131,6 +132,47 @@ void fvad_wav_free_i16(int16_t** channel_pcm, size_t n_channels)
     if (!channel_pcm) return;
     for (size_t c = 0; c < n_channels; ++c) free(channel_pcm[c]);
     free(channel_pcm);
+}
+
+// AudioBuffer.saveToFile (src/audio_utils/AudioBuffer.zig:61-118) for the WAV container: interleave the planar
+// channels and write IEEE float32 (as_pcm16 == 0) or PCM16.  The reference writes through libsndfile
+// (sf_writef_float: WAV, FLAC or Vorbis by Format); PCM16 here is libsndfile's default float -> short conversion
+// with normalisation on, lrintf(x * 32767) after clipping to [-1, 1] [external: libsndfile's f2s_clip_array].
+int fvad_wav_write(const char* path, const float* const* channel_pcm, size_t n_channels, size_t n_frames, size_t sample_rate,
+                   int as_pcm16)
+{
+    if (!path || (n_frames && !channel_pcm) || n_channels == 0 || n_channels > 65535 || sample_rate == 0) return FVAD_ERR_INVALID_ARGUMENT;
+    for (size_t c = 0; c < n_channels && n_frames; ++c) if (!channel_pcm[c]) return FVAD_ERR_CHANNEL_COUNT_MISMATCH;
+    const size_t bytes_per = as_pcm16 ? 2 : 4;
+    const uint64_t data_bytes = (uint64_t)n_frames * n_channels * bytes_per;
+    if (data_bytes > 0xFFFFFF00ull) return FVAD_ERR_INVALID_ARGUMENT; // RIFF sizes are 32-bit
+    std::vector<uint8_t> buf(44 + (size_t)data_bytes);
+    auto wr32 = [&](size_t o, uint32_t v) { buf[o] = (uint8_t)v; buf[o + 1] = (uint8_t)(v >> 8); buf[o + 2] = (uint8_t)(v >> 16); buf[o + 3] = (uint8_t)(v >> 24); };
+    auto wr16 = [&](size_t o, uint16_t v) { buf[o] = (uint8_t)v; buf[o + 1] = (uint8_t)(v >> 8); };
+    memcpy(&buf[0], "RIFF", 4); wr32(4, (uint32_t)(36 + data_bytes)); memcpy(&buf[8], "WAVEfmt ", 8);
+    wr32(16, 16); wr16(20, as_pcm16 ? 1 : 3); wr16(22, (uint16_t)n_channels); wr32(24, (uint32_t)sample_rate);
+    wr32(28, (uint32_t)(sample_rate * n_channels * bytes_per)); wr16(32, (uint16_t)(n_channels * bytes_per)); wr16(34, (uint16_t)(bytes_per * 8));
+    memcpy(&buf[36], "data", 4); wr32(40, (uint32_t)data_bytes);
+    size_t o = 44;
+    for (size_t i = 0; i < n_frames; ++i)
+        for (size_t c = 0; c < n_channels; ++c) {
+            const float x = channel_pcm[c][i];
+            if (as_pcm16) {
+                const float cl = x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x);
+                wr16(o, (uint16_t)(int16_t)lrintf(cl * 32767.0f));
+                o += 2;
+            } else {
+                uint32_t u;
+                memcpy(&u, &x, 4);
+                wr32(o, u);
+                o += 4;
+            }
+        }
+    FILE* fp = fopen(path, "wb");
+    if (!fp) return FVAD_ERR_IO;
+    const size_t put = fwrite(buf.data(), 1, buf.size(), fp);
+    const int cl = fclose(fp);
+    return (put == buf.size() && cl == 0) ? FVAD_OK : FVAD_ERR_IO;
 }
 
 } // extern "C"

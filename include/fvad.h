@@ -470,6 +470,10 @@ void fvad_wav_free(float **channel_pcm, size_t n_channels);
 int fvad_wav_read_i16(const char *path, int16_t ***channel_pcm, size_t *n_channels, size_t *n_frames,
                       size_t *sample_rate);
 void fvad_wav_free_i16(int16_t **channel_pcm, size_t n_channels);
+/* AudioBuffer.saveToFile (src/audio_utils/AudioBuffer.zig:61-118) for the WAV container -- what a recording
+ * callback does with its clip (main.zig saves them): planar channels -> float32 (as_pcm16 == 0) or PCM16 WAV. */
+int fvad_wav_write(const char *path, const float *const *channel_pcm, size_t n_channels,
+                   size_t n_frames, size_t sample_rate, int as_pcm16);
 
 #ifdef __cplusplus
 }

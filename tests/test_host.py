@@ -575,6 +575,23 @@ def test_vad_batch_equals_oracle_pipeline(fv, pkg):
     b.close()
 
 
+def test_wav_write_round_trips(fv, tmp_path):
+    # AudioBuffer.saveToFile for WAV: float32 is lossless; PCM16 is lrintf(clip(x) * 32767) and comes back as s / 32768
+    rng = np.random.default_rng(4)
+    x = rng.uniform(-1.2, 1.2, (2, 777)).astype(np.float32)
+    p32, p16 = str(tmp_path / "f32.wav"), str(tmp_path / "i16.wav")
+    fv.wav_write(p32, x, 16000)
+    got, sr = fv.wav_read(p32)
+    assert sr == 16000 and np.array_equal(got, x)
+    fv.wav_write(p16, x, 48000, pcm16=True)
+    s16, sr = fv.wav_read_i16(p16)
+    assert sr == 48000 and np.array_equal(s16, np.rint(np.clip(x, -1, 1) * np.float32(32767.0)).astype(np.int16))
+    fv.wav_write(p16, np.zeros((1, 0), np.float32))               # an empty clip is a valid file
+    assert fv.wav_read(p16)[0].shape == (1, 0)
+    with pytest.raises(fv.FvadError):
+        fv.wav_write(str(tmp_path / "no" / "dir.wav"), x)
+
+
 def test_golden_vad_stream_segments(fv):
     # committed band volumes of a 120 s synthetic stream -> the exact segment list
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden_vad_seed40.npz"))
