@@ -191,6 +191,7 @@ SIGNATURES = {
     "fvad_engine_enqueue_device_i16": (C.c_int, [vp, vp, sz, sz, sz, vp, vp, vp, C.POINTER(EngineOpts)]),
     "fvad_nsnet2_forward": (C.c_int, [vp, c_float_p, sz, sz, c_float_p]),
     "fvad_ctx_enable_timing": (C.c_int, [vp, C.c_int]),
+    "fvad_ctx_set_nn_math": (C.c_int, [vp, C.c_int]),
     "fvad_ctx_kernel_times": (C.c_int, [vp, C.POINTER(C.c_char_p), c_float_p, sz,
                                         C.POINTER(sz)]),
     "fvad_vad_config_default": (None, [C.POINTER(VadConfig)]),
@@ -368,6 +369,17 @@ class Context:
 
     def synchronize(self):
         self._ck(lib().fvad_ctx_synchronize(self.h), "fvad_ctx_synchronize")
+
+    def set_nn_math(self, mode):
+        """'f16x3' (default) or 'f32': arithmetic of the large-batch NSNet2 matrix products; returns the previous mode"""
+        m = {"f32": 0, "f16x3": 1}[mode]
+        prev = lib().fvad_ctx_set_nn_math(self.h, m)
+        if prev < 0:
+            self._ck(prev, "fvad_ctx_set_nn_math")
+        return ("f32", "f16x3")[prev]
+
+    def set_nn_math_raw(self, mode):
+        return self._ck(lib().fvad_ctx_set_nn_math(self.h, int(mode)), "fvad_ctx_set_nn_math")
 
     def enable_timing(self, on=True):
         self._ck(lib().fvad_ctx_enable_timing(self.h, 1 if on else 0), "fvad_ctx_enable_timing")

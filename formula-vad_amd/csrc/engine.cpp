@@ -120,6 +120,15 @@ int upload_model(fvad_ctx* ctx)
         pack_panel(tile_major_rows(wf.data(), 161).data(), 1200, 161, 5, 15, 11, f);
         if ((rc = upload(ctx, m.gi1f_w, f))) return rc;
         if ((rc = upload(ctx, m.gi1f_b, tile_major_rows(bf.data(), 1)))) return rc;
+        // f16x3 form of the same folded layer; its input, the log-power features, is bounded by log10 of the
+        // largest f32 squared (NSNet2.zig:266-287)
+        {
+            const std::vector<float> wt = tile_major_rows(wf.data(), 161);
+            m.h3_gi1f.sw = h3_weight_scale(wt.data(), wt.size());
+            m.h3_gi1f.sx = h3_activation_scale(80.0);
+            pack_panel_h3(wt.data(), 1200, 161, 5, 15, m.h3_gi1f.sw, f);
+            if ((rc = upload(ctx, m.gi1f_h3, f))) return rc;
+        }
         // gru_rec3_kernel adds only the n-gate recurrent bias itself: for z and r, Wb + Rb is one constant
         for (int o = 0; o < 2 * H; ++o) bf[o] += w.gru1_b[3 * H + o];
         if ((rc = upload(ctx, m.gi1f_bzr, tile_major_rows(bf.data(), 1)))) return rc;
@@ -148,6 +157,49 @@ int upload_model(fvad_ctx* ctx)
     pack_panel(w.fc4_w.data(), 161, 600, 1, 11, 38, f);
     if ((rc = upload(ctx, m.fc4_w, f))) return rc;
     if ((rc = upload(ctx, m.fc4_b, padded(w.fc4_b.data(), 161, 176)))) return rc;
+    // ---- f16x3 layouts of the remaining layers.  Input scales from rigorous bounds: GRU states lie in (-1, 1)
+    // (h = (1 - z) n + z h with |n| < 1, z in (0, 1), h_0 = 0); a dense layer's outputs are bounded by its
+    // rows' l1 norms times the input bound plus the bias.
+    {
+        auto l1_bound = [](const std::vector<float>& W, const std::vector<float>& b, int N, int K, double in_bound) {
+            double mx = 0.0;
+            for (int n = 0; n < N; ++n) {
+                double a = 0.0;
+                for (int k = 0; k < K; ++k) a += fabs((double)W[(size_t)n * K + k]);
+                mx = std::max(mx, a * in_bound + fabs((double)b[n]));
+            }
+            return mx;
+        };
+        const double b_fc2 = l1_bound(w.fc2_w, w.fc2_b, 600, 400, 1.0);
+        const double b_fc3 = l1_bound(w.fc3_w, w.fc3_b, 600, 600, b_fc2);
+        const std::vector<float> g2 = tile_major_rows(w.gru2_w.data(), 400);
+        m.h3_gi2 = {h3_weight_scale(g2.data(), g2.size()), h3_activation_scale(1.0)};
+        pack_panel_h3(g2.data(), 1200, 400, 5, 15, m.h3_gi2.sw, f);
+        if ((rc = upload(ctx, m.gi2_h3, f))) return rc;
+        m.h3_fc2 = {h3_weight_scale(w.fc2_w.data(), w.fc2_w.size()), h3_activation_scale(1.0)};
+        pack_panel_h3(w.fc2_w.data(), 600, 400, 4, 10, m.h3_fc2.sw, f);
+        if ((rc = upload(ctx, m.fc2_h3, f))) return rc;
+        if ((rc = upload(ctx, m.fc2h3_b, padded(w.fc2_b.data(), 600, 640)))) return rc;
+        m.h3_fc3 = {h3_weight_scale(w.fc3_w.data(), w.fc3_w.size()), h3_activation_scale(b_fc2)};
+        pack_panel_h3(w.fc3_w.data(), 600, 600, 4, 10, m.h3_fc3.sw, f);
+        if ((rc = upload(ctx, m.fc3_h3, f))) return rc;
+        if ((rc = upload(ctx, m.fc3h3_b, padded(w.fc3_b.data(), 600, 640)))) return rc;
+        m.h3_fc4 = {h3_weight_scale(w.fc4_w.data(), w.fc4_w.size()), h3_activation_scale(b_fc3)};
+        pack_panel_h3(w.fc4_w.data(), 161, 600, 1, 12, m.h3_fc4.sw, f);
+        if ((rc = upload(ctx, m.fc4_h3, f))) return rc;
+        if ((rc = upload(ctx, m.fc4h3_b, padded(w.fc4_b.data(), 161, 192)))) return rc;
+        m.h3_r1 = {h3_weight_scale(w.gru1_r.data(), w.gru1_r.size()), h3_activation_scale(1.0)};
+        pack_gru_r_h3(w.gru1_r.data(), H, m.h3_r1.sw, f);
+        if ((rc = upload(ctx, m.r1_h3, f))) return rc;
+        m.h3_r2 = {h3_weight_scale(w.gru2_r.data(), w.gru2_r.size()), h3_activation_scale(1.0)};
+        pack_gru_r_h3(w.gru2_r.data(), H, m.h3_r2.sw, f);
+        if ((rc = upload(ctx, m.r2_h3, f))) return rc;
+        // the scales are finite powers of two whenever the weights and the bounds are finite
+        m.h3_ok = std::isfinite(b_fc3) && b_fc3 < 1e30;
+        for (const DeviceModel::H3Scale* sc : {&m.h3_gi1f, &m.h3_gi2, &m.h3_fc2, &m.h3_fc3, &m.h3_fc4, &m.h3_r1, &m.h3_r2})
+            m.h3_ok = m.h3_ok && std::isfinite(sc->sw) && std::isfinite(sc->sx) && sc->sw > 0.0f && sc->sx > 0.0f &&
+                      std::isfinite(sc->sw * sc->sx) && std::isfinite(1.0f / (sc->sw * sc->sx));
+    }
     m.loaded = true;
     return FVAD_OK;
 }
@@ -362,6 +414,54 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
                         int nblk, int S, int K, int act, int valid, int mT, int mskip) {
             return fvad_launch_panel_gemm3(A, lda, W, b, Cc, ldc, r, nt, nblk, S, K, act, valid, mT, mskip, ctx->n_cu, st);
         };
+        auto gemm_h3 = [&](const float* A, int lda, const DevBuf& W, const DeviceModel::H3Scale& sc, const float* b, float* Cc,
+                           int ldc, long r, int nt, int nblk, int K, int act, int valid, int mT, int mskip) {
+            return fvad_launch_panel_gemm_h3(A, lda, W.p, b, Cc, ldc, r, nt, nblk, K, act, valid, mT, mskip, sc.sx, sc.sw, ctx->n_cu, st);
+        };
+        const char* math = getenv("FVAD_NN_MATH"); // tuning aid: "f32" (f32 MFMA) / "f16x3" (kernels_h3.hip)
+        const bool want_h3 = math ? !strcmp(math, "f16x3") : ctx->nn_math == FVAD_NN_MATH_F16X3;
+        const bool h3 = want_h3 && m.h3_ok && !(force && strstr(force, "nofold"));
+        if (h3) {
+            GruChoice gc = pick_gru(ctx, n_pad, true);
+            if (!getenv("FVAD_GRU_KERNEL") && gc.version == 3 && (n_pad % 192 == 0 || n_pad % 128 == 0)) {
+                const char* hw = getenv("FVAD_H3_WAVES"); // tuning aid: 8 / 12
+                int waves = n_pad % 192 == 0 ? 12 : 8;
+                if (hw && (atoi(hw) == 8 || atoi(hw) == 12) && n_pad % (16 * atoi(hw)) == 0) waves = atoi(hw);
+                gc = {6, waves}; // gru_rec_h3
+            }
+            if (gc.version == 5 && (rc = prepare_gru_ws(ctx, n_pad))) return rc;
+            const bool bzr = gc.version == 3 || gc.version == 6;
+            auto launch_gru_h3 = [&](fvad_ctx* c, GruChoice g, const float* gi, const DevBuf& r_v2, const float* bR, float* hout,
+                                     long n, int T_, int layer, int tm) {
+                if (g.version != 6) return launch_gru(c, g, gi, r_v2, bR, hout, n, T_, layer, tm);
+                const DeviceModel::H3Scale& sc = layer ? m.h3_r2 : m.h3_r1;
+                return fvad_launch_gru_rec_h3(gi, (layer ? m.r2_h3 : m.r1_h3).p, bR, hout, n, T_, g.waves, sc.sx, sc.sw, st);
+            };
+            time_begin(ctx, "gru1_in_gemm_fc1folded");
+            rc |= gemm_h3(ws.feat, kFeatStride, m.gi1f_h3, m.h3_gi1f, bzr ? m.gi1f_bzr.p : m.gi1f_b.p, ws.gi, 1200, rows, 15, 5, 161, FVAD_ACT_NONE, 75, 0, 0);
+            time_end(ctx);
+            time_begin(ctx, "gru1_rec");
+            rc |= launch_gru_h3(ctx, gc, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T, 0, 1);
+            time_end(ctx);
+            time_begin(ctx, "gru2_in_gemm");
+            rc |= gemm_h3(ws.h1, 400, m.gi2_h3, m.h3_gi2, bzr ? m.gi2_bzr.p : m.gi2_btm.p, ws.gi, 1200, rows, 15, 5, 400, FVAD_ACT_NONE, 75, 0, 0);
+            time_end(ctx);
+            time_begin(ctx, "gru2_rec");
+            rc |= launch_gru_h3(ctx, gc, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T, 1, 1);
+            time_end(ctx);
+            time_begin(ctx, "fc2_gemm");
+            rc |= gemm_h3(ws.h2, 400, m.fc2_h3, m.h3_fc2, m.fc2h3_b.p, ws.f2, 608, rows_out, 10, 4, 400, FVAD_ACT_RELU, 38, skip ? T : 0, skip);
+            time_end(ctx);
+            time_begin(ctx, "fc3_gemm");
+            rc |= gemm_h3(ws.f2, 608, m.fc3_h3, m.h3_fc3, m.fc3h3_b.p, ws.f3, 608, rows_out, 10, 4, 600, FVAD_ACT_RELU, 38, 0, 0);
+            time_end(ctx);
+            time_begin(ctx, "fc4_gemm");
+            rc |= gemm_h3(ws.f3, 608, m.fc4_h3, m.h3_fc4, m.fc4h3_b.p, ws.gains, kFeatStride, rows_out, 12, 1, 600, FVAD_ACT_SIGMOID, 11, 0, 0);
+            time_end(ctx);
+            if (rc) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "no kernel instance for this layer shape");
+            FVAD_HIP(ctx, hipGetLastError());
+            return FVAD_OK;
+        }
         const bool fold = !(force && strstr(force, "nofold"));
         const GruChoice gc = pick_gru(ctx, n_pad, fold);
         if (gc.version == 5 && (rc = prepare_gru_ws(ctx, n_pad))) return rc; // only when forced: tuning / tests
@@ -728,6 +828,15 @@ int fvad_ctx_copy_to_host(fvad_ctx* ctx, void* dst_host, const void* src_device,
     if (!ctx || (bytes && (!dst_host || !src_device))) return FVAD_ERR_INVALID_ARGUMENT;
     if (bytes) FVAD_HIP(ctx, hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return FVAD_OK;
+}
+
+int fvad_ctx_set_nn_math(fvad_ctx* ctx, int mode)
+{
+    if (!ctx || (mode != FVAD_NN_MATH_F32 && mode != FVAD_NN_MATH_F16X3)) return FVAD_ERR_INVALID_ARGUMENT;
+    const int prev = ctx->nn_math;
+    if (prev != mode) ctx->ws.generation++; // a captured launch sequence holds the other kernels
+    ctx->nn_math = mode;
+    return prev;
 }
 
 int fvad_ctx_enable_timing(fvad_ctx* ctx, int on)

@@ -38,6 +38,11 @@ int read_onnx_nsnet2(const char* path, HostWeights& w, std::string& err);
 // fragment-major packing for the MFMA kernels (see kernels_nn.hip)
 void pack_panel(const float* W, int N, int K, int n_blocks, int NT, int S, std::vector<float>& out);
 void pack_gru_r2(const float* R, int H, std::vector<float>& out);
+// f16x3 layouts (kernels_h3.hip): hi/lo f16 pieces of W * sw as bit patterns in float storage
+float h3_weight_scale(const float* W, size_t n);      // power of two: max |W| * sw in [2^14, 2^15); 0 if a weight is not finite
+float h3_activation_scale(double bound);              // power of two: |x| <= bound -> |x * sx| <= 2^14
+void pack_panel_h3(const float* W, int N, int K, int n_blocks, int NT, float sw, std::vector<float>& out);
+void pack_gru_r_h3(const float* R, int H, float sw, std::vector<float>& out);
 
 // ------------------------------------------------------------------ device model
 struct DevBuf {
@@ -51,6 +56,11 @@ struct DeviceModel {
         fc2v3_w, fc3v3_w, fc2v3_b, fc3v3_b, // fc2/fc3 as 3 column blocks of 13 tiles for panel_gemm3
         gi1f_bzr, gi2_bzr, // input-projection biases with the recurrent z/r biases folded in (gru_rec3)
         gi1_btm, gi2_btm;  // plain input-projection biases in tile-major unit order (large-batch GEMM without the fold)
+    // f16x3 layouts (kernels_h3.hip): two f16 pieces per weight; sw = weight scale, sx = input scale of the layer
+    DevBuf gi1f_h3, gi2_h3, fc2_h3, fc3_h3, fc4_h3, fc2h3_b, fc3h3_b, fc4h3_b, r1_h3, r2_h3;
+    struct H3Scale { float sw = 1.0f, sx = 1.0f; };
+    H3Scale h3_gi1f, h3_gi2, h3_fc2, h3_fc3, h3_fc4, h3_r1, h3_r2;
+    bool h3_ok = false; // every weight and bound finite: the f16x3 kernels may be used
     bool loaded = false;
 };
 
@@ -126,6 +136,7 @@ struct fvad_ctx {
     fvad::HostWeights hw;
     fvad::DeviceModel dm;
     fvad::Workspace ws;
+    int nn_math = 1; // FVAD_NN_MATH_F16X3
     // timing
     bool timing = false;
     std::vector<fvad::KernelTime> times;

@@ -76,6 +76,12 @@ int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const fl
 int fvad_launch_panel_gemm3(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
                             int ldc, long rows, int nt, int n_blocks, int S_steps, int K, int act,
                             int n_valid_tiles, int map_T, int map_skip, int n_wg, hipStream_t stream);
+// f16x3 form (kernels_h3.hip): Wfrag from pack_panel_h3, K = true reduction length, sx / sw = input / weight scales
+int fvad_launch_panel_gemm_h3(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
+                              int ldc, long rows, int nt, int n_blocks, int K, int act, int n_valid_tiles,
+                              int map_T, int map_skip, float sx, float sw, int n_wg, hipStream_t stream);
+int fvad_launch_gru_rec_h3(const float* gi, const float* Rfrag, const float* bR, float* hout, long n_seq_pad, int T,
+                           int waves, float sx, float sw, hipStream_t stream);
 // guard != nullptr: the kernel returns at once unless *guard != 0 (fallback behind fvad_launch_gru_ws)
 // tile_major: gi rows are [25 J][3 gates][16] (large-batch GEMM) instead of [3 gates][400] (small-batch GEMM)
 int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, float* hout,

@@ -207,6 +207,119 @@ void pack_gru_r2(const float* R, int H, std::vector<float>& out)
                     }
 }
 
+// ---- f16x3 layouts (kernels_h3.hip): every weight as two f16 pieces of W * sw
+// f32 -> f16 bits, round to nearest even (weights are finite; |v| < 65520 by the choice of sw)
+static uint16_t f32_to_f16_bits(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7FFFFFFFu;
+    if (u >= 0x47800000u) return (uint16_t)(sign | 0x7C00u);           // >= 65536 (or NaN): infinity, never reached
+    if (u < 0x38800000u) {                                             // below 2^-14: subnormal half
+        if (u < 0x33000000u) return (uint16_t)sign;                    // below 2^-25: zero
+        const int e = (int)(u >> 23);                                  // biased f32 exponent, 102..112
+        const uint32_t mant = (u & 0x7FFFFFu) | 0x800000u;
+        const int shift = 126 - e;                                     // 14..24: mant >> shift is the half mantissa
+        uint32_t h = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((u - 0x38000000u) >> 13);
+    const uint32_t rem = u & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;            // may carry into the exponent: still right
+    return (uint16_t)(sign | h);
+}
+static float f16_bits_to_f32(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const int e = (h >> 10) & 31;
+    const uint32_t m = h & 0x3FFu;
+    float v;
+    if (e == 0) v = ldexpf((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = ldexpf((float)(m | 0x400u), e - 25);
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    u |= sign;
+    memcpy(&v, &u, 4);
+    return v;
+}
+
+float h3_weight_scale(const float* W, size_t n)
+{
+    float mx = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        if (!std::isfinite(W[i])) return 0.0f; // not representable: the caller keeps the f32 kernels
+        mx = std::max(mx, fabsf(W[i]));
+    }
+    if (!(mx > 0.0f)) return 1.0f;
+    int e;
+    frexpf(mx, &e);                 // mx = f * 2^e, f in [0.5, 1)
+    return ldexpf(1.0f, 15 - e);    // mx * sw in [2^14, 2^15)
+}
+
+float h3_activation_scale(double bound)
+{
+    if (!(bound > 0.0) || !std::isfinite(bound)) return 1.0f;
+    int e;
+    const double f = frexp(bound, &e); // bound = f * 2^e
+    if (f == 0.5) --e;                 // exact power of two
+    return ldexpf(1.0f, 14 - e);       // |x| <= bound  ->  |x * sx| <= 2^14
+}
+
+// the two f16 fragment dwords of one value pair are written as bit patterns into float storage
+static void put_half(std::vector<float>& out, size_t dword, int upper, uint16_t bits)
+{
+    uint32_t u;
+    memcpy(&u, &out[dword], 4);
+    u = upper ? ((u & 0x0000FFFFu) | ((uint32_t)bits << 16)) : ((u & 0xFFFF0000u) | bits);
+    memcpy(&out[dword], &u, 4);
+}
+static inline int h3_slot_k(int s, int qa, int j) { return j < 4 ? 32 * s + 4 * qa + j : 32 * s + 16 + 4 * qa + (j - 4); }
+static void h3_put(std::vector<float>& out, size_t block_dword, int lane, int j, float w_scaled)
+{
+    const uint16_t hi = f32_to_f16_bits(w_scaled);
+    const uint16_t lo = f32_to_f16_bits(w_scaled - f16_bits_to_f32(hi));
+    const size_t d = block_dword + (size_t)lane * 4 + (size_t)(j >> 1);
+    put_half(out, d, j & 1, hi);
+    put_half(out, d + 256, j & 1, lo);
+}
+
+// [n_blocks][S32][NT][hi, lo][64 lanes][8 halves], S32 = ceil(ceil(K / 16) / 2) K-steps of 32 slots
+void pack_panel_h3(const float* W, int N, int K, int n_blocks, int NT, float sw, std::vector<float>& out)
+{
+    const int S = ((K + 15) / 16 + 1) / 2;
+    out.assign((size_t)n_blocks * S * NT * 512, 0.0f);
+    for (int b = 0; b < n_blocks; ++b)
+        for (int s = 0; s < S; ++s)
+            for (int t = 0; t < NT; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int n = (b * NT + t) * 16 + (lane & 15);
+                        const int k = h3_slot_k(s, lane >> 4, j);
+                        if (n < N && k < K)
+                            h3_put(out, (((size_t)b * S + s) * NT + t) * 512, lane, j, W[(size_t)n * K + k] * sw);
+                    }
+}
+
+// one contiguous slab per unit tile: [J][S32 = 13][3 gates][hi, lo][64][8 halves]  (78 KB)
+void pack_gru_r_h3(const float* R, int H, float sw, std::vector<float>& out)
+{
+    const int J = H / 16, S = (J + 1) / 2;
+    out.assign((size_t)J * S * 3 * 512, 0.0f);
+    for (int jt = 0; jt < J; ++jt)
+        for (int s = 0; s < S; ++s)
+            for (int g = 0; g < 3; ++g)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int n = g * H + 16 * jt + (lane & 15);
+                        const int k = h3_slot_k(s, lane >> 4, j);
+                        if (k < H) h3_put(out, (((size_t)jt * S + s) * 3 + g) * 512, lane, j, R[(size_t)n * H + k] * sw);
+                    }
+}
+
 // ------------------------------------------------------------------ ONNX (protobuf) reader
 // Wire format only: varint, 64-bit, length-delimited, 32-bit.  Message/field numbers from
 // onnx.proto3: ModelProto.graph = 7; GraphProto.node = 1, .initializer = 5; NodeProto.input = 1,

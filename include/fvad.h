@@ -260,6 +260,16 @@ int fvad_engine_enqueue_device_i16(fvad_ctx *ctx, const int16_t *d_pcm16, size_t
  * Replaces onnx_instance.run() (NSNet2.zig:220) for n_seq independent sequences. */
 int fvad_nsnet2_forward(fvad_ctx *ctx, const float *features, size_t n_seq, size_t T,
                         float *gains);
+/* Arithmetic of the NSNet2 matrix products for large batches (>= 2048 sequences per launch):
+ *   FVAD_NN_MATH_F16X3 (default): every f32 operand as two f16 pieces of a power-of-two scaled value, three f16
+ *     MFMAs with f32 accumulation per product (kernels_h3.hip) -- 22 significand bits per operand, measured against
+ *     float64 as close as the f32 form (tests), at 5.3 x the f32 matrix rate;
+ *   FVAD_NN_MATH_F32: v_mfma_f32_16x16x4_f32 throughout (kernels_nn.hip), each output a k-ordered chain of f32 fmas
+ *     like the reference's ONNX Runtime CPU kernels (NSNet2.zig:220).
+ * Small batches always use the f32 kernels.  The environment variable FVAD_NN_MATH=f32|f16x3 overrides the
+ * setting (tuning aid).  Returns the previous mode, or a negative status. */
+enum { FVAD_NN_MATH_F32 = 0, FVAD_NN_MATH_F16X3 = 1 };
+int fvad_ctx_set_nn_math(fvad_ctx *ctx, int mode);
 /* Per-kernel device time of the last fvad_engine_* call (HIP events on the context's stream):
  * names[i]/ms[i] for i < *n.  Enabled by fvad_ctx_enable_timing(ctx, 1). */
 int fvad_ctx_enable_timing(fvad_ctx *ctx, int on);

@@ -197,7 +197,8 @@ def test_nsnet2_forward_matches_oracle(fv, gpu_ctx, weights7):
 @pytest.mark.parametrize("env", [
     {}, {"FVAD_GRU_KERNEL": "v3w12"}, {"FVAD_GRU_KERNEL": "v3w8"}, {"FVAD_GRU_KERNEL": "v3w4"},
     {"FVAD_GEMM_KERNEL": "v3nofold"}, {"FVAD_GEMM_KERNEL": "v1"}, {"FVAD_GRU_KERNEL": "v4w8"},
-    {"FVAD_GRU_KERNEL": "v5w0"},
+    {"FVAD_GRU_KERNEL": "v5w0"}, {"FVAD_NN_MATH": "f32"}, {"FVAD_NN_MATH": "f16x3", "FVAD_H3_WAVES": "8"},
+    {"FVAD_NN_MATH": "f16x3", "FVAD_H3_WAVES": "12"}, {"FVAD_NN_MATH": "f32", "FVAD_GRU_KERNEL": "v3w12"},
 ], ids=lambda e: "-".join(e.values()) or "default")
 def test_nsnet2_large_batch_kernels_match_oracle(fv, gpu_ctx, weights7, env, monkeypatch):
     # 2100 sequences take the large-batch path (LDS-DMA GEMMs, persistent GEMM, multi-wave recurrence);
@@ -213,6 +214,44 @@ def test_nsnet2_large_batch_kernels_match_oracle(fv, gpu_ctx, weights7, env, mon
     ref = np.stack([orc.nsnet2_forward(weights7, f[i]) for i in pick])
     assert_rel(g[pick], ref, 1e-4, floor=1e-2, what=f"gains large batch {env}")
     assert g.min() >= 0 and g.max() <= 1
+
+
+def test_f16x3_products_are_as_close_to_float64_as_f32(fv, weights7):
+    # The large-batch matrix products run as three f16 MFMAs on (hi, lo) f16 pieces of power-of-two scaled
+    # operands (kernels_h3.hip).  Against float64 numpy they must be as close as the f32 MFMA kernels and the
+    # oracle (both plain f32 evaluations); and the scale selection must hold for weights far from unit size.
+    rng = np.random.default_rng(33)
+    f = rng.uniform(-11, 2, (6, 54, 161)).astype(np.float32)
+    f[1] = rng.uniform(20, 60, (54, 161))          # absurdly loud input: features far above the usual range
+    f[2, :, ::3] = -12.0                           # digital silence in a third of the bins
+    fb = np.tile(f, (400, 1, 1))                   # 2400 sequences: the large-batch path
+
+    def run(w, mode):
+        ctx = fv.Context(0)
+        ctx.load_weights(w)
+        assert ctx.set_nn_math(mode) == "f16x3"    # the default
+        g = ctx.nsnet2_forward(fb)
+        ctx.close()
+        return g
+
+    for scale in (1.0, 37.3, 1.0 / 64.0):
+        w = {k: v.copy() for k, v in weights7.items()}
+        # scale one dense layer up and the next down: same function up to rounding, very different operand sizes
+        w["fc2_w"] *= np.float32(scale); w["fc2_b"] *= np.float32(scale)
+        w["fc3_w"] /= np.float32(scale)
+        g64 = np.stack([_nsnet2_float64(w, s) for s in f])
+        g_orc = np.stack([orc.nsnet2_forward(w, s) for s in f])
+        e_orc = np.abs(g_orc - g64).max()
+        g_h3, g_f32 = run(w, "f16x3"), run(w, "f32")
+        e_h3 = max(np.abs(g_h3[:6] - g64).max(), np.abs(g_h3[-6:] - g64).max())
+        e_f32 = max(np.abs(g_f32[:6] - g64).max(), np.abs(g_f32[-6:] - g64).max())
+        assert e_h3 <= max(2 * e_orc, 2e-6), (scale, e_h3, e_f32, e_orc)
+        assert e_f32 <= max(2 * e_orc, 2e-6), (scale, e_h3, e_f32, e_orc)
+        assert np.array_equal(g_h3[:6], g_h3[-6:])  # same sequences, different workgroups: same bits
+    c = fv.Context(0)
+    with pytest.raises(fv.FvadError):
+        c.set_nn_math_raw(7)
+    c.close()
 
 
 def test_get_weights_roundtrip(fv, gpu_ctx, weights7):
