@@ -206,7 +206,7 @@ int upload_model(fvad_ctx* ctx)
 
 static void free_workspace_nn(Workspace& ws)
 {
-    float** bufs[] = {&ws.feat, &ws.spec, &ws.a1, &ws.gi, &ws.h1, &ws.h2, &ws.f2, &ws.f3, &ws.gains};
+    float** bufs[] = {&ws.feat, &ws.spec, &ws.a1, &ws.gi, &ws.h1, &ws.h2, &ws.hs1, &ws.hs2, &ws.f2, &ws.f3, &ws.gains};
     for (float** b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
     if (ws.descs) hipFree(ws.descs);
     if (ws.h_descs) hipHostFree(ws.h_descs);
@@ -235,6 +235,9 @@ int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
     if ((rc = dev_alloc(ctx, &ws.gi, rows * 1200, true))) return rc;
     if ((rc = dev_alloc(ctx, &ws.h1, rows * 400, true))) return rc;
     if ((rc = dev_alloc(ctx, &ws.h2, rows * 400, true))) return rc;
+    // f16x3 path: h1 / h2 once more as split f16 fragments, 13 K-steps of 2 KB per 16 rows
+    if ((rc = dev_alloc(ctx, &ws.hs1, rows * 416, true))) return rc;
+    if ((rc = dev_alloc(ctx, &ws.hs2, rows * 416, true))) return rc;
     if ((rc = dev_alloc(ctx, &ws.f2, rows * 608, true))) return rc;
     if ((rc = dev_alloc(ctx, &ws.f3, rows * 608, true))) return rc;
     if ((rc = dev_alloc(ctx, &ws.gains, rows * kFeatStride, true))) return rc;
@@ -414,49 +417,43 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
                         int nblk, int S, int K, int act, int valid, int mT, int mskip) {
             return fvad_launch_panel_gemm3(A, lda, W, b, Cc, ldc, r, nt, nblk, S, K, act, valid, mT, mskip, ctx->n_cu, st);
         };
-        auto gemm_h3 = [&](const float* A, int lda, const DevBuf& W, const DeviceModel::H3Scale& sc, const float* b, float* Cc,
-                           int ldc, long r, int nt, int nblk, int K, int act, int valid, int mT, int mskip) {
-            return fvad_launch_panel_gemm_h3(A, lda, W.p, b, Cc, ldc, r, nt, nblk, K, act, valid, mT, mskip, sc.sx, sc.sw, ctx->n_cu, st);
+        // f16x3 path (kernels_h3.hip): its intermediates (gi, h1, h2, f2, f3) are in the tiled layout, row tiles of
+        // 16 sequences at one time step; the features come in and the gains go out row-major
+        auto gemm_h3 = [&](const float* A, int in_ts, int a_ld, const DevBuf& W, const DeviceModel::H3Scale& sc, const float* b,
+                           float* Cc, int out, int c_ld, int seq_T, long row_tiles, int nt, int nblk, int K, int act,
+                           int valid, int mT, int mskip, float out_sx) {
+            return fvad_launch_panel_gemm_h3(A, in_ts, a_ld, W.p, b, Cc, out, c_ld, seq_T, row_tiles, nt, nblk, K, act, valid,
+                                             mT, mskip, sc.sx, sc.sw, out_sx, ctx->n_cu, st);
         };
         const char* math = getenv("FVAD_NN_MATH"); // tuning aid: "f32" (f32 MFMA) / "f16x3" (kernels_h3.hip)
         const bool want_h3 = math ? !strcmp(math, "f16x3") : ctx->nn_math == FVAD_NN_MATH_F16X3;
-        const bool h3 = want_h3 && m.h3_ok && !(force && strstr(force, "nofold"));
+        const bool h3 = want_h3 && m.h3_ok && !force && !getenv("FVAD_GRU_KERNEL") && (n_pad % 192 == 0 || n_pad % 128 == 0);
         if (h3) {
-            GruChoice gc = pick_gru(ctx, n_pad, true);
-            if (!getenv("FVAD_GRU_KERNEL") && gc.version == 3 && (n_pad % 192 == 0 || n_pad % 128 == 0)) {
-                const char* hw = getenv("FVAD_H3_WAVES"); // tuning aid: 8 / 12
-                int waves = n_pad % 192 == 0 ? 12 : 8;
-                if (hw && (atoi(hw) == 8 || atoi(hw) == 12) && n_pad % (16 * atoi(hw)) == 0) waves = atoi(hw);
-                gc = {6, waves}; // gru_rec_h3
-            }
-            if (gc.version == 5 && (rc = prepare_gru_ws(ctx, n_pad))) return rc;
-            const bool bzr = gc.version == 3 || gc.version == 6;
-            auto launch_gru_h3 = [&](fvad_ctx* c, GruChoice g, const float* gi, const DevBuf& r_v2, const float* bR, float* hout,
-                                     long n, int T_, int layer, int tm) {
-                if (g.version != 6) return launch_gru(c, g, gi, r_v2, bR, hout, n, T_, layer, tm);
-                const DeviceModel::H3Scale& sc = layer ? m.h3_r2 : m.h3_r1;
-                return fvad_launch_gru_rec_h3(gi, (layer ? m.r2_h3 : m.r1_h3).p, bR, hout, n, T_, g.waves, sc.sx, sc.sw, st);
-            };
+            const char* hw = getenv("FVAD_H3_WAVES"); // tuning aid: 8 / 12
+            int waves = n_pad % 192 == 0 ? 12 : 8;
+            if (hw && (atoi(hw) == 8 || atoi(hw) == 12) && n_pad % (16 * atoi(hw)) == 0) waves = atoi(hw);
+            const long G = n_pad / 16;
+            // gi: tiled f32; hs1 / hs2 / f2 / f3: split tiled, scaled for the layer that reads them
             time_begin(ctx, "gru1_in_gemm_fc1folded");
-            rc |= gemm_h3(ws.feat, kFeatStride, m.gi1f_h3, m.h3_gi1f, bzr ? m.gi1f_bzr.p : m.gi1f_b.p, ws.gi, 1200, rows, 15, 5, 161, FVAD_ACT_NONE, 75, 0, 0);
+            rc |= gemm_h3(ws.feat, 0, kFeatStride, m.gi1f_h3, m.h3_gi1f, m.gi1f_bzr.p, ws.gi, 1, 75, T, G * T, 15, 5, 161, FVAD_ACT_NONE, 75, 0, 0, 1.0f);
             time_end(ctx);
             time_begin(ctx, "gru1_rec");
-            rc |= launch_gru_h3(ctx, gc, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T, 0, 1);
+            rc |= fvad_launch_gru_rec_h3(ws.gi, m.r1_h3.p, m.br1.p, ws.h1, ws.hs1, n_pad, T, waves, m.h3_r1.sx, m.h3_r1.sw, st);
             time_end(ctx);
             time_begin(ctx, "gru2_in_gemm");
-            rc |= gemm_h3(ws.h1, 400, m.gi2_h3, m.h3_gi2, bzr ? m.gi2_bzr.p : m.gi2_btm.p, ws.gi, 1200, rows, 15, 5, 400, FVAD_ACT_NONE, 75, 0, 0);
+            rc |= gemm_h3(ws.hs1, 1, 13, m.gi2_h3, m.h3_gi2, m.gi2_bzr.p, ws.gi, 1, 75, T, G * T, 15, 5, 400, FVAD_ACT_NONE, 75, 0, 0, 1.0f);
             time_end(ctx);
             time_begin(ctx, "gru2_rec");
-            rc |= launch_gru_h3(ctx, gc, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T, 1, 1);
+            rc |= fvad_launch_gru_rec_h3(ws.gi, m.r2_h3.p, m.br2.p, ws.h2, ws.hs2, n_pad, T, waves, m.h3_r2.sx, m.h3_r2.sw, st);
             time_end(ctx);
             time_begin(ctx, "fc2_gemm");
-            rc |= gemm_h3(ws.h2, 400, m.fc2_h3, m.h3_fc2, m.fc2h3_b.p, ws.f2, 608, rows_out, 10, 4, 400, FVAD_ACT_RELU, 38, skip ? T : 0, skip);
+            rc |= gemm_h3(ws.hs2, 1, 13, m.fc2_h3, m.h3_fc2, m.fc2h3_b.p, ws.f2, 2, 19, T - skip, G * (T - skip), 10, 4, 400, FVAD_ACT_RELU, 38, skip ? T : 0, skip, m.h3_fc3.sx);
             time_end(ctx);
             time_begin(ctx, "fc3_gemm");
-            rc |= gemm_h3(ws.f2, 608, m.fc3_h3, m.h3_fc3, m.fc3h3_b.p, ws.f3, 608, rows_out, 10, 4, 600, FVAD_ACT_RELU, 38, 0, 0);
+            rc |= gemm_h3(ws.f2, 1, 19, m.fc3_h3, m.h3_fc3, m.fc3h3_b.p, ws.f3, 2, 19, T - skip, G * (T - skip), 10, 4, 600, FVAD_ACT_RELU, 38, 0, 0, m.h3_fc4.sx);
             time_end(ctx);
             time_begin(ctx, "fc4_gemm");
-            rc |= gemm_h3(ws.f3, 608, m.fc4_h3, m.h3_fc4, m.fc4h3_b.p, ws.gains, kFeatStride, rows_out, 12, 1, 600, FVAD_ACT_SIGMOID, 11, 0, 0);
+            rc |= gemm_h3(ws.f3, 1, 19, m.fc4_h3, m.h3_fc4, m.fc4h3_b.p, ws.gains, 0, kFeatStride, T - skip, G * (T - skip), 12, 1, 600, FVAD_ACT_SIGMOID, 11, 0, 0, 1.0f);
             time_end(ctx);
             if (rc) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "no kernel instance for this layer shape");
             FVAD_HIP(ctx, hipGetLastError());

@@ -72,7 +72,7 @@ struct Workspace {
     hipEvent_t desc_ev[2] = {nullptr, nullptr}; // slot's upload has left the host
     int desc_slot = 0;
     float *feat = nullptr, *spec = nullptr, *a1 = nullptr, *gi = nullptr,
-          *h1 = nullptr, *h2 = nullptr, *f2 = nullptr, *f3 = nullptr, *gains = nullptr;
+          *h1 = nullptr, *h2 = nullptr, *hs1 = nullptr, *hs2 = nullptr, *f2 = nullptr, *f3 = nullptr, *gains = nullptr;
     // generic scratch (engine_run staging, denoised audio, band sums)
     float* in = nullptr;  size_t in_cap = 0;
     float* den = nullptr; size_t den_cap = 0;

@@ -76,12 +76,17 @@ int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const fl
 int fvad_launch_panel_gemm3(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
                             int ldc, long rows, int nt, int n_blocks, int S_steps, int K, int act,
                             int n_valid_tiles, int map_T, int map_skip, int n_wg, hipStream_t stream);
-// f16x3 form (kernels_h3.hip): Wfrag from pack_panel_h3, K = true reduction length, sx / sw = input / weight scales
-int fvad_launch_panel_gemm_h3(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
-                              int ldc, long rows, int nt, int n_blocks, int K, int act, int n_valid_tiles,
-                              int map_T, int map_skip, float sx, float sw, int n_wg, hipStream_t stream);
-int fvad_launch_gru_rec_h3(const float* gi, const float* Rfrag, const float* bR, float* hout, long n_seq_pad, int T,
-                           int waves, float sx, float sw, hipStream_t stream);
+// f16x3 form (kernels_h3.hip): Wfrag from pack_panel_h3, K = true reduction length, sx / sw = input / weight scales.
+// in_ts: A in the split tiled layout (a_ld = K-steps per row tile) or row-major f32 [sequence][seq_T][a_ld];
+// out: 0 row-major f32, 1 tiled f32 (c_ld unit tiles per row tile), 2 split tiled (c_ld K-steps, scaled by out_sx);
+// row_tiles = output row tiles of 16 rows
+int fvad_launch_panel_gemm_h3(const float* A, int in_ts, int a_ld, const float* Wfrag, const float* bias, float* C,
+                              int out, int c_ld, int seq_T, long row_tiles, int nt, int n_blocks, int K, int act,
+                              int n_valid_tiles, int map_T, int map_skip, float sx, float sw, float out_sx, int n_wg,
+                              hipStream_t stream);
+// gi, hout: tiled f32; hsplit: split tiled (13 K-steps per row tile)
+int fvad_launch_gru_rec_h3(const float* gi, const float* Rfrag, const float* bR, float* hout, float* hsplit,
+                           long n_seq_pad, int T, int waves, float sx, float sw, hipStream_t stream);
 // guard != nullptr: the kernel returns at once unless *guard != 0 (fallback behind fvad_launch_gru_ws)
 // tile_major: gi rows are [25 J][3 gates][16] (large-batch GEMM) instead of [3 gates][400] (small-batch GEMM)
 int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, float* hout,

@@ -73,20 +73,44 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, float sx,
 } // namespace
 
 // ------------------------------------------------------------------ panel GEMM, f16x3 (persistent)
-// Same skeleton as panel_gemm3_kernel: one workgroup per CU walks (row panel of WAVES*RT*16 rows, column
+// Same skeleton as panel_gemm3_kernel: one workgroup per CU walks (row panel of WAVES*RT row tiles, column
 // block of NT tiles) items; weight fragment blocks stream through two LDS slabs by LDS-DMA, SP K-steps per
 // phase; fragment reads are inline ds_read_b128 with counted lgkmcnt waits, a ring of D tiles ahead
-// (D divides NT so that ring slots are compile-time).  Activations are loaded as f32 one K-step ahead and
-// split in the middle of the tile loop, next to the other wavefront's MFMAs.
-//   S_steps: 32-deep K-steps; k_tiles = ceil(K / 16): the 16-wide k tiles that exist in A (the upper half of the
-//   last K-step is zero when k_tiles is odd).  bias_scale = 2^(Pw+Px), out_scale = 2^-(Pw+Px).
-template <int NT, int RT, int ACT, int SP, int D, int WAVES>
+// (D divides NT so that ring slots are compile-time).  Activations are loaded as f32 two K-steps ahead and
+// split at the end of a step, next to the other wavefront's MFMAs.
+//
+// Timing-only variants and a device-clock timeline of the first version (f32 row-major activations, split
+// in the loop) showed where its time went: a K-step's 90 MFMAs issue in ~1 450 cycles, but each wavefront then
+// spent ~800 cycles splitting the next step's operands and ~500 waiting for them (16 rows x 64 bytes per
+// load instruction, queued behind the weight DMA), ~700 issuing the DMA, and the partner wavefront of the SIMD
+// was usually in the same state.  So the f16x3 path keeps its intermediates in TILED layouts:
+//   * rows are regrouped into row tiles of 16 SEQUENCES at one time step,
+//         row tile R = group * T + t   holds rows (sequence 16 group + m, time t), m = 0..15,
+//     which is also what the recurrence needs (16 sequences at the same t);
+//   * "TL" (f32, gi only): [R][unit tile U][64 lanes][4 floats], lane = m + 16 q, float r = unit 16 U + 4 q + r
+//     -- one MFMA result tile per 1 KB block;
+//   * "TS" (split, every matrix-product INPUT: h1, h2, f2, f3): [R][K-step S][hi, lo][64 lanes][8 halves] -- the
+//     two f16 fragments of a K-step exactly as the MFMA takes them, already scaled by the consumer's 2^Px.  The
+//     producer (GEMM epilogue / recurrence) does the split once per value; the consumer's K loop is loads and
+//     MFMAs only, and every load or store wave-instruction moves 1 KB of contiguous memory.
+// Row-major buffers exist only at the ends: the features the STFT kernel writes (IN_TS = false: the 16 rows of
+// a tile are gathered and split in the loop, K = 161 only) and the gains the inverse STFT kernel reads
+// (OUT = 0: scattered through the lane transpose of panel_gemm3_kernel).
+//   S_steps: 32-deep K-steps; k_tiles = ceil(K / 16) (the upper half of the last K-step is zero when it is odd).
+//   a_ld: floats per row (row-major) or K-steps per row tile (TS).  c_ld: floats per row (OUT 0), unit tiles per
+//   row tile (OUT 1, TL) or K-steps per row tile (OUT 2, TS).  seq_T: rows per sequence of the row-major side.
+//   map_T / map_skip: output row tile Ro reads input row tile
+//   (Ro / (map_T - map_skip)) * map_T + map_skip + Ro % (map_T - map_skip)  (fc2 skips the 4 warm-up steps).
+//   bias_scale = 2^(Pw+Px), out_scale = 2^-(Pw+Px); out_sx: the next layer's 2^Px (OUT 2).
+template <int NT, int RT, int ACT, int SP, int D, int WAVES, bool IN_TS, int OUT>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void panel_gemm_h3_kernel(
-    const float* __restrict__ A, int lda, const float* __restrict__ Wfrag,
-    const float* __restrict__ bias, float* __restrict__ C, int ldc, int S_steps, int k_tiles, int n_blocks,
-    int n_valid_tiles, int row_map_T, int row_map_skip, unsigned n_items, float sx, float bias_scale, float out_scale)
+    const float* __restrict__ A, int a_ld, const float* __restrict__ Wfrag,
+    const float* __restrict__ bias, float* __restrict__ C, int c_ld, int seq_T, int S_steps, int k_tiles, int n_blocks,
+    int n_valid_tiles, int map_T, int map_skip, unsigned n_items, float sx, float bias_scale, float out_scale,
+    float out_sx)
 {
     static_assert(NT % D == 0, "ring slots must be compile-time");
+    static_assert(OUT != 2 || NT % 2 == 0, "the split output pairs unit tiles");
     static_assert(NT * SP * 2048 <= 65536, "ds_read offset field");
     __shared__ __attribute__((aligned(16))) float slab[2][NT * SP * 512];
     __shared__ __attribute__((aligned(16))) float sbias[2][NT * 16];
@@ -101,14 +125,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
 
     auto a_pointer = [&](unsigned item, int rt) -> const float* {
         const unsigned panel = item / (unsigned)n_blocks;
-        const unsigned row = ((panel * WAVES + wave) * RT + rt) * 16 + m;
-        unsigned a_row = row;
-        if (row_map_T > 0) {
-            const unsigned per = (unsigned)(row_map_T - row_map_skip);
-            const unsigned qd = row / per;
-            a_row = qd * (unsigned)row_map_T + (unsigned)row_map_skip + (row - qd * per);
+        unsigned R = (panel * WAVES + wave) * RT + rt;
+        if (map_T > 0) {
+            const unsigned per = (unsigned)(map_T - map_skip);
+            const unsigned g = R / per;
+            R = g * (unsigned)map_T + (unsigned)map_skip + (R - g * per);
         }
-        return A + (size_t)a_row * (size_t)lda + 4 * q;
+        if (IN_TS) return A + (size_t)R * (size_t)a_ld * 512 + lane * 4;
+        const unsigned g = R / (unsigned)seq_T, t = R - g * (unsigned)seq_T;
+        return A + ((size_t)(g * 16 + m) * seq_T + t) * (size_t)a_ld + 4 * q;
     };
     auto issue = [&](unsigned item, int p, float* dst) {
         const int nblk = (int)(item % (unsigned)n_blocks);
@@ -136,24 +161,39 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
 
     unsigned item = (gridDim.x % 8u == 0u) ? (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u : blockIdx.x;
     if (item >= n_items) return;
+#ifdef H3_STAGGER
+    // Workgroups do identical work, so left alone they all reach their epilogues together and the chip's
+    // stores (and the activation reads) come in bursts; starting them up to one item apart spreads the traffic.
+    for (int i = 0, n = (int)((blockIdx.x / 8u) % 16u) * S_steps * H3_STAGGER / 16; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+#endif
     const unsigned slab_addr[2] = {(unsigned)(uintptr_t)(lds_float*)slab[0] + (unsigned)lane * 16u,
                                    (unsigned)(uintptr_t)(lds_float*)slab[1] + (unsigned)lane * 16u};
     typedef const __attribute__((address_space(1))) f32x4* gptr4;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto load_step = [&](const float* base, int s, f32x4& lo4, f32x4& hi4) {
-        lo4 = *(gptr4)(base + 32 * s);
-        hi4 = (2 * s + 1 < k_tiles) ? *(gptr4)(base + 32 * s + 16) : zero4;
+    // one K-step of this lane's operand: TS: the two fragments as stored; row-major: two float4s to be split
+    auto load_step = [&](const float* base, int s, f32x4& a4, f32x4& b4) {
+        if (IN_TS) {
+            a4 = *(gptr4)(base + 512 * s);
+            b4 = *(gptr4)(base + 512 * s + 256);
+        } else {
+            a4 = *(gptr4)(base + 32 * s);
+            b4 = (2 * s + 1 < k_tiles) ? *(gptr4)(base + 32 * s + 16) : zero4;
+        }
+    };
+    auto to_frags = [&](const f32x4& a4, const f32x4& b4, h16x8& hi, h16x8& lo) {
+        if (IN_TS) { hi = __builtin_bit_cast(h16x8, a4); lo = __builtin_bit_cast(h16x8, b4); }
+        else split8(a4, b4, sx, hi, lo);
     };
 
     const float* a_ptr[RT];
     h16x8 xh[RT], xl[RT];   // this K-step's activation fragments
-    f32x4 ra[RT], rb[RT];   // raw f32 of the K-step after it
+    f32x4 ra[RT], rb[RT];   // the K-step after it, as loaded
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         a_ptr[rt] = a_pointer(item, rt);
         f32x4 a0, b0;
         load_step(a_ptr[rt], 0, a0, b0);
-        split8(a0, b0, sx, xh[rt], xl[rt]);
+        to_frags(a0, b0, xh[rt], xl[rt]);
         load_step(a_ptr[rt], 1, ra[rt], rb[rt]);
     }
     issue(item, 0, slab[0]);
@@ -216,7 +256,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
                 // step after it (the next item's first steps near the end: in flight across the epilogue)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
-                    split8(ra[rt], rb[rt], sx, xh[rt], xl[rt]);
+                    to_frags(ra[rt], rb[rt], xh[rt], xl[rt]);
                     const int s2 = sg + 2;
                     if (s2 < S_steps) load_step(a_ptr[rt], s2, ra[rt], rb[rt]);
                     else load_step(a_nextitem[rt], s2 - S_steps, ra[rt], rb[rt]);
@@ -229,29 +269,60 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
 
         const int nblk = (int)(item % (unsigned)n_blocks);
         const unsigned panel = item / (unsigned)n_blocks;
-        const int bp_addr = ((lane >> 2) + 16 * (lane & 3)) * 4;
-        float* c_ptr[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const unsigned row = ((panel * WAVES + wave) * RT + rt) * 16 + (unsigned)(lane >> 2);
-            c_ptr[rt] = C + (size_t)row * (size_t)ldc + nblk * (NT * 16) + 4 * (lane & 3);
-        }
         const int valid_t = n_valid_tiles - nblk * NT;
-        auto emit = [&](int t, int rt) {
-            f32x4 v = acc[rt][t] * out_scale;
+        auto activate = [&](f32x4 v) {
+            v *= out_scale;
             if (ACT == FVAD_ACT_RELU) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             } else if (ACT == FVAD_ACT_SIGMOID) {
                 v.x = act_sigmoid(v.x); v.y = act_sigmoid(v.y); v.z = act_sigmoid(v.z); v.w = act_sigmoid(v.w);
             }
-            f32x4 o;
-            o.x = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[0])));
-            o.y = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[1])));
-            o.z = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[2])));
-            o.w = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[3])));
-            *reinterpret_cast<f32x4*>(c_ptr[rt] + 16 * t) = o;
+            return v;
         };
-        if (valid_t >= NT) {
+        float* c_ptr[RT];
+        const int bp_addr = ((lane >> 2) + 16 * (lane & 3)) * 4; // row-major output: lane 4 m + q takes row m, columns 4 q ..
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const unsigned R = (panel * WAVES + wave) * RT + rt;
+            if (OUT == 1) {
+                c_ptr[rt] = C + ((size_t)R * (size_t)c_ld + (size_t)nblk * NT) * 256 + lane * 4;
+            } else if (OUT == 2) {
+                c_ptr[rt] = C + ((size_t)R * (size_t)c_ld + (size_t)(nblk * NT / 2)) * 512 + lane * 4;
+            } else {
+                const unsigned g = R / (unsigned)seq_T, t = R - g * (unsigned)seq_T;
+                c_ptr[rt] = C + ((size_t)(g * 16 + (unsigned)(lane >> 2)) * seq_T + t) * (size_t)c_ld + nblk * (NT * 16) + 4 * (lane & 3);
+            }
+        }
+        auto emit = [&](int t, int rt) {
+            f32x4 v = activate(acc[rt][t]);
+            if (OUT == 1) {
+                *reinterpret_cast<f32x4*>(c_ptr[rt] + 256 * t) = v;
+            } else {
+                f32x4 o;
+                o.x = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[0])));
+                o.y = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[1])));
+                o.z = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[2])));
+                o.w = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[3])));
+                *reinterpret_cast<f32x4*>(c_ptr[rt] + 16 * t) = o;
+            }
+        };
+        // split output: unit tiles 2 u and 2 u + 1 of this lane are the two halves of K-step u's fragments
+        auto emit_pair = [&](int u, int rt) {
+            const f32x4 v0 = activate(acc[rt][2 * u]), v1 = activate(acc[rt][2 * u + 1]);
+            h16x8 hi, lo;
+            split8(v0, v1, out_sx, hi, lo);
+            *reinterpret_cast<f32x4*>(c_ptr[rt] + 512 * u) = __builtin_bit_cast(f32x4, hi);
+            *reinterpret_cast<f32x4*>(c_ptr[rt] + 512 * u + 256) = __builtin_bit_cast(f32x4, lo);
+        };
+        if (OUT == 2) {
+#pragma unroll
+            for (int u = 0; u < NT / 2; ++u) {
+                if (2 * u < valid_t) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) emit_pair(u, rt);
+                }
+            }
+        } else if (valid_t >= NT) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -271,29 +342,33 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
     }
 }
 
-// rows must be a multiple of 256; grid = one persistent workgroup per CU.  K = true reduction length.
-// Returns -1 when there is no instance for (nt, act).
-int fvad_launch_panel_gemm_h3(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
-                              int ldc, long rows, int nt, int n_blocks, int K, int act, int n_valid_tiles,
-                              int map_T, int map_skip, float sx, float sw, int n_wg, hipStream_t stream)
+// row_tiles (output row tiles of 16 rows) must be a multiple of 16; grid = one persistent workgroup per CU.
+// in_ts: A is in the split tiled layout (a_ld = K-steps per row tile) or row-major f32 [sequence][seq_T][a_ld];
+// out: 0 row-major f32 [sequence][seq_T][c_ld], 1 TL f32 (c_ld unit tiles per row tile), 2 TS (c_ld K-steps per
+// row tile, scaled by out_sx).  K = true reduction length.  Returns -1 when there is no instance.
+int fvad_launch_panel_gemm_h3(const float* A, int in_ts, int a_ld, const float* Wfrag, const float* bias, float* C,
+                              int out, int c_ld, int seq_T, long row_tiles, int nt, int n_blocks, int K, int act,
+                              int n_valid_tiles, int map_T, int map_skip, float sx, float sw, float out_sx, int n_wg,
+                              hipStream_t stream)
 {
-    if (rows % 256) return -1;
+    if (row_tiles % 16) return -1;
     const int k_tiles = (K + 15) / 16;
     const int S_steps = (k_tiles + 1) / 2;
     if (S_steps < 3) return -1;
-    const unsigned n_items = (unsigned)((rows / 256) * n_blocks);
+    const unsigned n_items = (unsigned)((row_tiles / 16) * n_blocks);
     const unsigned grid = n_items < (unsigned)n_wg ? n_items : (unsigned)n_wg;
     const float bias_scale = sx * sw, out_scale = 1.0f / (sx * sw);
-#define CASEH(NT_, ACT_, SP_, D_)                                                                           \
-    if (nt == NT_ && act == ACT_) {                                                                         \
-        hipLaunchKernelGGL((panel_gemm_h3_kernel<NT_, 2, ACT_, SP_, D_, 8>), dim3(grid), dim3(512), 0, stream, \
-                           A, lda, Wfrag, bias, C, ldc, S_steps, k_tiles, n_blocks, n_valid_tiles, map_T,   \
-                           map_skip, n_items, sx, bias_scale, out_scale);                                   \
-        return 0;                                                                                           \
+#define CASEH(NT_, ACT_, SP_, D_, IN_, OUT_)                                                                  \
+    if (nt == NT_ && act == ACT_ && (in_ts != 0) == IN_ && out == OUT_) {                                     \
+        hipLaunchKernelGGL((panel_gemm_h3_kernel<NT_, 2, ACT_, SP_, D_, 8, IN_, OUT_>), dim3(grid), dim3(512), 0, \
+                           stream, A, a_ld, Wfrag, bias, C, c_ld, seq_T, S_steps, k_tiles, n_blocks,          \
+                           n_valid_tiles, map_T, map_skip, n_items, sx, bias_scale, out_scale, out_sx);       \
+        return 0;                                                                                             \
     }
-    CASEH(15, FVAD_ACT_NONE, 2, 3)
-    CASEH(10, FVAD_ACT_RELU, 3, 5)
-    CASEH(12, FVAD_ACT_SIGMOID, 2, 4)
+    CASEH(15, FVAD_ACT_NONE, 2, 3, false, 1)   // features (row-major) -> gi (TL)
+    CASEH(15, FVAD_ACT_NONE, 2, 5, true, 1)    // h1 (TS) -> gi (TL)
+    CASEH(10, FVAD_ACT_RELU, 3, 5, true, 2)    // fc2, fc3 (TS -> TS)
+    CASEH(12, FVAD_ACT_SIGMOID, 2, 4, true, 0) // fc4 (TS) -> gains (row-major)
 #undef CASEH
     return -1;
 }
@@ -304,8 +379,9 @@ int fvad_launch_panel_gemm_h3(const float* A, int lda, const float* Wfrag, const
 // is zero); a unit tile's recurrent weights -- [13 S][3 gates][hi, lo] fragment blocks, 78 KB, pack_gru_r_h3 --
 // stream through two LDS slabs by LDS-DMA while the previous tile computes: 9 MFMAs per K-step
 //     a_g += Wg_hi hl + Wg_hi hh + Wg_lo hh        g = z, r, n
-// i.e. 117 MFMAs of 16 cycles per tile against 300 of 32.  The gates, the f32 h_{t-1} of the z h term and the
-// h_t store are gru_rec3's: h crosses steps through hout (f32, exact), and is re-split at the top of every step.
+// i.e. 117 MFMAs of 16 cycles per tile against 300 of 32.  The gates and the f32 h_{t-1} of the z h term are
+// gru_rec3's: h crosses steps through hout (f32, exact), and is re-split at the top of every step.  gi and hout
+// are in the tiled layout of panel_gemm_h3_kernel.
 constexpr int H3_S = 13;                       // 32-deep K-steps covering H = 400 (416 slots)
 constexpr int H3_SLAB = H3_S * 3 * 512;        // floats per unit tile: 79872 bytes
 
@@ -329,7 +405,8 @@ template <int N> __device__ __forceinline__ void lds_wait1(f32x4& a)
 template <int WAVES, int D>
 __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __restrict__ gi,
                                                                 const float* __restrict__ Rfrag,
-                                                                const float* __restrict__ bR, float* hout, int T,
+                                                                const float* __restrict__ bR, float* hout,
+                                                                float* hsplit, int T,
                                                                 float sx, float bias_scale, float out_scale)
 {
     __shared__ __attribute__((aligned(16))) float slab[2][H3_SLAB];
@@ -340,28 +417,61 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __r
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15;
     const int q = lane >> 4;
+    // gi and hout are in the tiled layout (see panel_gemm_h3_kernel): this wavefront's 16 sequences are group
+    // `grp`; row tile grp * T + t holds their time step t as [unit tile][64 lanes][4 floats] blocks, so a gate's
+    // operand tile, h_{t-1}'s operand halves and the h_t store are 1 KB of contiguous memory each.  gi's unit
+    // tiles are in TILE-major gate order: 3 J + {z, r, n}.
     typedef const __attribute__((address_space(1))) char* gbytes;
-    const size_t seq0 = (size_t)(blockIdx.x * WAVES + wave) * 16;
-    gbytes gi_w = (gbytes)(gi + seq0 * T * (3 * GRU_H));
-    __attribute__((address_space(1))) char* h_w = (__attribute__((address_space(1))) char*)(hout + seq0 * T * GRU_H);
+    const size_t grp = (size_t)(blockIdx.x * WAVES + wave);
+    gbytes gi_w = (gbytes)(gi + grp * T * (3 * GRU_J * 256));
+    __attribute__((address_space(1))) char* h_w = (__attribute__((address_space(1))) char*)(hout + grp * T * (GRU_J * 256));
+    // h again in the split tiled layout (TS): what this kernel's next step and the next matrix product read
+    __attribute__((address_space(1))) char* hs_w = (__attribute__((address_space(1))) char*)(hsplit + grp * T * (H3_S * 512));
     gbytes bR_b = (gbytes)bR;
-    const unsigned gi_off = ((unsigned)m * (unsigned)T * (3 * GRU_H) + 4u * q) * 4u;
-    const unsigned h_off = ((unsigned)m * (unsigned)T * GRU_H + 4u * q) * 4u;
+    const unsigned gi_off = (unsigned)lane * 16u;
+    const unsigned h_off = (unsigned)lane * 16u;
     const unsigned b_off = 16u * q;
+    (void)m;
     auto ld4 = [](gbytes base, unsigned off) {
         asm volatile("" : "+v"(off));
         return *(const __attribute__((address_space(1))) f32x4*)(base + off);
     };
     const unsigned slab_addr[2] = {(unsigned)(uintptr_t)(lds_float*)slab[0] + (unsigned)lane * 16u,
                                    (unsigned)(uintptr_t)(lds_float*)slab[1] + (unsigned)lane * 16u};
+    // unit tile J of h_t as f16 pieces: half (J & 1) of K-step J / 2's fragments (8 bytes of hi, 8 of lo per
+    // lane); the last tile also writes the zero upper half of K-step 12
+    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+    auto store_split = [&](__attribute__((address_space(1))) char* hs_t, int J, const f32x4& h) {
+        h16x4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = h[r] * sx;
+            const _Float16 a = (_Float16)v;
+            hi[r] = a;
+            lo[r] = (_Float16)(v - (float)a);
+        }
+        unsigned o = (unsigned)lane * 16u;
+        asm volatile("" : "+v"(o));
+        __attribute__((address_space(1))) char* dst = hs_t + (J >> 1) * 2048 + (J & 1) * 8 + o;
+        if (J == GRU_J - 1) {
+            const h16x4 z4 = (h16x4){0, 0, 0, 0};
+            h16x8 hi8 = __builtin_shufflevector(hi, z4, 0, 1, 2, 3, 4, 5, 6, 7);
+            h16x8 lo8 = __builtin_shufflevector(lo, z4, 0, 1, 2, 3, 4, 5, 6, 7);
+            *(__attribute__((address_space(1))) h16x8*)dst = hi8;
+            *(__attribute__((address_space(1))) h16x8*)(dst + 1024) = lo8;
+        } else {
+            *(__attribute__((address_space(1))) h16x4*)dst = hi;
+            *(__attribute__((address_space(1))) h16x4*)(dst + 1024) = lo;
+        }
+    };
 
     h3_issue_slab<WAVES>(Rfrag, slab[0], wave, (unsigned)lane * 16u);
 
     // ---- t = 0: h_{-1} = 0, so R h + Rb = Rb
     for (int J = 0; J < GRU_J; ++J) {
-        const f32x4 giz = ld4(gi_w + 192 * J, gi_off);
-        const f32x4 gir = ld4(gi_w + 192 * J + 64, gi_off);
-        const f32x4 gin = ld4(gi_w + 192 * J + 128, gi_off);
+        const f32x4 giz = ld4(gi_w + 3072 * J, gi_off);
+        const f32x4 gir = ld4(gi_w + 3072 * J + 1024, gi_off);
+        const f32x4 gin = ld4(gi_w + 3072 * J + 2048, gi_off);
         const f32x4 bn = ld4(bR_b + 64 * J + 8 * GRU_H, b_off);
         f32x4 h;
 #pragma unroll
@@ -371,32 +481,40 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __r
             const float n = fast_tanh(gin[r] + rr * bn[r]);
             h[r] = (1.0f - z) * n + z * 0.0f;
         }
-        *(__attribute__((address_space(1))) f32x4*)(h_w + 64 * J + h_off) = h;
+        *(__attribute__((address_space(1))) f32x4*)(h_w + 1024 * J + h_off) = h;
+        store_split(hs_w, J, h);
     }
     __syncthreads();
     int buf = 0;
 
     for (int t = 1; t < T; ++t) {
-        gbytes gi_t = gi_w + (size_t)t * (12 * GRU_H);
-        gbytes h_prev = (gbytes)h_w + (size_t)(t - 1) * (4 * GRU_H);
-        __attribute__((address_space(1))) char* h_out = h_w + (size_t)t * (4 * GRU_H);
+        gbytes gi_t = gi_w + (size_t)t * (3 * GRU_J * 1024);
+        gbytes h_prev = (gbytes)h_w + (size_t)(t - 1) * (GRU_J * 1024);
+        __attribute__((address_space(1))) char* h_out = h_w + (size_t)t * (GRU_J * 1024);
 
+        gbytes hs_prev = (gbytes)hs_w + (size_t)(t - 1) * (H3_S * 2048);
+        __attribute__((address_space(1))) char* hs_out = hs_w + (size_t)t * (H3_S * 2048);
         h16x8 hh[H3_S], hl[H3_S];
-        {
-            const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int S = 0; S < H3_S; ++S) {
-                const f32x4 a = ld4(h_prev + 128 * S, h_off);
-                const f32x4 b = (2 * S + 1 < GRU_J) ? ld4(h_prev + 128 * S + 64, h_off) : zero4;
-                split8(a, b, sx, hh[S], hl[S]);
-            }
-#pragma unroll
-            for (int S = 0; S < H3_S; ++S) asm volatile("" : "+v"(hh[S]), "+v"(hl[S]));
+        for (int S = 0; S < H3_S; ++S) {
+            hh[S] = __builtin_bit_cast(h16x8, ld4(hs_prev + 2048 * S, h_off));
+            hl[S] = __builtin_bit_cast(h16x8, ld4(hs_prev + 2048 * S + 1024, h_off));
         }
+#pragma unroll
+        for (int S = 0; S < H3_S; ++S) asm volatile("" : "+v"(hh[S]), "+v"(hl[S]));
 
         for (int J = 0; J < GRU_J; ++J) {
             const int nJ = (J + 1 == GRU_J) ? 0 : J + 1;
-            h3_issue_slab<WAVES>(Rfrag + (size_t)nJ * H3_SLAB, slab[buf ^ 1], wave, (unsigned)lane * 16u);
+            // Cache prefetch: the next tile's gate operands (3 KB of gi, streamed from HBM) are touched one tile
+            // ahead by ONE dword load per lane at a 64-byte stride -- one VGPR instead of the 12 a register
+            // prefetch would hold across the K loop; the real loads below then hit in L2 (~0.3 us instead of ~2).
+            {
+                unsigned po = (unsigned)lane * 64u;
+                asm volatile("" : "+v"(po));
+                gbytes nxt = (J + 1 < GRU_J) ? gi_t + 3072 * (J + 1) : gi_t + (size_t)(t + 1 < T ? 3 * GRU_J * 1024 : 0);
+                float touch = *(const __attribute__((address_space(1))) float*)(nxt + po);
+                asm volatile("" :: "v"(touch));
+            }
 
             // ds_read's offset field is 16 bits and a slab is 78 KB: one base for K-steps 0..7, one for 8..12
             const unsigned rd0 = slab_addr[buf], rd1 = rd0 + 8 * 6144;
@@ -443,12 +561,16 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __r
                 an = MFMA_H(__builtin_bit_cast(h16x8, w[k][5]), xh, an);
                 if constexpr (S + D < H3_S) read_step(std::integral_constant<int, S + D>{}, std::integral_constant<int, k>{});
             };
-            constexpr int LOAD_AT = 9;
-            SFor<0, LOAD_AT>::run(k_step);
-            const f32x4 giz = ld4(gi_t + 192 * J, gi_off);
-            const f32x4 gir = ld4(gi_t + 192 * J + 64, gi_off);
-            const f32x4 gin = ld4(gi_t + 192 * J + 128, gi_off);
-            const f32x4 hp = ld4(h_prev + 64 * J, h_off);
+            // the next slab's DMA is issued two K-steps into the tile, beside the other wavefronts' MFMAs (at the
+            // top of the tile all wavefronts would stand in the address unit's queue together)
+            constexpr int ISSUE_AT = 2, LOAD_AT = 9;
+            SFor<0, ISSUE_AT>::run(k_step);
+            h3_issue_slab<WAVES>(Rfrag + (size_t)nJ * H3_SLAB, slab[buf ^ 1], wave, (unsigned)lane * 16u);
+            SFor<ISSUE_AT, LOAD_AT>::run(k_step);
+            const f32x4 giz = ld4(gi_t + 3072 * J, gi_off);
+            const f32x4 gir = ld4(gi_t + 3072 * J + 1024, gi_off);
+            const f32x4 gin = ld4(gi_t + 3072 * J + 2048, gi_off);
+            const f32x4 hp = ld4(h_prev + 1024 * J, h_off);
             SFor<LOAD_AT, H3_S>::run(k_step);
             f32x4 h;
 #pragma unroll
@@ -461,27 +583,29 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __r
             {
                 unsigned o = h_off;
                 asm volatile("" : "+v"(o));
-                *(__attribute__((address_space(1))) f32x4*)(h_out + 64 * J + o) = h;
+                *(__attribute__((address_space(1))) f32x4*)(h_out + 1024 * J + o) = h;
             }
-            asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+            store_split(hs_out, J, h);
+            // the slab DMA is older than this tile's three stores
+            asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
             buf ^= 1;
         }
     }
 }
 
-// Rfrag: pack_gru_r_h3 layout; sx / sw: the scales of h (2^14) and of R
-int fvad_launch_gru_rec_h3(const float* gi, const float* Rfrag, const float* bR, float* hout, long n_seq_pad, int T,
-                           int waves, float sx, float sw, hipStream_t stream)
+// Rfrag: pack_gru_r_h3 layout; sx / sw: the scales of h (2^14) and of R; gi, hout: TL; hsplit: TS with 13 K-steps
+int fvad_launch_gru_rec_h3(const float* gi, const float* Rfrag, const float* bR, float* hout, float* hsplit,
+                           long n_seq_pad, int T, int waves, float sx, float sw, hipStream_t stream)
 {
     if (waves <= 0 || n_seq_pad % (16 * waves)) return -1;
     const unsigned grid = (unsigned)(n_seq_pad / (16 * waves));
     const float out_scale = 1.0f / (sx * sw);
     if (waves == 8) {
-        hipLaunchKernelGGL((gru_rec_h3_kernel<8, 2>), dim3(grid), dim3(512), 0, stream, gi, Rfrag, bR, hout, T, sx, sx * sw, out_scale);
+        hipLaunchKernelGGL((gru_rec_h3_kernel<8, 2>), dim3(grid), dim3(512), 0, stream, gi, Rfrag, bR, hout, hsplit, T, sx, sx * sw, out_scale);
         return 0;
     }
     if (waves == 12) {
-        hipLaunchKernelGGL((gru_rec_h3_kernel<12, 1>), dim3(grid), dim3(768), 0, stream, gi, Rfrag, bR, hout, T, sx, sx * sw, out_scale);
+        hipLaunchKernelGGL((gru_rec_h3_kernel<12, 1>), dim3(grid), dim3(768), 0, stream, gi, Rfrag, bR, hout, hsplit, T, sx, sx * sw, out_scale);
         return 0;
     }
     return -1;
