@@ -32,10 +32,13 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/F16 MFMA, dense (the f16x3 kernels issue v_mfma_f32_16x16x32_f16)
 HBM_PEAK_GBPS = 8000.0          # spec
 FRAMES_PER_CHUNK = 50
 CHUNK = 24000
 GRU_FLOP_PER_CHUNK_LAUNCH = 53 * 2 * 1200 * 400   # one GRU layer's recurrence: 53 steps with h != 0
+# the same recurrence as the f16x3 kernel executes it: three f16 MFMAs per product, K padded 400 -> 416
+GRU_H3_MFMA_FLOP_PER_CHUNK_LAUNCH = 53 * 2 * 1200 * 416 * 3
 # the network as the reference runs it (fc1 separate, no padding): "effective" FLOPs
 NSNET2_FLOP_PER_CHUNK = 2 * (54 * (161 * 400 + 2 * 1200 * 400) + 53 * 2 * 1200 * 400
                              + 50 * (400 * 600 + 600 * 600 + 600 * 161))
@@ -55,6 +58,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-2 / config-3 side measurements")
     ap.add_argument("--vad-threads", type=int, default=0)
+    ap.add_argument("--nn-math", default="f16x3", choices=("f16x3", "f32"),
+                    help="arithmetic of the large-batch NSNet2 matrix products (fvad_ctx_set_nn_math): f16x3 = three f16 "
+                         "MFMAs on split f32 operands, f32-class accuracy (default); f32 = v_mfma_f32_16x16x4_f32")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL; one rank per GPU) or gloo (rehearsal: every rank on cuda:0)")
     ap.add_argument("--config", default="headline", choices=("headline", "cfg4"),
@@ -299,17 +305,18 @@ def cpu_model():
     return "unknown"
 
 
-def pmc_traffic(chunks_per_launch, raw=False):
+def pmc_traffic(chunks_per_launch, nn_math="f16x3", raw=False):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_summary.json; counters cannot be read from inside the benchmark), or None when
-    the profile was taken at a different launch size."""
+    the profile was taken at a different launch size or with the other arithmetic."""
+    want = "gru_rec_h3_kernel" if nn_math == "f16x3" else "gru_rec3_kernel"
     try:
         files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
         d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
         if d["chunks_per_launch"] != min(chunks_per_launch, 49152):
             return None
         for k, v in d["kernels"].items():
-            if k.startswith("gru_rec3_kernel") or k.startswith("gru_rec2_kernel"):
+            if k.startswith(want):
                 return v["hbm_bytes_per_launch"] if not raw else v.get("hbm_bytes_per_launch_raw_counters")
     except Exception:
         pass
@@ -341,6 +348,8 @@ def main():
     L = fv.lib()
     ctx = fv.Context(local_rank)
     ctx.load_synth(7)
+    ctx.set_nn_math(args.nn_math)
+    nn_math = os.environ.get("FVAD_NN_MATH", args.nn_math)   # the environment variable overrides the setting
     weights = ctx.weights()
 
     if args.config == "cfg4":
@@ -442,6 +451,27 @@ def main():
     barrier()
     dev_elapsed = time.perf_counter() - t1
 
+    # ---- the other arithmetic on the same batch, for the record (device-only, three steps)
+    other_math = None
+    if rank == 0 and not args.no_extra:
+        other = "f32" if nn_math == "f16x3" else "f16x3"
+        if "FVAD_NN_MATH" not in os.environ:
+            ctx.set_nn_math(other)
+            gpu_stage(0)
+            ctx.enable_timing(True)
+            barrier()
+            t2 = time.perf_counter()
+            for i in range(3):
+                gpu_stage(i & 1)
+            barrier()
+            dt = time.perf_counter() - t2
+            kt = ctx.kernel_times()
+            ctx.enable_timing(False)
+            other_math = {"nn_math": other, "device_only_ms_per_step": dt / 3 * 1e3,
+                          "device_only_frames_per_s": 3 * frames_per_step / dt,
+                          "kernel_ms_per_step": {k: v / 3 for k, v in kt.items()}}
+            ctx.set_nn_math(nn_math)
+
     # ---- the same batch read as 192 STEREO streams (the reference's real corpus is stereo: channel_vol_ratio):
     # the GPU work is identical (a lane is a channel), the host stage runs 2-channel state machines on
     # min-over-channels band sums and the per-chunk RMS ratio (BufferedVolumeAnalyzer.zig:48-69)
@@ -482,7 +512,11 @@ def main():
         value = total_frames / elapsed
         gru_ms = (ktimes.get("gru1_rec", 0.0) + ktimes.get("gru2_rec", 0.0)) / (2 * args.steps)
         gru_flop = lanes * n_chunks * GRU_FLOP_PER_CHUNK_LAUNCH
-        achieved = gru_flop / (gru_ms * 1e-3) / 1e12 if gru_ms > 0 else 0.0
+        h3 = nn_math == "f16x3"
+        gru_mfma_flop = lanes * n_chunks * (GRU_H3_MFMA_FLOP_PER_CHUNK_LAUNCH if h3 else GRU_FLOP_PER_CHUNK_LAUNCH)
+        mfma_peak = F16_MFMA_PEAK_TFLOPS if h3 else FP32_MFMA_PEAK_TFLOPS
+        achieved = gru_mfma_flop / (gru_ms * 1e-3) / 1e12 if gru_ms > 0 else 0.0
+        gru_hbm_bytes = lanes * n_chunks * (54 * 1200 * 4 + 2 * 54 * 400 * 4 + (2 * 54 * 416 * 4 if h3 else 0))
         dev_ms_step = sum(ktimes.values()) / args.steps
         nn_ms = sum(v for k, v in ktimes.items() if "gemm" in k or "gru" in k) / args.steps
         out = {
@@ -496,7 +530,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (NSNet2 products as f16x3: three f16 MFMAs on split f32 operands, f32 accumulate)" if h3 else "f32",
             "data": "synthetic 48 kHz mono (seeded noise floor + 500-2000 Hz harmonic bursts; every lane a different stream), random-init NSNet2 weights seed 7",
             "config": {"workload": f"full pipeline (window->STFT->NSNet2->iSTFT->FFT1024 band->VAD decision), "
                                    f"{lanes} streams x {seconds} s per GPU per step = {lanes * n_chunks} chunks = "
@@ -507,17 +541,26 @@ def main():
                        "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
             "audio_seconds_per_s": value / 100.0,
             "device_only_frames_per_s": total_frames / dev_elapsed,
-            "roofline": {"bound": "mfma", "kernel": "gru_rec3_kernel<12, 2> (fp32 v_mfma_f32_16x16x4_f32)",
-                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(lanes * n_chunks),
-                         # FETCH_SIZE + WRITE_SIZE without the guide's x2 fetch correction: for this kernel's 64-byte
-                         # row segments the uncorrected sum equals the algorithmic 21.2 GB
-                         "traffic_uncorrected_counters": pmc_traffic(lanes * n_chunks, raw=True),
-                         "algorithmic_hbm_bytes_per_launch": lanes * n_chunks * (54 * 1200 * 4 + 2 * 54 * 400 * 4),
-                         "launch_ms": gru_ms, "flop_per_launch": gru_flop},
+            # dominant kernel: the GRU recurrence (two launches per step).  achieved = MFMA FLOPs the kernel executes
+            # (f16x3: three f16 MFMAs per f32 product, K padded to 416) / its HIP-event time; peak = the dense MFMA
+            # peak of the instruction it issues
+            "roofline": {"bound": "mfma",
+                         "kernel": ("gru_rec_h3_kernel<12, 1> (v_mfma_f32_16x16x32_f16, three per f32 product)" if h3 else
+                                    "gru_rec3_kernel<12, 2> (fp32 v_mfma_f32_16x16x4_f32)"),
+                         "achieved": achieved, "peak": mfma_peak, "unit": "TFLOP/s",
+                         "frac": achieved / mfma_peak, "traffic": pmc_traffic(lanes * n_chunks, nn_math),
+                         # FETCH_SIZE + WRITE_SIZE without the guide's x2 fetch correction
+                         "traffic_uncorrected_counters": pmc_traffic(lanes * n_chunks, nn_math, raw=True),
+                         "algorithmic_hbm_bytes_per_launch": gru_hbm_bytes,
+                         "algorithmic_hbm_frac_of_8TBps": gru_hbm_bytes / (gru_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if gru_ms > 0 else 0.0,
+                         "launch_ms": gru_ms, "flop_per_launch": gru_mfma_flop,
+                         # the same launch priced as the f32 arithmetic it replaces (2 x 400 x 1200 per step and sequence)
+                         "f32_equivalent_tflops": gru_flop / (gru_ms * 1e-3) / 1e12 if gru_ms > 0 else 0.0,
+                         "f32_equivalent_frac_of_f32_mfma_peak": gru_flop / (gru_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS if gru_ms > 0 else 0.0},
             "roofline_pipeline": {
-                "nsnet2_executed_tflops": lanes * n_chunks * NSNET2_EXECUTED_FLOP_PER_CHUNK / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
-                "nsnet2_executed_frac_of_mfma_peak": lanes * n_chunks * NSNET2_EXECUTED_FLOP_PER_CHUNK / (nn_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS if nn_ms else 0.0,
+                "nn_math": nn_math,
+                "nsnet2_f32_equivalent_tflops": lanes * n_chunks * NSNET2_EXECUTED_FLOP_PER_CHUNK / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
+                "nsnet2_f32_equivalent_frac_of_f32_mfma_peak": lanes * n_chunks * NSNET2_EXECUTED_FLOP_PER_CHUNK / (nn_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS if nn_ms else 0.0,
                 "nsnet2_effective_tflops_unfolded_network": lanes * n_chunks * NSNET2_FLOP_PER_CHUNK / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
                 "hbm_algorithmic_GBps": frames_per_step * 3840 / (dev_ms_step * 1e-3) / 1e9 if dev_ms_step else 0.0,
                 "hbm_frac_of_8TBps": frames_per_step * 3840 / (dev_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS if dev_ms_step else 0.0},
@@ -526,6 +569,7 @@ def main():
                           "ppv": agg.precision.overall, "collective": collective},
             "self_check": self_check,
             "headline_as_stereo": stereo,
+            "other_nn_math": other_math,
             "host_vad_threads": vad_threads,
             "gpu_stage_wall_ms": float(np.mean(gpu_wall_ms[args.warmup:])),
             "kernel_ms_sum": float(sum(ktimes.values()) / args.steps),
@@ -549,6 +593,7 @@ def main():
 
 
 def side_measurements(pkg, fv, ctx, torch, dev):
+    note = lambda m: print(f"bench.py: side measurement: {m}", file=sys.stderr, flush=True)  # noqa: E731
     """BASELINE config 2 (FFT isolation, 1024 frames and 2^20 frames) and config 3 at its literal
     batch (82 chunks = 4100 frames), device-resident, timed with HIP events."""
     import ctypes as C
@@ -557,6 +602,7 @@ def side_measurements(pkg, fv, ctx, torch, dev):
     f = fv.FFT(ctx, 320, 16000)
     win = torch.from_numpy(np.ascontiguousarray(__import__("numpy").sqrt(
         0.5 - 0.5 * np.cos(2 * np.pi * np.arange(320) / 319)).astype(np.float32))).to(dev)
+    note("config 2 (FFT isolation)")
     for n in (1024, 1 << 20):
         x = torch.rand((n, 320), device=dev) * 2 - 1
         mag = torch.empty((n, 161), device=dev)
@@ -590,6 +636,7 @@ def side_measurements(pkg, fv, ctx, torch, dev):
     # host-buffer entry point (what AudioPipeline.pushSamples hands over): H2D of the 48 kHz input, the
     # kernels, D2H of band sums / RMS (and of the denoised audio in the second figure).  Pageable numpy
     # buffers, staged by the library; never `value`.
+    note("host-buffer entry point (PCIe-inclusive)")
     n_l, n_s = 128, 64
     import ctypes as C
     src = [pkg.synth.make_stream(n_s + 0.5, seed=500 + i)[0][0][: n_s * 48000].copy() for i in range(4)]
@@ -680,6 +727,7 @@ def side_measurements(pkg, fv, ctx, torch, dev):
         extra["pcie_inclusive_pinned"] = {"error": repr(e)}
     # BASELINE config 4's shape on one GPU: 21 long streams (Miami-race sized, 7200 s each) end to end,
     # input resident in HBM: kernels, D2H of band sums / RMS, host VAD for all 21 streams
+    note("config 4's corpus shape on one GPU")
     try:
         n_st, n_sec = 21, 7200
         base = torch.from_numpy(pkg.synth.make_stream(600.5, seed=900)[0][0][: 600 * 48000].copy()).to(dev)
@@ -727,6 +775,7 @@ def side_measurements(pkg, fv, ctx, torch, dev):
         extra["cfg4_shape_21_streams_x_7200s_one_gpu"] = {"error": repr(e)}
     # BASELINE config 5's "hipGraph-captured steady-state loop": the same device-resident call launched
     # directly and replayed from a captured hipGraph (FVAD_GRAPH=1), at a large and at the smallest shape
+    note("hipGraph replay")
     try:
         for tag, n_l2, n_ch2, reps in (("16384_chunks", 128, 128, 6), ("2_chunks", 2, 1, 40)):
             xg = torch.from_numpy(np.stack([host_pcm[i % len(host_pcm)][: n_ch2 * CHUNK] for i in range(n_l2)])).to(dev)

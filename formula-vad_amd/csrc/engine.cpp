@@ -247,8 +247,13 @@ int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
     return FVAD_OK;
 }
 
+// FVAD_TRACE_KERNELS=1 (debugging aid): name every stage on stderr and wait for it, so that a faulting kernel is
+// the last one named
+static const char* g_trace_name = nullptr;
 void time_begin(fvad_ctx* ctx, const char* name)
 {
+    static const bool trace = getenv("FVAD_TRACE_KERNELS") != nullptr;
+    if (trace) { g_trace_name = name; fprintf(stderr, "fvad: %s ...", name); fflush(stderr); }
     if (!ctx->timing) return;
     KernelTime kt;
     kt.name = name;
@@ -259,6 +264,12 @@ void time_begin(fvad_ctx* ctx, const char* name)
 }
 void time_end(fvad_ctx* ctx)
 {
+    if (g_trace_name) {
+        const hipError_t e = hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, " %s\n", e == hipSuccess ? "done" : hipGetErrorString(e));
+        fflush(stderr);
+        g_trace_name = nullptr;
+    }
     if (!ctx->timing) return;
     hipEventRecord(ctx->times.back().e1, ctx->stream);
 }

@@ -505,16 +505,7 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __r
 
         for (int J = 0; J < GRU_J; ++J) {
             const int nJ = (J + 1 == GRU_J) ? 0 : J + 1;
-            // Cache prefetch: the next tile's gate operands (3 KB of gi, streamed from HBM) are touched one tile
-            // ahead by ONE dword load per lane at a 64-byte stride -- one VGPR instead of the 12 a register
-            // prefetch would hold across the K loop; the real loads below then hit in L2 (~0.3 us instead of ~2).
-            {
-                unsigned po = (unsigned)lane * 64u;
-                asm volatile("" : "+v"(po));
-                gbytes nxt = (J + 1 < GRU_J) ? gi_t + 3072 * (J + 1) : gi_t + (size_t)(t + 1 < T ? 3 * GRU_J * 1024 : 0);
-                float touch = *(const __attribute__((address_space(1))) float*)(nxt + po);
-                asm volatile("" :: "v"(touch));
-            }
+            h3_issue_slab<WAVES>(Rfrag + (size_t)nJ * H3_SLAB, slab[buf ^ 1], wave, (unsigned)lane * 16u);
 
             // ds_read's offset field is 16 bits and a slab is 78 KB: one base for K-steps 0..7, one for 8..12
             const unsigned rd0 = slab_addr[buf], rd1 = rd0 + 8 * 6144;
@@ -561,12 +552,8 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __r
                 an = MFMA_H(__builtin_bit_cast(h16x8, w[k][5]), xh, an);
                 if constexpr (S + D < H3_S) read_step(std::integral_constant<int, S + D>{}, std::integral_constant<int, k>{});
             };
-            // the next slab's DMA is issued two K-steps into the tile, beside the other wavefronts' MFMAs (at the
-            // top of the tile all wavefronts would stand in the address unit's queue together)
-            constexpr int ISSUE_AT = 2, LOAD_AT = 9;
-            SFor<0, ISSUE_AT>::run(k_step);
-            h3_issue_slab<WAVES>(Rfrag + (size_t)nJ * H3_SLAB, slab[buf ^ 1], wave, (unsigned)lane * 16u);
-            SFor<ISSUE_AT, LOAD_AT>::run(k_step);
+            constexpr int LOAD_AT = 9;
+            SFor<0, LOAD_AT>::run(k_step);
             const f32x4 giz = ld4(gi_t + 3072 * J, gi_off);
             const f32x4 gir = ld4(gi_t + 3072 * J + 1024, gi_off);
             const f32x4 gin = ld4(gi_t + 3072 * J + 2048, gi_off);
