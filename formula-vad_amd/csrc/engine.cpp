@@ -449,13 +449,13 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
             rc |= gemm_h3(ws.feat, 0, kFeatStride, m.gi1f_h3, m.h3_gi1f, m.gi1f_bzr.p, ws.gi, 1, 75, T, G * T, 15, 5, 161, FVAD_ACT_NONE, 75, 0, 0, 1.0f);
             time_end(ctx);
             time_begin(ctx, "gru1_rec");
-            rc |= fvad_launch_gru_rec_h3(ws.gi, m.r1_h3.p, m.br1.p, ws.h1, ws.hs1, n_pad, T, waves, m.h3_r1.sx, m.h3_r1.sw, st);
+            rc |= fvad_launch_gru_rec_h3(ws.gi, m.r1_h3.p, m.br1.p, ws.hs1, n_pad, T, waves, m.h3_r1.sx, m.h3_r1.sw, st);
             time_end(ctx);
             time_begin(ctx, "gru2_in_gemm");
             rc |= gemm_h3(ws.hs1, 1, 13, m.gi2_h3, m.h3_gi2, m.gi2_bzr.p, ws.gi, 1, 75, T, G * T, 15, 5, 400, FVAD_ACT_NONE, 75, 0, 0, 1.0f);
             time_end(ctx);
             time_begin(ctx, "gru2_rec");
-            rc |= fvad_launch_gru_rec_h3(ws.gi, m.r2_h3.p, m.br2.p, ws.h2, ws.hs2, n_pad, T, waves, m.h3_r2.sx, m.h3_r2.sw, st);
+            rc |= fvad_launch_gru_rec_h3(ws.gi, m.r2_h3.p, m.br2.p, ws.hs2, n_pad, T, waves, m.h3_r2.sx, m.h3_r2.sw, st);
             time_end(ctx);
             time_begin(ctx, "fc2_gemm");
             rc |= gemm_h3(ws.hs2, 1, 13, m.fc2_h3, m.h3_fc2, m.fc2h3_b.p, ws.f2, 2, 19, T - skip, G * (T - skip), 10, 4, 400, FVAD_ACT_RELU, 38, skip ? T : 0, skip, m.h3_fc3.sx);

@@ -84,8 +84,8 @@ int fvad_launch_panel_gemm_h3(const float* A, int in_ts, int a_ld, const float* 
                               int out, int c_ld, int seq_T, long row_tiles, int nt, int n_blocks, int K, int act,
                               int n_valid_tiles, int map_T, int map_skip, float sx, float sw, float out_sx, int n_wg,
                               hipStream_t stream);
-// gi, hout: tiled f32; hsplit: split tiled (13 K-steps per row tile)
-int fvad_launch_gru_rec_h3(const float* gi, const float* Rfrag, const float* bR, float* hout, float* hsplit,
+// gi: tiled f32; hsplit: h as split fragments (13 K-steps per row tile), the only form h exists in
+int fvad_launch_gru_rec_h3(const float* gi, const float* Rfrag, const float* bR, float* hsplit,
                            long n_seq_pad, int T, int waves, float sx, float sw, hipStream_t stream);
 // guard != nullptr: the kernel returns at once unless *guard != 0 (fallback behind fvad_launch_gru_ws)
 // tile_major: gi rows are [25 J][3 gates][16] (large-batch GEMM) instead of [3 gates][400] (small-batch GEMM)

@@ -379,9 +379,8 @@ int fvad_launch_panel_gemm_h3(const float* A, int in_ts, int a_ld, const float* 
 // is zero); a unit tile's recurrent weights -- [13 S][3 gates][hi, lo] fragment blocks, 78 KB, pack_gru_r_h3 --
 // stream through two LDS slabs by LDS-DMA while the previous tile computes: 9 MFMAs per K-step
 //     a_g += Wg_hi hl + Wg_hi hh + Wg_lo hh        g = z, r, n
-// i.e. 117 MFMAs of 16 cycles per tile against 300 of 32.  The gates and the f32 h_{t-1} of the z h term are
-// gru_rec3's: h crosses steps through hout (f32, exact), and is re-split at the top of every step.  gi and hout
-// are in the tiled layout of panel_gemm_h3_kernel.
+// i.e. 117 MFMAs of 16 cycles per tile against 300 of 32.  The gates are gru_rec3's.  gi is in the tiled f32
+// layout of panel_gemm_h3_kernel; h is written, and read back at the top of the next step, as split fragments.
 constexpr int H3_S = 13;                       // 32-deep K-steps covering H = 400 (416 slots)
 constexpr int H3_SLAB = H3_S * 3 * 512;        // floats per unit tile: 79872 bytes
 
@@ -405,7 +404,7 @@ template <int N> __device__ __forceinline__ void lds_wait1(f32x4& a)
 template <int WAVES, int D>
 __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __restrict__ gi,
                                                                 const float* __restrict__ Rfrag,
-                                                                const float* __restrict__ bR, float* hout,
+                                                                const float* __restrict__ bR,
                                                                 float* hsplit, int T,
                                                                 float sx, float bias_scale, float out_scale)
 {
@@ -424,13 +423,16 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __r
     typedef const __attribute__((address_space(1))) char* gbytes;
     const size_t grp = (size_t)(blockIdx.x * WAVES + wave);
     gbytes gi_w = (gbytes)(gi + grp * T * (3 * GRU_J * 256));
-    __attribute__((address_space(1))) char* h_w = (__attribute__((address_space(1))) char*)(hout + grp * T * (GRU_J * 256));
-    // h again in the split tiled layout (TS): what this kernel's next step and the next matrix product read
+    // h lives only in the split tiled layout (TS): the f16 pieces of h 2^14 are what this kernel's next step and
+    // the next matrix product take as operands, and the z h_{t-1} term reads h_{t-1} back as hi + lo -- 22
+    // significand bits instead of 24, which changes the gains by less than the f32 accumulation does (emulated:
+    // rms error against float64 8.2e-8 -> 8.3e-8, maximum unchanged)
     __attribute__((address_space(1))) char* hs_w = (__attribute__((address_space(1))) char*)(hsplit + grp * T * (H3_S * 512));
     gbytes bR_b = (gbytes)bR;
     const unsigned gi_off = (unsigned)lane * 16u;
     const unsigned h_off = (unsigned)lane * 16u;
     const unsigned b_off = 16u * q;
+    const float inv_sx = 1.0f / sx;
     (void)m;
     auto ld4 = [](gbytes base, unsigned off) {
         asm volatile("" : "+v"(off));
@@ -481,7 +483,6 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __r
             const float n = fast_tanh(gin[r] + rr * bn[r]);
             h[r] = (1.0f - z) * n + z * 0.0f;
         }
-        *(__attribute__((address_space(1))) f32x4*)(h_w + 1024 * J + h_off) = h;
         store_split(hs_w, J, h);
     }
     __syncthreads();
@@ -489,8 +490,6 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __r
 
     for (int t = 1; t < T; ++t) {
         gbytes gi_t = gi_w + (size_t)t * (3 * GRU_J * 1024);
-        gbytes h_prev = (gbytes)h_w + (size_t)(t - 1) * (GRU_J * 1024);
-        __attribute__((address_space(1))) char* h_out = h_w + (size_t)t * (GRU_J * 1024);
 
         gbytes hs_prev = (gbytes)hs_w + (size_t)(t - 1) * (H3_S * 2048);
         __attribute__((address_space(1))) char* hs_out = hs_w + (size_t)t * (H3_S * 2048);
@@ -557,7 +556,16 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __r
             const f32x4 giz = ld4(gi_t + 3072 * J, gi_off);
             const f32x4 gir = ld4(gi_t + 3072 * J + 1024, gi_off);
             const f32x4 gin = ld4(gi_t + 3072 * J + 2048, gi_off);
-            const f32x4 hp = ld4(h_prev + 1024 * J, h_off);
+            // h_{t-1} of this unit tile: half (J & 1) of K-step J / 2's fragments
+            typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+            h16x4 hp_hi, hp_lo;
+            {
+                unsigned o = h_off;
+                asm volatile("" : "+v"(o));
+                gbytes src = hs_prev + (J >> 1) * 2048 + (J & 1) * 8 + o;
+                hp_hi = *(const __attribute__((address_space(1))) h16x4*)src;
+                hp_lo = *(const __attribute__((address_space(1))) h16x4*)(src + 1024);
+            }
             SFor<LOAD_AT, H3_S>::run(k_step);
             f32x4 h;
 #pragma unroll
@@ -565,34 +573,30 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __r
                 const float z = fast_sigmoid(giz[r] + az[r] * out_scale);
                 const float rr = fast_sigmoid(gir[r] + ar[r] * out_scale);
                 const float n = fast_tanh(gin[r] + rr * (an[r] * out_scale));
-                h[r] = (1.0f - z) * n + z * hp[r];
-            }
-            {
-                unsigned o = h_off;
-                asm volatile("" : "+v"(o));
-                *(__attribute__((address_space(1))) f32x4*)(h_out + 1024 * J + o) = h;
+                const float hp = ((float)hp_hi[r] + (float)hp_lo[r]) * inv_sx;
+                h[r] = (1.0f - z) * n + z * hp;
             }
             store_split(hs_out, J, h);
-            // the slab DMA is older than this tile's three stores
-            asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+            // the slab DMA is older than this tile's two stores
+            asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
             buf ^= 1;
         }
     }
 }
 
-// Rfrag: pack_gru_r_h3 layout; sx / sw: the scales of h (2^14) and of R; gi, hout: TL; hsplit: TS with 13 K-steps
-int fvad_launch_gru_rec_h3(const float* gi, const float* Rfrag, const float* bR, float* hout, float* hsplit,
+// Rfrag: pack_gru_r_h3 layout; sx / sw: the scales of h (2^14) and of R; gi: TL; hsplit: TS with 13 K-steps
+int fvad_launch_gru_rec_h3(const float* gi, const float* Rfrag, const float* bR, float* hsplit,
                            long n_seq_pad, int T, int waves, float sx, float sw, hipStream_t stream)
 {
     if (waves <= 0 || n_seq_pad % (16 * waves)) return -1;
     const unsigned grid = (unsigned)(n_seq_pad / (16 * waves));
     const float out_scale = 1.0f / (sx * sw);
     if (waves == 8) {
-        hipLaunchKernelGGL((gru_rec_h3_kernel<8, 2>), dim3(grid), dim3(512), 0, stream, gi, Rfrag, bR, hout, hsplit, T, sx, sx * sw, out_scale);
+        hipLaunchKernelGGL((gru_rec_h3_kernel<8, 2>), dim3(grid), dim3(512), 0, stream, gi, Rfrag, bR, hsplit, T, sx, sx * sw, out_scale);
         return 0;
     }
     if (waves == 12) {
-        hipLaunchKernelGGL((gru_rec_h3_kernel<12, 1>), dim3(grid), dim3(768), 0, stream, gi, Rfrag, bR, hout, hsplit, T, sx, sx * sw, out_scale);
+        hipLaunchKernelGGL((gru_rec_h3_kernel<12, 1>), dim3(grid), dim3(768), 0, stream, gi, Rfrag, bR, hsplit, T, sx, sx * sw, out_scale);
         return 0;
     }
     return -1;
