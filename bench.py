@@ -373,8 +373,10 @@ def main():
     d_den = ctx.device_alloc(lanes * n_chunks * CHUNK * 4)
     d_band = [ctx.device_alloc(lanes * n_frames_fft * 4) for _ in range(2)]
     d_rms = [ctx.device_alloc(lanes * n_chunks * 4) for _ in range(2)]
-    h_band = [np.empty((lanes, n_frames_fft), np.float32) for _ in range(2)]
-    h_rms = [np.empty((lanes, n_chunks), np.float32) for _ in range(2)]
+    # page-locked (fvad_host_alloc): a device -> host copy into pageable memory would block the enqueueing thread
+    # until everything queued before it has run
+    h_band = [ctx.host_alloc(lanes * n_frames_fft).reshape(lanes, n_frames_fft) for _ in range(2)]
+    h_rms = [ctx.host_alloc(lanes * n_chunks).reshape(lanes, n_chunks) for _ in range(2)]
     # a 1-GPU box gives this process a 16-CPU share whatever os.cpu_count() says
     vad_threads = args.vad_threads or min(lanes, 16, max(1, (os.cpu_count() or 2) - 1))
 
@@ -391,8 +393,12 @@ def main():
         results[step] = vad_batch.run(h_band[slot], h_rms[slot], n_threads=vad_threads)
         host_ms.append((time.perf_counter() - t_h0) * 1e3)
 
+    eopts = fv.EngineOpts()
+    L.fvad_engine_opts_default(C.byref(eopts))
+    eopts.no_wait = 1          # return when queued: the next step is enqueued behind the running one
+
     def gpu_stage(slot):
-        rc = L.fvad_engine_enqueue_device(ctx.h, d_pcm, lanes, n_samp, n_samp, d_den, d_band[slot], d_rms[slot], None)
+        rc = L.fvad_engine_enqueue_device(ctx.h, d_pcm, lanes, n_samp, n_samp, d_den, d_band[slot], d_rms[slot], C.byref(eopts))
         fv.check(rc, "fvad_engine_enqueue_device", ctx.h)
         fv.check(L.fvad_ctx_copy_to_host(ctx.h, h_band[slot].ctypes.data, d_band[slot], h_band[slot].nbytes),
                  "copy band sums", ctx.h)
@@ -401,19 +407,39 @@ def main():
 
     gpu_wall_ms = []
     join_ms = []
+    # HIP events on the context's stream (fvad_ctx_stream): step i+1 is enqueued while step i is still running, so
+    # the GPU does not idle between steps; the host waits for step i's event, not for the whole stream
+    hip = C.CDLL("libamdhip64.so")
+    L.fvad_ctx_stream.restype = C.c_void_p
+    stream = C.c_void_p(L.fvad_ctx_stream(ctx.h))
+    step_ev = [C.c_void_p(), C.c_void_p()]
+    for e in step_ev:
+        if hip.hipEventCreateWithFlags(C.byref(e), 0x2) != 0:      # hipEventDisableTiming
+            raise RuntimeError("hipEventCreate failed")
 
     def run_steps(k, tag):
+        """K steps; step i = GPU stage (kernels + D2H of band sums / RMS into slot i & 1) then the host stage on
+        those buffers.  Order per iteration: wait for the host stage of step i-1 (it frees slot (i+1) & 1),
+        enqueue step i+1, wait for step i's event, start its host stage."""
         worker = None
+        t_g = time.perf_counter()
+        if k > 0:
+            gpu_stage(0)
+            hip.hipEventRecord(step_ev[0], stream)
         for i in range(k):
             slot = i & 1
-            t_g = time.perf_counter()
-            gpu_stage(slot)
-            ctx.synchronize()                    # band sums of step i are on the host
-            gpu_wall_ms.append((time.perf_counter() - t_g) * 1e3)
             t_j = time.perf_counter()
             if worker is not None:
                 worker.join()                    # host stage of step i-1 (overlapped the GPU stage of i)
             join_ms.append((time.perf_counter() - t_j) * 1e3)
+            if i + 1 < k:
+                gpu_stage(slot ^ 1)
+                hip.hipEventRecord(step_ev[slot ^ 1], stream)
+            if hip.hipEventSynchronize(step_ev[slot]) != 0:      # band sums of step i are on the host
+                raise RuntimeError("hipEventSynchronize failed")
+            now = time.perf_counter()
+            gpu_wall_ms.append((now - t_g) * 1e3)    # completion to completion
+            t_g = now
             worker = threading.Thread(target=host_stage, args=((tag, i), slot))
             worker.start()
         if worker is not None:

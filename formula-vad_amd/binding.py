@@ -91,7 +91,7 @@ class Lane(C.Structure):
 
 class EngineOpts(C.Structure):
     _fields_ = [("on_device", C.c_int32), ("min_bin", C.c_int32), ("max_bin", C.c_int32),
-                ("max_chunks_per_launch", C.c_int32), ("fft_size", C.c_int32)]
+                ("max_chunks_per_launch", C.c_int32), ("fft_size", C.c_int32), ("no_wait", C.c_int32)]
 
 
 class AudioBuffer(C.Structure):
@@ -491,10 +491,12 @@ class Context:
         self.synchronize()
         return arr
 
-    def enqueue_device(self, d_pcm, n_lanes, lane_stride, n_samples, d_den, d_band, d_rms, max_chunks_per_launch=0):
+    def enqueue_device(self, d_pcm, n_lanes, lane_stride, n_samples, d_den, d_band, d_rms, max_chunks_per_launch=0,
+                       no_wait=False):
         opts = EngineOpts()
         lib().fvad_engine_opts_default(C.byref(opts))
         opts.max_chunks_per_launch = max_chunks_per_launch
+        opts.no_wait = 1 if no_wait else 0
         self._ck(lib().fvad_engine_enqueue_device(self.h, vp(d_pcm), n_lanes, lane_stride, n_samples,
                                                   vp(d_den) if d_den else None, vp(d_band), vp(d_rms) if d_rms else None,
                                                   C.byref(opts)), "fvad_engine_enqueue_device")

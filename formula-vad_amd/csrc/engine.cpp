@@ -769,6 +769,7 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     if (ws.copy_in) hipStreamDestroy(ws.copy_in);
     if (ws.copy_out) hipStreamDestroy(ws.copy_out);
     for (hipEvent_t& e : ws.desc_ev) if (e) hipEventDestroy(e);
+    for (hipEvent_t& e : ws.jobs_ev) if (e) hipEventDestroy(e);
     if (ws.fft_jobs) hipFree(ws.fft_jobs);
     if (ws.h_fft_jobs) hipHostFree(ws.h_fft_jobs);
     DeviceModel& m = ctx->dm;
@@ -996,6 +997,7 @@ void fvad_engine_opts_default(fvad_engine_opts* o)
     o->max_bin = 43; // FFT.freqToBin(2000)
     o->max_chunks_per_launch = 0;
     o->fft_size = 0; // 1024
+    o->no_wait = 0;
 }
 
 static int grow(fvad_ctx* ctx, float** p, size_t* cap, size_t need)
@@ -1274,7 +1276,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
             if (ws.h_fft_jobs) hipHostFree(ws.h_fft_jobs);
             ws.fft_jobs = nullptr; ws.h_fft_jobs = nullptr; ws.fft_jobs_cap = 0;
             FVAD_HIP(ctx, hipMalloc((void**)&ws.fft_jobs, n_lanes * sizeof(VadFftJob)));
-            FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_fft_jobs, n_lanes * sizeof(VadFftJob), hipHostMallocDefault));
+            FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_fft_jobs, 2 * n_lanes * sizeof(VadFftJob), hipHostMallocDefault));
             ws.fft_jobs_cap = n_lanes;
             ws.generation++;
         }
@@ -1427,7 +1429,7 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
         if (ws.h_fft_jobs) hipHostFree(ws.h_fft_jobs);
         ws.fft_jobs = nullptr; ws.h_fft_jobs = nullptr; ws.fft_jobs_cap = 0;
         FVAD_HIP(ctx, hipMalloc((void**)&ws.fft_jobs, n_lanes * sizeof(VadFftJob)));
-        FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_fft_jobs, n_lanes * sizeof(VadFftJob), hipHostMallocDefault));
+        FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_fft_jobs, 2 * n_lanes * sizeof(VadFftJob), hipHostMallocDefault));
         ws.fft_jobs_cap = n_lanes;
         ws.generation++;
     }
@@ -1523,8 +1525,14 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
         return FVAD_OK;
     }
 
-    if ((rc = enqueue(nullptr, nullptr, ws.h_fft_jobs, ws.fft_jobs))) return rc;
-    FVAD_HIP(ctx, hipStreamSynchronize(st)); // the pinned job table is reused by the next call
+    // the pinned job table has two slots: a slot is rewritten only after its previous upload has left the host
+    const int js = ws.jobs_slot;
+    ws.jobs_slot ^= 1;
+    if (!ws.jobs_ev[js]) FVAD_HIP(ctx, hipEventCreateWithFlags(&ws.jobs_ev[js], hipEventDisableTiming));
+    else FVAD_HIP(ctx, hipEventSynchronize(ws.jobs_ev[js]));
+    if ((rc = enqueue(nullptr, nullptr, ws.h_fft_jobs + (size_t)js * ws.fft_jobs_cap, ws.fft_jobs))) return rc;
+    FVAD_HIP(ctx, hipEventRecord(ws.jobs_ev[js], st));
+    if (!opts.no_wait) FVAD_HIP(ctx, hipStreamSynchronize(st));
     FVAD_HIP(ctx, hipGetLastError());
     return FVAD_OK;
 }

@@ -84,7 +84,8 @@ struct Workspace {
     // (256 flags per GRU layer + the error word, zeroed by ONE memset in front of every network pass)
     float* hx = nullptr; size_t hx_cap = 0;
     unsigned* ws_sync = nullptr;
-    VadFftJob* fft_jobs = nullptr; VadFftJob* h_fft_jobs = nullptr; size_t fft_jobs_cap = 0;
+    VadFftJob* fft_jobs = nullptr; VadFftJob* h_fft_jobs = nullptr; size_t fft_jobs_cap = 0; // host table: two slots of fft_jobs_cap
+    hipEvent_t jobs_ev[2] = {nullptr, nullptr}; int jobs_slot = 0; // slot's upload has left the host (no_wait calls)
     // pinned staging ring for large host <-> device transfers (two halves of kPinSlots slots)
     struct PinRing { char* base = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
     PinRing ring_in, ring_out; // host->device staging / device->host draining (used by different threads)

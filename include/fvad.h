@@ -236,6 +236,11 @@ typedef struct {
     int32_t fft_size;        /* frame length of the VAD-side FFT (VADPipeline.Config.fft_size, VADPipeline.zig:21):
                                 512, 1024 or 2048; 0 = 1024.  min_bin / max_bin index that transform's bins and
                                 fft_bins rows have fft_size / 2 + 1 entries */
+    int32_t no_wait;         /* fvad_engine_enqueue_device* only: 1 = return as soon as the work is queued on the
+                                context's stream (results valid after fvad_ctx_synchronize or an event the caller
+                                records on fvad_ctx_stream); the next call may be made at once -- descriptor and job
+                                tables are double-buffered -- so a caller can keep one batch queued behind the running
+                                one.  0 (default) = return when the work has completed */
 } fvad_engine_opts;
 void fvad_engine_opts_default(fvad_engine_opts *o);
 
@@ -245,8 +250,7 @@ int fvad_engine_run(fvad_ctx *ctx, fvad_lane *lanes, size_t n_lanes, const fvad_
  * d_denoised [n_lanes][n_chunks*24000] (NULL: kept in the context's workspace), d_band_sum
  * [n_lanes][n_chunks*24000/1024] and d_chunk_rms [n_lanes][n_chunks] (may be NULL) are device buffers
  * too; nothing is copied to the host.  Every lane starts from zero history.  The call returns once
- * the work has COMPLETED on the context's stream (its pinned descriptor tables are reused by the next
- * call). */
+ * the work has COMPLETED on the context's stream, unless opts->no_wait is set. */
 int fvad_engine_enqueue_device(fvad_ctx *ctx, const float *d_pcm, size_t n_lanes,
                                size_t lane_stride, size_t n_samples, float *d_denoised,
                                float *d_band_sum, float *d_chunk_rms,

@@ -522,6 +522,38 @@ def test_graph_replay_equals_direct_launches():
 
 
 # ------------------------------------------------------------------ the configuration bench.py times
+def test_enqueue_device_no_wait_queues_calls_back_to_back(fv, gpu_ctx, pkg):
+    # fvad_engine_opts.no_wait: the call returns when the work is queued; a second call may follow at once (the
+    # pinned descriptor / job tables are double-buffered).  Three queued calls on different inputs give the
+    # results of three synchronous calls, bit for bit.
+    n_l, n_ch = 6, 40
+    n = n_ch * 24000
+    pcms = [np.stack([pkg.synth.make_stream(20.5, seed=700 + 10 * k + i)[0][0][:n] for i in range(n_l)]) for k in range(3)]
+    nfr = n // 1024
+    d_in = [gpu_ctx.device_alloc(n_l * n * 4) for _ in range(3)]
+    d_band = [gpu_ctx.device_alloc(n_l * nfr * 4) for _ in range(3)]
+    d_rms = [gpu_ctx.device_alloc(n_l * n_ch * 4) for _ in range(3)]
+    d_den = [gpu_ctx.device_alloc(n_l * n * 4) for _ in range(3)]
+    for k in range(3):
+        gpu_ctx.to_device(d_in[k], pcms[k])
+    ref = []
+    for k in range(3):
+        gpu_ctx.enqueue_device(d_in[k], n_l, n, n, d_den[k], d_band[k], d_rms[k])
+        ref.append((gpu_ctx.to_host(np.empty((n_l, nfr), np.float32), d_band[k]), gpu_ctx.to_host(np.empty((n_l, n), np.float32), d_den[k]),
+                    gpu_ctx.to_host(np.empty((n_l, n_ch), np.float32), d_rms[k])))
+    for k in range(3):                              # poison the outputs, then queue all three without waiting
+        gpu_ctx.to_device(d_band[k], np.full((n_l, nfr), -1.0, np.float32))
+    for k in range(3):
+        gpu_ctx.enqueue_device(d_in[k], n_l, n, n, d_den[k], d_band[k], d_rms[k], no_wait=True)
+    gpu_ctx.synchronize()
+    for k in range(3):
+        assert np.array_equal(gpu_ctx.to_host(np.empty((n_l, nfr), np.float32), d_band[k]), ref[k][0])
+        assert np.array_equal(gpu_ctx.to_host(np.empty((n_l, n), np.float32), d_den[k]), ref[k][1])
+        assert np.array_equal(gpu_ctx.to_host(np.empty((n_l, n_ch), np.float32), d_rms[k]), ref[k][2])
+    for a in d_in + d_band + d_rms + d_den:
+        gpu_ctx.device_free(a)
+
+
 def bench_shape_inputs(pkg, lanes, seconds, n_base=8, unique=()):
     """lane i carries base stream i % n_base, except the lanes in `unique`, which get streams of their own"""
     bases = [pkg.synth.make_stream(float(seconds), seed=2000 + k)[0][0][: seconds * 48000].copy() for k in range(n_base)]
