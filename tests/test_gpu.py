@@ -254,6 +254,19 @@ def test_f16x3_products_are_as_close_to_float64_as_f32(fv, weights7):
     c.close()
 
 
+@pytest.mark.parametrize("n_seq,T", [(2304, 7), (2176, 20), (4000, 54)])
+def test_f16x3_other_sequence_lengths_and_paddings(fv, gpu_ctx, weights7, n_seq, T):
+    # the tiled layouts of the f16x3 path group 16 sequences per time step: other sequence lengths than the
+    # pipeline's 54 rows, a batch that pads to 128- rather than 192-sequence workgroups (2176), and one that is not
+    # a multiple of anything (4000) must come out the same as through the oracle
+    rng = np.random.default_rng(100 + T)
+    f = rng.uniform(-11, 2, (n_seq, T, 161)).astype(np.float32)
+    g = gpu_ctx.nsnet2_forward(f)
+    pick = [0, 15, 16, 17, n_seq // 2, n_seq - 17, n_seq - 1]
+    ref = np.stack([orc.nsnet2_forward(weights7, f[i]) for i in pick])
+    assert_rel(g[pick], ref, 1e-4, floor=1e-2, what=f"gains n_seq={n_seq} T={T}")
+
+
 def test_get_weights_roundtrip(fv, gpu_ctx, weights7):
     got = gpu_ctx.weights()
     for k in fv.WEIGHT_NAMES:
