@@ -312,12 +312,13 @@ def pmc_traffic(chunks_per_launch, nn_math="f16x3", raw=False):
     want = "gru_rec_h3_kernel" if nn_math == "f16x3" else "gru_rec3_kernel"
     try:
         files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
-        d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
-        if d["chunks_per_launch"] != min(chunks_per_launch, 49152):
-            return None
-        for k, v in d["kernels"].items():
-            if k.startswith(want):
-                return v["hbm_bytes_per_launch"] if not raw else v.get("hbm_bytes_per_launch_raw_counters")
+        for name in reversed(files):                      # the latest profile that holds this kernel
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if d["chunks_per_launch"] != min(chunks_per_launch, 49152):
+                continue
+            for k, v in d["kernels"].items():
+                if k.startswith(want):
+                    return v["hbm_bytes_per_launch"] if not raw else v.get("hbm_bytes_per_launch_raw_counters")
     except Exception:
         pass
     return None
