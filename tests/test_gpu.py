@@ -267,6 +267,19 @@ def test_f16x3_other_sequence_lengths_and_paddings(fv, gpu_ctx, weights7, n_seq,
     assert_rel(g[pick], ref, 1e-4, floor=1e-2, what=f"gains n_seq={n_seq} T={T}")
 
 
+def test_f16x3_large_batch_is_deterministic_and_position_independent(fv, gpu_ctx):
+    # the same 192 sequences in each of 128 workgroup-sized groups, three times: every group and every repeat
+    # must give the same bits (a race on a weight slab or a missed wait in the LDS-DMA kernels would show here;
+    # tools/h3_soak.py is the long form)
+    rng = np.random.default_rng(5)
+    base = rng.uniform(-11, 2, (192, 54, 161)).astype(np.float32)
+    f = np.tile(base, (128, 1, 1))
+    g0 = gpu_ctx.nsnet2_forward(f)
+    assert np.array_equal(g0.reshape(128, 192, 54, 161), np.broadcast_to(g0[:192], (128, 192, 54, 161)))
+    for _ in range(2):
+        assert np.array_equal(gpu_ctx.nsnet2_forward(f), g0)
+
+
 def test_get_weights_roundtrip(fv, gpu_ctx, weights7):
     got = gpu_ctx.weights()
     for k in fv.WEIGHT_NAMES:
