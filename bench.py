@@ -543,7 +543,8 @@ def main():
         gru_mfma_flop = lanes * n_chunks * (GRU_H3_MFMA_FLOP_PER_CHUNK_LAUNCH if h3 else GRU_FLOP_PER_CHUNK_LAUNCH)
         mfma_peak = F16_MFMA_PEAK_TFLOPS if h3 else FP32_MFMA_PEAK_TFLOPS
         achieved = gru_mfma_flop / (gru_ms * 1e-3) / 1e12 if gru_ms > 0 else 0.0
-        gru_hbm_bytes = lanes * n_chunks * (54 * 1200 * 4 + 2 * 54 * 400 * 4 + (2 * 54 * 416 * 4 if h3 else 0))
+        # gi read once; h written and read back once: as f32 rows (f32 kernels) or as split fragments (f16x3: 416 slots x 4 B)
+        gru_hbm_bytes = lanes * n_chunks * (54 * 1200 * 4 + 2 * 54 * (416 if h3 else 400) * 4)
         dev_ms_step = sum(ktimes.values()) / args.steps
         nn_ms = sum(v for k, v in ktimes.items() if "gemm" in k or "gru" in k) / args.steps
         out = {
