@@ -195,7 +195,9 @@ int upload_model(fvad_ctx* ctx)
         pack_gru_r_h3(w.gru2_r.data(), H, m.h3_r2.sw, f);
         if ((rc = upload(ctx, m.r2_h3, f))) return rc;
         // the scales are finite powers of two whenever the weights and the bounds are finite
-        m.h3_ok = std::isfinite(b_fc3) && b_fc3 < 1e30;
+        // ... and the split keeps its 22 bits only for values within ~18 binades below the bound: a model whose l1
+        // bounds are absurdly loose (activations expected around 1 against a bound above 2^17) keeps the f32 kernels
+        m.h3_ok = std::isfinite(b_fc3) && b_fc3 <= 131072.0 && b_fc2 <= 131072.0;
         for (const DeviceModel::H3Scale* sc : {&m.h3_gi1f, &m.h3_gi2, &m.h3_fc2, &m.h3_fc3, &m.h3_fc4, &m.h3_r1, &m.h3_r2})
             m.h3_ok = m.h3_ok && std::isfinite(sc->sw) && std::isfinite(sc->sx) && sc->sw > 0.0f && sc->sx > 0.0f &&
                       std::isfinite(sc->sw * sc->sx) && std::isfinite(1.0f / (sc->sw * sc->sx));
