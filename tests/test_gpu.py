@@ -234,7 +234,7 @@ def test_f16x3_products_are_as_close_to_float64_as_f32(fv, weights7):
         ctx.close()
         return g
 
-    for scale in (1.0, 37.3, 1.0 / 64.0):
+    for scale in (1.0, 37.3, 1.0 / 64.0, 1.0e5):       # 1e5: fc2's l1 bound leaves the f16x3 range -> the f32 kernels run
         w = {k: v.copy() for k, v in weights7.items()}
         # scale one dense layer up and the next down: same function up to rounding, very different operand sizes
         w["fc2_w"] *= np.float32(scale); w["fc2_b"] *= np.float32(scale)
