@@ -58,9 +58,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-2 / config-3 side measurements")
     ap.add_argument("--vad-threads", type=int, default=0)
-    ap.add_argument("--nn-math", default="f16x3", choices=("f16x3", "f32"),
-                    help="arithmetic of the large-batch NSNet2 matrix products (fvad_ctx_set_nn_math): f16x3 = three f16 "
-                         "MFMAs on split f32 operands, f32-class accuracy (default); f32 = v_mfma_f32_16x16x4_f32")
+    ap.add_argument("--nn-math", default="f32", choices=("f32", "f16x3"),
+                    help="arithmetic of the NSNet2 matrix products of the HEADLINE (fvad_ctx_set_nn_math): f32 = "
+                         "v_mfma_f32_16x16x4_f32, the reference's arithmetic (default); f16x3 = the emulation (three f16 "
+                         "MFMAs on split f32 operands, 22-bit operands).  With f32 the emulation is timed too, over the "
+                         "same number of steps, and reported in the `emulated` block")
+    ap.add_argument("--no-emulated", action="store_true", help="skip the `emulated` block (the f16x3 path)")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL; one rank per GPU) or gloo (rehearsal: every rank on cuda:0)")
     ap.add_argument("--config", default="headline", choices=("headline", "cfg4"),
@@ -154,22 +157,24 @@ def check_against_oracle(ctx, weights, host_pcm, lanes, d_den, n_samp, band, seg
 def gather_all_stats(pkg, fv, ctx, dist, world, args, cdev, local_ids, local_stats, n_streams):
     """Per-stream SingleStats of every rank, in plan order.  One rank per GPU: the library's own RCCL
     all-gather (fvad_stats_allgather, no torch on the path); rehearsal ranks that share a GPU, or a failure of
-    the native path, use the same exchange over torch.distributed.  Returns (stats, description)."""
+    the native path, use the same exchange over torch.distributed.  Returns (stats, description, ranks the RCCL
+    communicator saw or None)."""
     if world == 1:
-        return pkg.shard.gather_stats(local_ids, [fv.single_stats_to_array(s) for s in local_stats], n_streams), "none"
+        return pkg.shard.gather_stats(local_ids, [fv.single_stats_to_array(s) for s in local_stats], n_streams), "none", None
     if args.dist_backend == "nccl":
         try:
             comm = pkg.shard.native_comm(ctx, dist)
+            seen = int(fv.lib().fvad_comm_world(comm.h))
             out = pkg.shard.gather_stats_native(comm, local_ids, local_stats, n_streams)
             comm.close()
-            return out, "fvad_stats_allgather (ncclAllGather via librccl, C ABI)"
+            return out, "fvad_stats_allgather (ncclAllGather via librccl, C ABI)", seen
         except Exception as e:  # keep the run alive; the JSON line says what happened
             note = f"torch.distributed all_gather(nccl) after native path failed: {e!r}"
     else:
         note = f"torch.distributed all_gather({args.dist_backend})"
     out = pkg.shard.gather_stats(local_ids, [fv.single_stats_to_array(s) for s in local_stats], n_streams,
                                  dist=dist, device=cdev)
-    return out, note
+    return out, note, None
 
 
 def roll_labels(labels, shift_s, period_s, reps):
@@ -305,30 +310,92 @@ def cpu_model():
     return "unknown"
 
 
-def pmc_traffic(chunks_per_launch, nn_math="f16x3", raw=False):
+def kernel_source_digest():
+    """sha256 over the kernel sources: profiles/*_pmc_summary.json records the digest of the build its counters were
+    taken from, so a stale profile is visible in the line instead of being quoted silently"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "formula-vad_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(chunks_per_launch, nn_math="f32"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_summary.json; counters cannot be read from inside the benchmark), or None when
-    the profile was taken at a different launch size or with the other arithmetic."""
+    (profiles/*_pmc_summary.json; counters cannot be read from inside the benchmark) together with where they
+    come from: file, the commit and kernel-source digest recorded when the passes were summarised, and whether
+    that digest is the current build's.  None when no profile holds this kernel at this launch size."""
     want = "gru_rec_h3_kernel" if nn_math == "f16x3" else "gru_rec3_kernel"
     try:
-        files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
-        for name in reversed(files):                      # the latest profile that holds this kernel
-            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        pdir = os.path.join(ROOT, "profiles")
+        files = sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_summary.json")),
+                       key=lambda f: os.path.getmtime(os.path.join(pdir, f)))
+        cands = []
+        for name in files:
+            d = json.load(open(os.path.join(pdir, name)))
             if d["chunks_per_launch"] != min(chunks_per_launch, 49152):
                 continue
             for k, v in d["kernels"].items():
                 if k.startswith(want):
-                    return v["hbm_bytes_per_launch"] if not raw else v.get("hbm_bytes_per_launch_raw_counters")
-    except Exception:
-        pass
-    return None
+                    cands.append((d.get("recorded_at", ""), name, k, v, d))
+        if not cands:
+            return None
+        # the newest summary by its own timestamp (file mtimes do not survive a checkout); unstamped ones are oldest
+        _, name, k, v, d = sorted(cands, key=lambda c: (c[0], c[1]))[-1]
+        digest = d.get("kernel_source_digest")
+        return {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
+                "hbm_bytes_per_launch_raw_counters": v.get("hbm_bytes_per_launch_raw_counters"),
+                "mfma_busy_frac": v.get("mfma_busy_frac"), "clock_GHz": v.get("clock_GHz"),
+                "kernel": k, "profile": "profiles/" + name, "profile_commit": d.get("source_commit"),
+                "profile_kernel_source_digest": digest, "current_kernel_source_digest": kernel_source_digest(),
+                "stale": None if digest is None else digest != kernel_source_digest()}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (torch.distributed.run,
+    one rank per GPU over RCCL; this process never touches a GPU), relay their output -- rank 0's JSON line included
+    -- and exit with the launcher's code.  One worker per stream / file joined before the report is the reference's
+    own parallelism (src/simulator.zig:221-232)."""
+    import socket
+    import subprocess
+    if args.dist_backend == "nccl":
+        import torch
+        have = torch.cuda.device_count()           # counts devices without initialising the runtime
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, this node shows {have} "
+                  f"(use --dist-backend gloo to rehearse several ranks on one GPU)", file=sys.stderr)
+            return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print(f"bench.py: launching {args.gpus} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env)
+    try:
+        return proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        return proc.wait()
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))               # before anything touches the GPU in this process
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
+        sys.exit(2)
     import torch
     import torch.distributed as dist
     rehearsal = args.dist_backend == "gloo"
@@ -350,7 +417,7 @@ def main():
     ctx = fv.Context(local_rank)
     ctx.load_synth(7)
     ctx.set_nn_math(args.nn_math)
-    nn_math = os.environ.get("FVAD_NN_MATH", args.nn_math)   # the environment variable overrides the setting
+    nn_math = ctx.nn_math_effective()            # what the context really uses (FVAD_NN_MATH at create overrides the setting)
     weights = ctx.weights()
 
     if args.config == "cfg4":
@@ -453,51 +520,105 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(args.warmup, "warm")
-    ctx.enable_timing(True)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps, "timed")
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ktimes = ctx.kernel_times()                  # sums over the K timed steps, HIP events on ctx's stream
-    ctx.enable_timing(False)
+    def measure(math, tag):
+        """W warm-up steps, then EXACTLY K timed steps (barrier + synchronize on both sides) of the whole path with the
+        context's arithmetic set to `math`; HIP-event kernel times over the timed steps; the self-check of the last
+        timed step; then the device-only rate of the same work (no host stage), for the record."""
+        ctx.set_nn_math(math)
+        eff = ctx.nn_math_effective()
+        del gpu_wall_ms[:], join_ms[:], host_ms[:]
+        run_steps(args.warmup, tag + "-warm")
+        ctx.enable_timing(True)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps, tag)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ktimes = ctx.kernel_times()              # sums over the K timed steps, HIP events on ctx's stream
+        ctx.enable_timing(False)
+        path = ctx.last_nn_path()
+        # self-check of the configuration that was just timed: two lanes of the LAST timed step (the first and
+        # the last of the batch) against the CPU oracle -- denoised audio, band sums, segment boundaries
+        check = None
+        if rank == 0:
+            check = check_against_oracle(ctx, weights, host_pcm, [0, lanes - 1], d_den, n_samp,
+                                         h_band[(args.steps - 1) & 1], results[(tag, args.steps - 1)])
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            gpu_stage(i & 1)
+        barrier()
+        dev_elapsed = time.perf_counter() - t1
+        t = torch.tensor([elapsed, dev_elapsed], dtype=torch.float64, device=cdev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return {"nn_math": eff, "elapsed": float(t[0]), "dev_elapsed": float(t[1]), "rank_elapsed": elapsed, "ktimes": ktimes,
+                "self_check": check, "nn_path": path, "gpu_wall_ms": float(np.mean(gpu_wall_ms[args.warmup:])),
+                "join_ms": [round(j, 1) for j in join_ms], "host_ms": float(np.mean(host_ms)) if host_ms else 0.0}
 
-    # self-check of the configuration that was just timed: two lanes of the LAST timed step (the first and
-    # the last of the batch) against the CPU oracle -- denoised audio, band sums, segment boundaries
-    self_check = None
-    if rank == 0:
-        self_check = check_against_oracle(ctx, weights, host_pcm, [0, lanes - 1], d_den, n_samp,
-                                          h_band[(args.steps - 1) & 1], results[("timed", args.steps - 1)])
+    def roofline_of(m):
+        """dominant kernel: the GRU recurrence (two launches per step).  achieved = the MFMA FLOPs one launch executes /
+        its mean HIP-event time; peak = the dense MFMA peak of the instruction it issues"""
+        h3 = m["nn_math"] == "f16x3"
+        kt = m["ktimes"]
+        gru_ms = (kt.get("gru1_rec", 0.0) + kt.get("gru2_rec", 0.0)) / (2 * args.steps)
+        gru_flop = lanes * n_chunks * GRU_FLOP_PER_CHUNK_LAUNCH
+        gru_mfma_flop = lanes * n_chunks * (GRU_H3_MFMA_FLOP_PER_CHUNK_LAUNCH if h3 else GRU_FLOP_PER_CHUNK_LAUNCH)
+        peak = F16_MFMA_PEAK_TFLOPS if h3 else FP32_MFMA_PEAK_TFLOPS
+        achieved = gru_mfma_flop / (gru_ms * 1e-3) / 1e12 if gru_ms > 0 else 0.0
+        # gi read once; h written and read back once: as f32 rows (f32 kernels) or as split fragments (f16x3: 416 slots x 4 B)
+        hbm = lanes * n_chunks * (54 * 1200 * 4 + 2 * 54 * (416 if h3 else 400) * 4)
+        pmc = pmc_traffic(lanes * n_chunks, m["nn_math"])
+        r = {"bound": "mfma",
+             "kernel": ("gru_rec_h3_kernel<12, 1> (v_mfma_f32_16x16x32_f16, three per f32 product)" if h3 else
+                        "gru_rec3_kernel<12, 2> (fp32 v_mfma_f32_16x16x4_f32)"),
+             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+             # HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction)
+             "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
+             "traffic_source": pmc,
+             "algorithmic_hbm_bytes_per_launch": hbm,
+             "algorithmic_hbm_frac_of_8TBps": hbm / (gru_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if gru_ms > 0 else 0.0,
+             "launch_ms": gru_ms, "flop_per_launch": gru_mfma_flop}
+        if h3:
+            # useful (algorithmic) FLOPs of the same launch: 2 x 400 x 1200 per step and sequence
+            r["algorithmic_tflops"] = gru_flop / (gru_ms * 1e-3) / 1e12 if gru_ms > 0 else 0.0
+            r["algorithmic_frac_of_f16_peak"] = r["algorithmic_tflops"] / F16_MFMA_PEAK_TFLOPS
+            r["f32_equivalent_frac_of_f32_mfma_peak"] = r["algorithmic_tflops"] / FP32_MFMA_PEAK_TFLOPS
+        return r
 
-    # device-only rate of the same work (no host stage), for the record
-    barrier()
-    t1 = time.perf_counter()
-    for i in range(args.steps):
-        gpu_stage(i & 1)
-    barrier()
-    dev_elapsed = time.perf_counter() - t1
+    def pipeline_of(m):
+        kt = m["ktimes"]
+        dev_ms_step = sum(kt.values()) / args.steps
+        nn_ms = sum(v for k, v in kt.items() if "gemm" in k or "gru" in k) / args.steps
+        c = lanes * n_chunks
+        return {"nn_math": m["nn_math"], "nn_path": m["nn_path"],
+                "nsnet2_executed_f32_equivalent_tflops": c * NSNET2_EXECUTED_FLOP_PER_CHUNK / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
+                "nsnet2_f32_equivalent_frac_of_f32_mfma_peak": c * NSNET2_EXECUTED_FLOP_PER_CHUNK / (nn_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS if nn_ms else 0.0,
+                "nsnet2_effective_tflops_unfolded_network": c * NSNET2_FLOP_PER_CHUNK / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
+                "hbm_algorithmic_GBps": frames_per_step * 3840 / (dev_ms_step * 1e-3) / 1e9 if dev_ms_step else 0.0,
+                "hbm_frac_of_8TBps": frames_per_step * 3840 / (dev_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS if dev_ms_step else 0.0,
+                "kernel_ms_sum": dev_ms_step}
 
-    # ---- the other arithmetic on the same batch, for the record (device-only, three steps)
-    other_math = None
-    if rank == 0 and not args.no_extra:
-        other = "f32" if nn_math == "f16x3" else "f16x3"
-        if "FVAD_NN_MATH" not in os.environ:
-            ctx.set_nn_math(other)
-            gpu_stage(0)
-            ctx.enable_timing(True)
-            barrier()
-            t2 = time.perf_counter()
-            for i in range(3):
-                gpu_stage(i & 1)
-            barrier()
-            dt = time.perf_counter() - t2
-            kt = ctx.kernel_times()
-            ctx.enable_timing(False)
-            other_math = {"nn_math": other, "device_only_ms_per_step": dt / 3 * 1e3,
-                          "device_only_frames_per_s": 3 * frames_per_step / dt,
-                          "kernel_ms_per_step": {k: v / 3 for k, v in kt.items()}}
-            ctx.set_nn_math(nn_math)
+    head = measure(nn_math, "timed")
+    if head["nn_math"] != nn_math:
+        raise RuntimeError(f"asked for {nn_math}, the context runs {head['nn_math']}")
+    # ---- the emulated arithmetic on the same batch, first-class: the same W + K steps end to end, its own roofline
+    # and self-check.  It is NOT the headline: f16x3 carries 22 significand bits per operand, the reference's f32 24.
+    emulated = None
+    if nn_math == "f32" and not args.no_emulated:
+        em = measure("f16x3", "emulated")
+        if em["nn_math"] == "f16x3":
+            emulated = {"nn_math": "f16x3", "note": "three v_mfma_f32_16x16x32_f16 per product on (hi, lo) f16 pieces of power-of-two "
+                        "scaled f32 operands, f32 accumulation: 22 significand bits per operand (f32: 24) -- narrower than the "
+                        "reference's arithmetic, hence not `value`; opt-in through fvad_ctx_set_nn_math",
+                        "value": frames_per_step * args.steps * world / em["elapsed"], "unit": "frames/s",
+                        "ms_per_step": em["elapsed"] / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
+                        "device_only_frames_per_s": frames_per_step * args.steps * world / em["dev_elapsed"],
+                        "roofline": roofline_of(em), "roofline_pipeline": pipeline_of(em),
+                        "kernel_ms_per_step": {k: v / args.steps for k, v in em["ktimes"].items()},
+                        "self_check": em["self_check"], "host_stage_ms": em["host_ms"]}
+        ctx.set_nn_math(nn_math)
+    elapsed, dev_elapsed, ktimes, self_check = head["elapsed"], head["dev_elapsed"], head["ktimes"], head["self_check"]
 
     # ---- the same batch read as 192 STEREO streams (the reference's real corpus is stereo: channel_vol_ratio):
     # the GPU work is identical (a lane is a channel), the host stage runs 2-channel state machines on
@@ -525,28 +646,21 @@ def main():
         segs = [(np.float32(s[0]) / np.float32(48000), np.float32(s[1]) / np.float32(48000)) for s in last[lane]]
         local_stats.append(fv.stats_from_segments(segs, labels[lane], stat_cfg))
     ta = time.perf_counter()
-    allst, collective = gather_all_stats(pkg, fv, ctx, dist, world, args, cdev, local_ids, local_stats, lanes * world)
+    allst, collective, rccl_ranks = gather_all_stats(pkg, fv, ctx, dist, world, args, cdev, local_ids, local_stats, lanes * world)
     agg = fv.stats_aggregate([fv.array_to_single_stats(a) for a in allst])
     agg_ms = (time.perf_counter() - ta) * 1e3
 
-    t = torch.tensor([elapsed, dev_elapsed], dtype=torch.float64, device=cdev)
+    # per-rank step times and the communicator's size, for the record of an N-rank run
+    rank_ms = [None] * world
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, dev_elapsed = float(t[0]), float(t[1])
+        dist.all_gather_object(rank_ms, head["rank_elapsed"] / args.steps * 1e3)
+    else:
+        rank_ms = [head["rank_elapsed"] / args.steps * 1e3]
 
     if rank == 0:
         total_frames = frames_per_step * args.steps * world
         value = total_frames / elapsed
-        gru_ms = (ktimes.get("gru1_rec", 0.0) + ktimes.get("gru2_rec", 0.0)) / (2 * args.steps)
-        gru_flop = lanes * n_chunks * GRU_FLOP_PER_CHUNK_LAUNCH
         h3 = nn_math == "f16x3"
-        gru_mfma_flop = lanes * n_chunks * (GRU_H3_MFMA_FLOP_PER_CHUNK_LAUNCH if h3 else GRU_FLOP_PER_CHUNK_LAUNCH)
-        mfma_peak = F16_MFMA_PEAK_TFLOPS if h3 else FP32_MFMA_PEAK_TFLOPS
-        achieved = gru_mfma_flop / (gru_ms * 1e-3) / 1e12 if gru_ms > 0 else 0.0
-        # gi read once; h written and read back once: as f32 rows (f32 kernels) or as split fragments (f16x3: 416 slots x 4 B)
-        gru_hbm_bytes = lanes * n_chunks * (54 * 1200 * 4 + 2 * 54 * (416 if h3 else 400) * 4)
-        dev_ms_step = sum(ktimes.values()) / args.steps
-        nn_ms = sum(v for k, v in ktimes.items() if "gemm" in k or "gru" in k) / args.steps
         out = {
             "metric": "20ms audio frames/sec end-to-end VAD pipeline",
             "value": value,
@@ -558,7 +672,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (NSNet2 products as f16x3: three f16 MFMAs on split f32 operands, f32 accumulate)" if h3 else "f32",
+            "dtype": "f16x3 EMULATION of f32 (22-bit operands: narrower than the reference's f32)" if h3 else "f32",
+            "nn_math_effective": head["nn_math"], "nn_path": head["nn_path"],
             "data": "synthetic 48 kHz mono (seeded noise floor + 500-2000 Hz harmonic bursts; every lane a different stream), random-init NSNet2 weights seed 7",
             "config": {"workload": f"full pipeline (window->STFT->NSNet2->iSTFT->FFT1024 band->VAD decision), "
                                    f"{lanes} streams x {seconds} s per GPU per step = {lanes * n_chunks} chunks = "
@@ -567,42 +682,25 @@ def main():
                        "streams_per_gpu": lanes, "seconds_per_stream": seconds,
                        "frame": "10 ms hop / 20 ms window @16 kHz (NSNet2.zig:12-13)",
                        "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
+            "ranks": {"launched": world, "backend": args.dist_backend if world > 1 else "none", "rccl_ranks": rccl_ranks,
+                      "ms_per_step_per_rank": rank_ms},
             "audio_seconds_per_s": value / 100.0,
             "device_only_frames_per_s": total_frames / dev_elapsed,
-            # dominant kernel: the GRU recurrence (two launches per step).  achieved = MFMA FLOPs the kernel executes
-            # (f16x3: three f16 MFMAs per f32 product, K padded to 416) / its HIP-event time; peak = the dense MFMA
-            # peak of the instruction it issues
-            "roofline": {"bound": "mfma",
-                         "kernel": ("gru_rec_h3_kernel<12, 1> (v_mfma_f32_16x16x32_f16, three per f32 product)" if h3 else
-                                    "gru_rec3_kernel<12, 2> (fp32 v_mfma_f32_16x16x4_f32)"),
-                         "achieved": achieved, "peak": mfma_peak, "unit": "TFLOP/s",
-                         "frac": achieved / mfma_peak, "traffic": pmc_traffic(lanes * n_chunks, nn_math),
-                         # FETCH_SIZE + WRITE_SIZE without the guide's x2 fetch correction
-                         "traffic_uncorrected_counters": pmc_traffic(lanes * n_chunks, nn_math, raw=True),
-                         "algorithmic_hbm_bytes_per_launch": gru_hbm_bytes,
-                         "algorithmic_hbm_frac_of_8TBps": gru_hbm_bytes / (gru_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if gru_ms > 0 else 0.0,
-                         "launch_ms": gru_ms, "flop_per_launch": gru_mfma_flop,
-                         # the same launch priced as the f32 arithmetic it replaces (2 x 400 x 1200 per step and sequence)
-                         "f32_equivalent_tflops": gru_flop / (gru_ms * 1e-3) / 1e12 if gru_ms > 0 else 0.0,
-                         "f32_equivalent_frac_of_f32_mfma_peak": gru_flop / (gru_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS if gru_ms > 0 else 0.0},
-            "roofline_pipeline": {
-                "nn_math": nn_math,
-                "nsnet2_f32_equivalent_tflops": lanes * n_chunks * NSNET2_EXECUTED_FLOP_PER_CHUNK / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
-                "nsnet2_f32_equivalent_frac_of_f32_mfma_peak": lanes * n_chunks * NSNET2_EXECUTED_FLOP_PER_CHUNK / (nn_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS if nn_ms else 0.0,
-                "nsnet2_effective_tflops_unfolded_network": lanes * n_chunks * NSNET2_FLOP_PER_CHUNK / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
-                "hbm_algorithmic_GBps": frames_per_step * 3840 / (dev_ms_step * 1e-3) / 1e9 if dev_ms_step else 0.0,
-                "hbm_frac_of_8TBps": frames_per_step * 3840 / (dev_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS if dev_ms_step else 0.0},
+            "roofline": roofline_of(head),
+            "roofline_pipeline": pipeline_of(head),
             "kernel_ms_per_step": {k: v / args.steps for k, v in ktimes.items()},
             "aggregate": {"ms": agg_ms, "n_streams": lanes * world, "tpr": agg.true_positive_rate.overall,
                           "ppv": agg.precision.overall, "collective": collective},
             "self_check": self_check,
+            "parity_note": "parity unpinned: the checker is oracle/, a CPU restatement of the reference; the reference holds no "
+                           "golden vector for FFT / NSNet2 / band sums / segments and cannot be built here (DESIGN.md section 4)",
+            "emulated": emulated,
             "headline_as_stereo": stereo,
-            "other_nn_math": other_math,
             "host_vad_threads": vad_threads,
-            "gpu_stage_wall_ms": float(np.mean(gpu_wall_ms[args.warmup:])),
+            "gpu_stage_wall_ms": head["gpu_wall_ms"],
             "kernel_ms_sum": float(sum(ktimes.values()) / args.steps),
-            "join_wait_ms": [round(j, 1) for j in join_ms],
-            "host_stage_ms": float(np.mean(host_ms)),
+            "join_wait_ms": head["join_ms"],
+            "host_stage_ms": head["host_ms"],
         }
         # the CPU baseline and the side measurements belong to the single-GPU run only
         if not args.no_cpu_baseline and world == 1:
@@ -610,7 +708,7 @@ def main():
         if not args.no_extra and world == 1:
             out["extra"] = side_measurements(pkg, fv, ctx, torch, dev)
         print(json.dumps(out))
-        if not self_check or not self_check["ok"]:
+        if not self_check or not self_check["ok"] or (emulated and not emulated["self_check"]["ok"]):
             print("bench.py: SELF-CHECK FAILED: the timed configuration does not match the oracle", file=sys.stderr)
             sys.exit(1)
     if world > 1:
@@ -802,7 +900,7 @@ def side_measurements(pkg, fv, ctx, torch, dev):
     except Exception as e:  # e.g. not enough free HBM next to other tenants
         extra["cfg4_shape_21_streams_x_7200s_one_gpu"] = {"error": repr(e)}
     # BASELINE config 5's "hipGraph-captured steady-state loop": the same device-resident call launched
-    # directly and replayed from a captured hipGraph (FVAD_GRAPH=1), at a large and at the smallest shape
+    # directly and replayed from a captured hipGraph (fvad_engine_opts.use_graph), at a large and at the smallest shape
     note("hipGraph replay")
     try:
         for tag, n_l2, n_ch2, reps in (("16384_chunks", 128, 128, 6), ("2_chunks", 2, 1, 40)):
@@ -812,19 +910,17 @@ def side_measurements(pkg, fv, ctx, torch, dev):
             dg = torch.empty((n_l2, n_ch2 * CHUNK), device=dev)
             res = {}
             for mode in ("direct", "graph"):
-                if mode == "graph":
-                    os.environ["FVAD_GRAPH"] = "1"
-                else:
-                    os.environ.pop("FVAD_GRAPH", None)
+                go = fv.EngineOpts()
+                L.fvad_engine_opts_default(C.byref(go))
+                go.use_graph = 1 if mode == "graph" else 0
                 for it in range(reps + 2):
                     if it == 2:
                         ctx.synchronize()
                         t0 = time.perf_counter()
                     fv.check(L.fvad_engine_enqueue_device(ctx.h, xg.data_ptr(), n_l2, xg.stride(0), n_ch2 * CHUNK, dg.data_ptr(),
-                                                          bg.data_ptr(), rg.data_ptr(), None), "graph bench", ctx.h)
+                                                          bg.data_ptr(), rg.data_ptr(), C.byref(go)), "graph bench", ctx.h)
                 ctx.synchronize()
                 res[mode] = (time.perf_counter() - t0) / reps * 1e3
-            os.environ.pop("FVAD_GRAPH", None)
             extra[f"hipgraph_replay_{tag}"] = {"direct_ms": res["direct"], "graph_ms": res["graph"],
                                                "note": "per call of fvad_engine_enqueue_device; ~12 kernel launches per launch batch"}
             del xg, bg, rg, dg

@@ -91,7 +91,8 @@ class Lane(C.Structure):
 
 class EngineOpts(C.Structure):
     _fields_ = [("on_device", C.c_int32), ("min_bin", C.c_int32), ("max_bin", C.c_int32),
-                ("max_chunks_per_launch", C.c_int32), ("fft_size", C.c_int32), ("no_wait", C.c_int32)]
+                ("max_chunks_per_launch", C.c_int32), ("fft_size", C.c_int32), ("no_wait", C.c_int32),
+                ("use_graph", C.c_int32)]
 
 
 class AudioBuffer(C.Structure):
@@ -192,6 +193,10 @@ SIGNATURES = {
     "fvad_nsnet2_forward": (C.c_int, [vp, c_float_p, sz, sz, c_float_p]),
     "fvad_ctx_enable_timing": (C.c_int, [vp, C.c_int]),
     "fvad_ctx_set_nn_math": (C.c_int, [vp, C.c_int]),
+    "fvad_ctx_nn_math_effective": (C.c_int, [vp]),
+    "fvad_ctx_last_nn_path": (C.c_char_p, [vp]),
+    "fvad_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
+    "fvad_ctx_ws_fallbacks": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "fvad_ctx_kernel_times": (C.c_int, [vp, C.POINTER(C.c_char_p), c_float_p, sz,
                                         C.POINTER(sz)]),
     "fvad_vad_config_default": (None, [C.POINTER(VadConfig)]),
@@ -371,7 +376,8 @@ class Context:
         self._ck(lib().fvad_ctx_synchronize(self.h), "fvad_ctx_synchronize")
 
     def set_nn_math(self, mode):
-        """'f16x3' (default) or 'f32': arithmetic of the large-batch NSNet2 matrix products; returns the previous mode"""
+        """'f32' (default: the reference's arithmetic) or 'f16x3' (emulation on the f16 matrix cores): arithmetic of the
+        NSNet2 matrix products at every batch size; returns the previous mode"""
         m = {"f32": 0, "f16x3": 1}[mode]
         prev = lib().fvad_ctx_set_nn_math(self.h, m)
         if prev < 0:
@@ -380,6 +386,42 @@ class Context:
 
     def set_nn_math_raw(self, mode):
         return self._ck(lib().fvad_ctx_set_nn_math(self.h, int(mode)), "fvad_ctx_set_nn_math")
+
+    def nn_math_effective(self):
+        """what the context uses with the loaded model: 'f32' or 'f16x3'"""
+        m = lib().fvad_ctx_nn_math_effective(self.h)
+        if m < 0:
+            self._ck(m, "fvad_ctx_nn_math_effective")
+        return ("f32", "f16x3")[m]
+
+    def last_nn_path(self):
+        return lib().fvad_ctx_last_nn_path(self.h).decode()
+
+    def set_option(self, name, value=None):
+        """testing / tuning aid (fvad_ctx_set_option); value None restores the default"""
+        v = None if value is None else str(value).encode()
+        self._ck(lib().fvad_ctx_set_option(self.h, name.encode(), v), "fvad_ctx_set_option")
+
+    def options(self, **kv):
+        """context manager: set the options, restore the defaults on exit"""
+        ctx = self
+
+        class _Opts:
+            def __enter__(self_):
+                for k, v in kv.items():
+                    ctx.set_option(k, v)
+                return ctx
+
+            def __exit__(self_, *exc):
+                for k in kv:
+                    ctx.set_option(k, None)
+                return False
+        return _Opts()
+
+    def ws_fallbacks(self):
+        n = C.c_uint64(0)
+        self._ck(lib().fvad_ctx_ws_fallbacks(self.h, C.byref(n)), "fvad_ctx_ws_fallbacks")
+        return n.value
 
     def enable_timing(self, on=True):
         self._ck(lib().fvad_ctx_enable_timing(self.h, 1 if on else 0), "fvad_ctx_enable_timing")
@@ -492,11 +534,12 @@ class Context:
         return arr
 
     def enqueue_device(self, d_pcm, n_lanes, lane_stride, n_samples, d_den, d_band, d_rms, max_chunks_per_launch=0,
-                       no_wait=False):
+                       no_wait=False, use_graph=False):
         opts = EngineOpts()
         lib().fvad_engine_opts_default(C.byref(opts))
         opts.max_chunks_per_launch = max_chunks_per_launch
         opts.no_wait = 1 if no_wait else 0
+        opts.use_graph = 1 if use_graph else 0
         self._ck(lib().fvad_engine_enqueue_device(self.h, vp(d_pcm), n_lanes, lane_stride, n_samples,
                                                   vp(d_den) if d_den else None, vp(d_band), vp(d_rms) if d_rms else None,
                                                   C.byref(opts)), "fvad_engine_enqueue_device")

@@ -67,6 +67,7 @@ struct fvad_comm {
     float* d_send = nullptr;
     float* d_recv = nullptr;
     size_t cap_rows = 0; // rows per rank the device blocks can hold
+    uint32_t* d_hdr = nullptr; // [2 + 2 * world] words: this rank's {n_streams, status}, then every rank's
 };
 
 extern "C" {
@@ -99,6 +100,11 @@ int fvad_comm_create(fvad_ctx* ctx, const uint8_t* id, size_t n, int world, int 
         delete c;
         return set_err(ctx, FVAD_ERR_HIP, std::string("ncclCommInitRank: ") + a->GetErrorString(r));
     }
+    if (hipMalloc((void**)&c->d_hdr, (size_t)(2 + 2 * world) * sizeof(uint32_t)) != hipSuccess) {
+        a->CommDestroy(c->comm);
+        delete c;
+        return set_err(ctx, FVAD_ERR_ALLOC_FAILED, "hipMalloc failed");
+    }
     *out = c;
     return FVAD_OK;
 }
@@ -111,6 +117,7 @@ void fvad_comm_destroy(fvad_comm* c)
     if (c->comm) rccl()->CommDestroy(c->comm);
     if (c->d_send) hipFree(c->d_send);
     if (c->d_recv) hipFree(c->d_recv);
+    if (c->d_hdr) hipFree(c->d_hdr);
     delete c;
 }
 
@@ -125,22 +132,46 @@ int fvad_stats_allgather(fvad_comm* c, const uint32_t* local_ids, const fvad_sin
     RcclApi* a = rccl();
     hipSetDevice(ctx->device);
     const size_t per_rank = (n_streams + (size_t)c->world - 1) / (size_t)c->world;
-    if (n_local > per_rank) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "more local streams than ceil(n_streams / world)");
-    if (per_rank > c->cap_rows) {
+    // Everything that can fail on ONE rank is checked before any rank enters the data collective, and the verdict is
+    // shared first: a header all-gather of {n_streams, local status} per rank (its count does not depend on the
+    // arguments).  A rank with a bad argument or a failed allocation still takes part in it, so no rank is left
+    // waiting in ncclAllGather for one that returned early, and ranks that disagree about n_streams (which sets the
+    // data collective's count) find out here.
+    int local_rc = FVAD_OK;
+    const char* local_msg = "";
+    if (n_local > per_rank) { local_rc = FVAD_ERR_INVALID_ARGUMENT; local_msg = "more local streams than ceil(n_streams / world)"; }
+    for (size_t j = 0; j < n_local && !local_rc; ++j)
+        if (local_ids[j] >= n_streams) { local_rc = FVAD_ERR_OUT_OF_RANGE; local_msg = "stream id >= n_streams"; }
+    if (!local_rc && per_rank > c->cap_rows) {
         hipStreamSynchronize(ctx->stream);
         if (c->d_send) hipFree(c->d_send);
         if (c->d_recv) hipFree(c->d_recv);
         c->d_send = c->d_recv = nullptr; c->cap_rows = 0;
-        FVAD_HIP(ctx, hipMalloc((void**)&c->d_send, per_rank * kRow * sizeof(float)));
-        FVAD_HIP(ctx, hipMalloc((void**)&c->d_recv, per_rank * kRow * sizeof(float) * (size_t)c->world));
-        c->cap_rows = per_rank;
+        if (hipMalloc((void**)&c->d_send, per_rank * kRow * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&c->d_recv, per_rank * kRow * sizeof(float) * (size_t)c->world) != hipSuccess) {
+            (void)hipGetLastError();
+            local_rc = FVAD_ERR_ALLOC_FAILED; local_msg = "hipMalloc failed";
+        } else c->cap_rows = per_rank;
+    }
+    {
+        const uint32_t hdr[2] = {(uint32_t)n_streams, (uint32_t)(-local_rc)};
+        std::vector<uint32_t> all_hdr(2 * (size_t)c->world);
+        FVAD_HIP(ctx, hipMemcpyAsync(c->d_hdr, hdr, sizeof hdr, hipMemcpyHostToDevice, ctx->stream));
+        const ncclResult_t r = a->AllGather(c->d_hdr, c->d_hdr + 2, 2, ncclUint32, c->comm, ctx->stream);
+        if (r != ncclSuccess) return set_err(ctx, FVAD_ERR_HIP, std::string("ncclAllGather (header): ") + a->GetErrorString(r));
+        FVAD_HIP(ctx, hipMemcpyAsync(all_hdr.data(), c->d_hdr + 2, all_hdr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        FVAD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (local_rc) return set_err(ctx, local_rc, local_msg);
+        for (int rk = 0; rk < c->world; ++rk) {
+            if (all_hdr[2 * rk + 1]) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "fvad_stats_allgather failed on rank " + std::to_string(rk) + " (status " + fvad_status_name(-(int)all_hdr[2 * rk + 1]) + ")");
+            if (all_hdr[2 * rk] != (uint32_t)n_streams) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "ranks disagree about n_streams (rank " + std::to_string(rk) + ")");
+        }
     }
     // this rank's block: [per_rank][12], unused rows carry the id 0xFFFFFFFF
     std::vector<float> block(per_rank * kRow, 0.0f);
     for (size_t j = 0; j < per_rank; ++j) {
         uint32_t id = 0xFFFFFFFFu;
         if (j < n_local) {
-            if (local_ids[j] >= n_streams) return set_err(ctx, FVAD_ERR_OUT_OF_RANGE, "stream id >= n_streams");
             id = local_ids[j];
             memcpy(&block[j * kRow + 1], &local_stats[j], sizeof(fvad_single_stats));
         }

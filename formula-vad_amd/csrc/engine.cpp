@@ -7,6 +7,7 @@
 // recomputed from the contiguous lane audio or, at the first chunk of a launch, read from the
 // lane's LaneCarry.
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -249,13 +250,12 @@ int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
     return FVAD_OK;
 }
 
-// FVAD_TRACE_KERNELS=1 (debugging aid): name every stage on stderr and wait for it, so that a faulting kernel is
+// option trace_kernels (debugging aid): name every stage on stderr and wait for it, so that a faulting kernel is
 // the last one named
 static const char* g_trace_name = nullptr;
 void time_begin(fvad_ctx* ctx, const char* name)
 {
-    static const bool trace = getenv("FVAD_TRACE_KERNELS") != nullptr;
-    if (trace) { g_trace_name = name; fprintf(stderr, "fvad: %s ...", name); fflush(stderr); }
+    if (ctx->tune.trace_kernels) { g_trace_name = name; fprintf(stderr, "fvad: %s ...", name); fflush(stderr); }
     if (!ctx->timing) return;
     KernelTime kt;
     kt.name = name;
@@ -317,15 +317,37 @@ static double gru_cost(long n_pad, int waves, int n_cu)
 // Batch padding: the 12-wave recurrence needs a multiple of 192 sequences and the GEMM row panels a
 // multiple of 256 rows (of 54 and of 50 rows per sequence), i.e. 384 sequences; the other shapes need
 // 128.  Pick whichever padding gives the cheaper recurrence.
+// The arithmetic of the NSNet2 matrix products is a property of the context (and of the loaded model), never of
+// a launch's size: f16x3 when it was asked for (fvad_ctx_set_nn_math, or FVAD_NN_MATH at fvad_ctx_create), the model
+// is eligible (DeviceModel::h3_ok) and no f32 kernel variant is forced; f32 otherwise.
+int nn_math_effective(const fvad_ctx* ctx)
+{
+    const Tuning& tn = ctx->tune;
+    const int want = tn.nn_math_force >= 0 ? tn.nn_math_force : ctx->nn_math;
+    if (want != FVAD_NN_MATH_F16X3) return FVAD_NN_MATH_F32;
+    if (!tn.gru_kernel.empty() || !tn.gemm_kernel.empty()) return FVAD_NN_MATH_F32;
+    if (ctx->dm.loaded && !ctx->dm.h3_ok) return FVAD_NN_MATH_F32;
+    return FVAD_NN_MATH_F16X3;
+}
+
 static long padded_batch(const fvad_ctx* ctx, long n)
 {
     const long a = (n + 383) / 384 * 384, b = (n + 127) / 128 * 128;
-    const char* force = getenv("FVAD_GRU_KERNEL");
+    const Tuning& tn = ctx->tune;
+    const char* force = tn.gru_kernel.empty() ? nullptr : tn.gru_kernel.c_str();
     const int cu = ctx->n_cu;
+    if (nn_math_effective(ctx) == FVAD_NN_MATH_F16X3) {
+        // kernels_h3.hip at every batch size: 192- or 128-sequence workgroups (a round of the latter costs 0.76 of a
+        // round of the former)
+        if (a == b || tn.h3_waves == 12) return a;
+        if (tn.h3_waves == 8) return b;
+        const double ca = (double)((a / 192 + cu - 1) / cu), cb = 0.76 * (double)((b / 128 + cu - 1) / cu);
+        return cb <= ca ? b : a;
+    }
     // the weight-stationary recurrence and the small-batch GEMMs (64-row workgroups over 54 n and 50 n rows)
     // only need a multiple of 32 sequences
     const long c = (n + 31) / 32 * 32;
-    if ((!force || force[1] == '5') && !getenv("FVAD_GEMM_KERNEL") && c < 2048 &&
+    if (!tn.reproducible && (!force || force[1] == '5') && tn.gemm_kernel.empty() && c < 2048 &&
         gru_ws_cost(c, cu) < std::min(gru_cost(b, 0, cu), gru_cost(b, 4, cu)))
         return c;
     if (force || a == b) return a;
@@ -336,13 +358,20 @@ static long padded_batch(const fvad_ctx* ctx, long n)
 
 static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, bool allow_v3)
 {
-    const char* force = getenv("FVAD_GRU_KERNEL"); // tuning aid: "v3w12", "v3w8", "v3w4", "v4w8" (gru_lat), "v5w0" (gru_ws)
+    const char* force = ctx->tune.gru_kernel.empty() ? nullptr : ctx->tune.gru_kernel.c_str(); // "v3w12", "v3w8", "v3w4", "v4w8" (gru_lat), "v5w0" (gru_ws)
     if (force) {
         GruChoice c{force[1] - '0', atoi(force + 3)};
         if (c.version == 3 && !allow_v3) c = {4, 8}; // gru_rec3 needs the folded biases of the large-batch path
         return c;
     }
     const int cu = ctx->n_cu;
+    if (ctx->tune.reproducible && allow_v3 && n_pad % 64 == 0) {
+        // one kernel family at every batch size: gru_rec3 (its 4-, 8- and 12-wave shapes run the same per-row chains)
+        int w = 4;
+        if (n_pad % 128 == 0 && gru_cost(n_pad, 8, cu) < gru_cost(n_pad, w, cu)) w = 8;
+        if (n_pad % 192 == 0 && gru_cost(n_pad, 12, cu) < gru_cost(n_pad, w, cu)) w = 12;
+        return {3, w};
+    }
     int best = 0; // low-latency shape
     if (n_pad % 64 == 0 && gru_cost(n_pad, 4, cu) < gru_cost(n_pad, best, cu)) best = 4;
     if (n_pad % 128 == 0 && gru_cost(n_pad, 8, cu) < gru_cost(n_pad, best, cu)) best = 8;
@@ -365,6 +394,11 @@ int ensure_gru_ws(fvad_ctx* ctx)
     }
     if (!ws.ws_sync) {
         FVAD_HIP(ctx, hipMalloc((void**)&ws.ws_sync, kWsSyncWords * sizeof(unsigned)));
+        ws.generation++;
+    }
+    if (!ws.ws_fallbacks) {
+        FVAD_HIP(ctx, hipMalloc((void**)&ws.ws_fallbacks, sizeof(unsigned long long)));
+        FVAD_HIP(ctx, hipMemsetAsync(ws.ws_fallbacks, 0, sizeof(unsigned long long), ctx->stream));
         ws.generation++;
     }
     return FVAD_OK;
@@ -400,12 +434,16 @@ static int launch_gru(fvad_ctx* ctx, GruChoice c, const float* gi, const DevBuf&
                 if (!ev) { if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return -1; }
                 else if (hipStreamWaitEvent(ctx->stream, ev, 0) != hipSuccess) return -1;
             }
-            rc = fvad_launch_gru_ws(gi, r_v2.p, bR, hout, ws.hx, ws.ws_sync + 256 * layer, err, n_pad, T, ctx->n_cu, tile_major, ctx->stream);
+            rc = fvad_launch_gru_ws(gi, r_v2.p, bR, hout, ws.hx, ws.ws_sync + 256 * layer, err, n_pad, T, ctx->n_cu, tile_major,
+                                    ctx->tune.ws_spin_ticks, ctx->stream);
             if (serialise && hipEventRecord(g_ws_ev[ctx->device], ctx->stream) != hipSuccess) return -1;
         }
         if (rc) return rc;
-        // fallback behind it: returns at once unless a workgroup of the launch above gave up waiting
-        return fvad_launch_gru_lat(gi, r_v2.p, bR, hout, n_pad, T, err, tile_major, ctx->stream);
+        // fallback behind it: returns at once unless a workgroup of the launch above gave up waiting; the last layer
+        // of a pass adds the error word to the context's fallback counter (fvad_ctx_ws_fallbacks)
+        rc = fvad_launch_gru_lat(gi, r_v2.p, bR, hout, n_pad, T, err, tile_major, ctx->stream);
+        if (rc == 0 && layer == 1) fvad_launch_count_word(ws.ws_fallbacks, err, ctx->stream);
+        return rc;
     }
     if (c.waves <= 0 || n_pad % (16 * c.waves)) return -1;
     if (c.version == 3) return fvad_launch_gru_rec3(gi, r_v2.p, bR, hout, n_pad, T, c.waves, ctx->stream);
@@ -421,8 +459,11 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     const long rows = n_pad * T;
     const long rows_out = n_pad * (T - skip);
     int rc = 0;
-    const char* force = getenv("FVAD_GEMM_KERNEL"); // tuning aid: "v1" (small-batch GEMM) / "v3" / "v3nofold"
-    const bool big = force ? force[1] != '1' : (n_pad >= 2048);
+    const Tuning& tn = ctx->tune;
+    const char* force = tn.gemm_kernel.empty() ? nullptr : tn.gemm_kernel.c_str(); // "v1" (small-batch GEMM) / "v3" / "v3nofold"
+    const bool h3 = nn_math_effective(ctx) == FVAD_NN_MATH_F16X3;
+    if (h3 && n_pad % 128) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "f16x3 kernels need a batch padded to 128 sequences");
+    const bool big = h3 || (force ? force[1] != '1' : (tn.reproducible || n_pad >= 2048));
     if (big && rows % 256 == 0 && rows_out % 256 == 0) {
         // The persistent kernel: one workgroup per CU walking all (row panel, column block) items; 15-, 13- and
         // 11-tile column blocks.  K is the true reduction length (S super-steps of 16 cover it, zero-padded).
@@ -438,13 +479,10 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
             return fvad_launch_panel_gemm_h3(A, in_ts, a_ld, W.p, b, Cc, out, c_ld, seq_T, row_tiles, nt, nblk, K, act, valid,
                                              mT, mskip, sc.sx, sc.sw, out_sx, ctx->n_cu, st);
         };
-        const char* math = getenv("FVAD_NN_MATH"); // tuning aid: "f32" (f32 MFMA) / "f16x3" (kernels_h3.hip)
-        const bool want_h3 = math ? !strcmp(math, "f16x3") : ctx->nn_math == FVAD_NN_MATH_F16X3;
-        const bool h3 = want_h3 && m.h3_ok && !force && !getenv("FVAD_GRU_KERNEL") && (n_pad % 192 == 0 || n_pad % 128 == 0);
         if (h3) {
-            const char* hw = getenv("FVAD_H3_WAVES"); // tuning aid: 8 / 12
             int waves = n_pad % 192 == 0 ? 12 : 8;
-            if (hw && (atoi(hw) == 8 || atoi(hw) == 12) && n_pad % (16 * atoi(hw)) == 0) waves = atoi(hw);
+            if ((tn.h3_waves == 8 || tn.h3_waves == 12) && n_pad % (16 * tn.h3_waves) == 0) waves = tn.h3_waves;
+            ctx->last_nn_path = std::string("f16x3: panel_gemm_h3 + gru_rec_h3<") + std::to_string(waves) + ">";
             const long G = n_pad / 16;
             // gi: tiled f32; hs1 / hs2 / f2 / f3: split tiled, scaled for the layer that reads them
             time_begin(ctx, "gru1_in_gemm_fc1folded");
@@ -474,6 +512,8 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
         }
         const bool fold = !(force && strstr(force, "nofold"));
         const GruChoice gc = pick_gru(ctx, n_pad, fold);
+        ctx->last_nn_path = std::string("f32: panel_gemm3") + (fold ? " (fc1 folded)" : "") + " + " +
+                            (gc.version == 3 ? "gru_rec3<" + std::to_string(gc.waves) + ">" : gc.version == 5 ? std::string("gru_ws") : std::string("gru_lat"));
         if (gc.version == 5 && (rc = prepare_gru_ws(ctx, n_pad))) return rc; // only when forced: tuning / tests
         const bool bzr = gc.version == 3;
         if (fold) {
@@ -518,6 +558,7 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     time_end(ctx);
     const GruChoice gcs = pick_gru(ctx, n_pad, false);
     if (gcs.version == 5 && (rc = prepare_gru_ws(ctx, n_pad))) return rc;
+    ctx->last_nn_path = std::string("f32: panel_gemm + ") + (gcs.version == 5 ? "gru_ws" : "gru_lat");
     time_begin(ctx, "gru1_rec");
     rc |= launch_gru(ctx, gcs, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T, 0, 0);
     time_end(ctx);
@@ -549,10 +590,7 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
     // uploaded once by the caller after the capture): the graph holds no copy node and does not depend on
     // the workspace's shared table, which direct calls overwrite.  No event is waited for or recorded.
     size_t capture_off = 0;
-    if (max_chunks <= 0) {
-        const char* e = getenv("FVAD_MAX_CHUNKS"); // tuning aid
-        max_chunks = e ? atol(e) : 49152;
-    }
+    if (max_chunks <= 0) max_chunks = ctx->tune.max_chunks;
     long total = 0;
     for (auto& j : jobs) total += (long)j.n_chunks;
     if (total == 0) return FVAD_OK;
@@ -662,6 +700,49 @@ int get_vad_plan(fvad_ctx* ctx, size_t n, VadFftPlan* out)
     return FVAD_OK;
 }
 
+// value == nullptr or "": back to the default
+static int apply_option(fvad_ctx* ctx, const std::string& name, const char* value)
+{
+    Tuning& tn = ctx->tune;
+    const Tuning def;
+    const bool unset = !value || !*value;
+    const std::string v = unset ? "" : value;
+    auto to_long = [&](long& out) { char* end = nullptr; out = strtol(v.c_str(), &end, 10); return end && *end == 0; };
+    auto to_bool = [&](bool& out) { if (unset || v == "0") { out = false; return true; } if (v == "1") { out = true; return true; } return false; };
+    if (name == "nn_math") {
+        if (unset) tn.nn_math_force = -1;
+        else if (v == "f32") tn.nn_math_force = FVAD_NN_MATH_F32;
+        else if (v == "f16x3") tn.nn_math_force = FVAD_NN_MATH_F16X3;
+        else return FVAD_ERR_INVALID_ARGUMENT;
+    } else if (name == "gru_kernel") {
+        if (!unset && v != "v3w12" && v != "v3w8" && v != "v3w4" && v != "v4w8" && v != "v5w0") return FVAD_ERR_INVALID_ARGUMENT;
+        tn.gru_kernel = v;
+    } else if (name == "gemm_kernel") {
+        if (!unset && v != "v1" && v != "v3" && v != "v3nofold") return FVAD_ERR_INVALID_ARGUMENT;
+        tn.gemm_kernel = v;
+    } else if (name == "h3_waves") {
+        long w = 0;
+        if (!unset && (!to_long(w) || (w != 0 && w != 8 && w != 12))) return FVAD_ERR_INVALID_ARGUMENT;
+        tn.h3_waves = (int)w;
+    } else if (name == "max_chunks") {
+        long c = def.max_chunks;
+        if (!unset && (!to_long(c) || c < 1)) return FVAD_ERR_INVALID_ARGUMENT;
+        tn.max_chunks = c;
+    } else if (name == "copy_threads") {
+        long c = def.copy_threads;
+        if (!unset && (!to_long(c) || c < 1 || c > 256)) return FVAD_ERR_INVALID_ARGUMENT;
+        tn.copy_threads = (int)c;
+    } else if (name == "ws_spin_ticks") {
+        if (unset) tn.ws_spin_ticks = def.ws_spin_ticks;
+        else { char* end = nullptr; tn.ws_spin_ticks = strtoull(v.c_str(), &end, 10); if (!end || *end) return FVAD_ERR_INVALID_ARGUMENT; }
+    } else if (name == "no_pipeline") { if (!to_bool(tn.no_pipeline)) return FVAD_ERR_INVALID_ARGUMENT; }
+    else if (name == "trace_kernels") { if (!to_bool(tn.trace_kernels)) return FVAD_ERR_INVALID_ARGUMENT; }
+    else if (name == "reproducible") { if (!to_bool(tn.reproducible)) return FVAD_ERR_INVALID_ARGUMENT; }
+    else return FVAD_ERR_INVALID_ARGUMENT;
+    ctx->ws.generation++; // a captured launch sequence holds the kernels of the old selection
+    return FVAD_OK;
+}
+
 } // namespace fvad
 
 using namespace fvad;
@@ -736,6 +817,18 @@ int fvad_ctx_create(int device, fvad_ctx** out)
     ctx->tb.st320 = ctx->d_tables + o_st320;
     VadFftPlan pl;
     if (get_vad_plan(ctx, kVadFft, &pl) != FVAD_OK) { fvad_ctx_destroy(ctx); return FVAD_ERR_HIP; }
+    // the tuning variables FVAD_<NAME> are read here, once; a bad value fails the creation rather than being ignored
+    for (const char* opt : {"nn_math", "gru_kernel", "gemm_kernel", "h3_waves", "max_chunks", "copy_threads", "ws_spin_ticks",
+                            "no_pipeline", "trace_kernels", "reproducible"}) {
+        std::string env = std::string("FVAD_") + opt;
+        for (char& c : env) c = (char)toupper((unsigned char)c);
+        const char* v = getenv(env.c_str());
+        if (v && *v && apply_option(ctx, opt, v) != FVAD_OK) {
+            fprintf(stderr, "fvad: bad value in environment: %s=%s\n", env.c_str(), v);
+            fvad_ctx_destroy(ctx);
+            return FVAD_ERR_INVALID_ARGUMENT;
+        }
+    }
     *out = ctx;
     return FVAD_OK;
 }
@@ -756,6 +849,7 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     if (ws.carries) hipFree(ws.carries);
     if (ws.hx) hipFree(ws.hx);
     if (ws.ws_sync) hipFree(ws.ws_sync);
+    if (ws.ws_fallbacks) hipFree(ws.ws_fallbacks);
     for (Workspace::PinRing* r : {&ws.ring_in, &ws.ring_out}) {
         if (r->base) hipHostFree(r->base);
         for (hipEvent_t& e : r->ev) if (e) hipEventDestroy(e);
@@ -848,6 +942,35 @@ int fvad_ctx_set_nn_math(fvad_ctx* ctx, int mode)
     if (prev != mode) ctx->ws.generation++; // a captured launch sequence holds the other kernels
     ctx->nn_math = mode;
     return prev;
+}
+
+int fvad_ctx_nn_math_effective(const fvad_ctx* ctx)
+{
+    if (!ctx) return FVAD_ERR_INVALID_ARGUMENT;
+    return nn_math_effective(ctx);
+}
+
+const char* fvad_ctx_last_nn_path(const fvad_ctx* ctx) { return ctx ? ctx->last_nn_path.c_str() : ""; }
+
+int fvad_ctx_ws_fallbacks(fvad_ctx* ctx, uint64_t* n)
+{
+    if (!ctx || !n) return FVAD_ERR_INVALID_ARGUMENT;
+    *n = 0;
+    if (!ctx->ws.ws_fallbacks) return FVAD_OK; // the weight-stationary recurrence never ran on this context
+    hipSetDevice(ctx->device);
+    unsigned long long v = 0;
+    FVAD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FVAD_HIP(ctx, hipMemcpy(&v, ctx->ws.ws_fallbacks, sizeof(v), hipMemcpyDeviceToHost));
+    *n = (uint64_t)v;
+    return FVAD_OK;
+}
+
+int fvad_ctx_set_option(fvad_ctx* ctx, const char* name, const char* value)
+{
+    if (!ctx || !name) return FVAD_ERR_INVALID_ARGUMENT;
+    const int rc = apply_option(ctx, name, value);
+    if (rc) return set_err(ctx, rc, std::string("fvad_ctx_set_option: unknown option or bad value: ") + name + "=" + (value ? value : ""));
+    return FVAD_OK;
 }
 
 int fvad_ctx_enable_timing(fvad_ctx* ctx, int on)
@@ -1000,6 +1123,7 @@ void fvad_engine_opts_default(fvad_engine_opts* o)
     o->max_chunks_per_launch = 0;
     o->fft_size = 0; // 1024
     o->no_wait = 0;
+    o->use_graph = 0;
 }
 
 static int grow(fvad_ctx* ctx, float** p, size_t* cap, size_t need)
@@ -1035,9 +1159,8 @@ int ensure_pin(fvad_ctx* ctx, Workspace::PinRing& ring)
     return FVAD_OK;
 }
 
-void parallel_memcpy(const std::vector<CopySeg>& blocks, size_t first, size_t n, char* slots, bool to_pinned)
+void parallel_memcpy(const std::vector<CopySeg>& blocks, size_t first, size_t n, char* slots, bool to_pinned, int n_threads)
 {
-    static const int n_threads = [] { const char* e = getenv("FVAD_COPY_THREADS"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();
     auto work = [&](size_t t) {
         for (size_t i = t; i < n; i += (size_t)n_threads) {
             const CopySeg& b = blocks[first + i];
@@ -1091,7 +1214,7 @@ int staged_copy(fvad_ctx* ctx, const std::vector<CopySeg>& segs, bool to_device,
     if (to_device) {
         for (size_t w = 0; w < n_waves; ++w) {
             if (w >= 2) FVAD_HIP(ctx, hipEventSynchronize(ring.ev[w & 1])); // this half's previous DMA is done
-            parallel_memcpy(blocks, w * kPinSlots, wave_n(w), half(w), true);
+            parallel_memcpy(blocks, w * kPinSlots, wave_n(w), half(w), true, ctx->tune.copy_threads);
             for (size_t i = 0; i < wave_n(w); ++i) {
                 const CopySeg& b = blocks[w * kPinSlots + i];
                 FVAD_HIP(ctx, hipMemcpyAsync(b.dev, half(w) + i * kPinSlotBytes, b.bytes, hipMemcpyHostToDevice, st));
@@ -1111,7 +1234,7 @@ int staged_copy(fvad_ctx* ctx, const std::vector<CopySeg>& segs, bool to_device,
             }
             if (w >= 1) { // drain the previous wave while this one's DMA runs
                 FVAD_HIP(ctx, hipEventSynchronize(ring.ev[(w - 1) & 1]));
-                parallel_memcpy(blocks, (w - 1) * kPinSlots, wave_n(w - 1), half(w - 1), false);
+                parallel_memcpy(blocks, (w - 1) * kPinSlots, wave_n(w - 1), half(w - 1), false, ctx->tune.copy_threads);
             }
         }
     }
@@ -1249,7 +1372,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
     size_t h2d_bytes = 0;
     for (const CopySeg& c : h2d) h2d_bytes += c.bytes;
     int G = 1;
-    if (!opts.on_device && n_lanes >= 8 && h2d_bytes >= (64u << 20) && !getenv("FVAD_NO_PIPELINE")) G = 4;
+    if (!opts.on_device && n_lanes >= 8 && h2d_bytes >= (64u << 20) && !ctx->tune.no_pipeline) G = 4;
     if (G > 1) {
         if (!ws.copy_in) FVAD_HIP(ctx, hipStreamCreateWithFlags(&ws.copy_in, hipStreamNonBlocking));
         if (!ws.copy_out) FVAD_HIP(ctx, hipStreamCreateWithFlags(&ws.copy_out, hipStreamNonBlocking));
@@ -1282,13 +1405,23 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
             ws.fft_jobs_cap = n_lanes;
             ws.generation++;
         }
+        // the pinned table has two slots (shared with fvad_engine_enqueue_device*, whose no_wait calls may still have
+        // an upload pending): a slot is rewritten only after its previous upload has left the host
+        const int js = ws.jobs_slot;
+        ws.jobs_slot ^= 1;
+        if (!ws.jobs_ev[js]) FVAD_HIP(ctx, hipEventCreateWithFlags(&ws.jobs_ev[js], hipEventDisableTiming));
+        else FVAD_HIP(ctx, hipEventSynchronize(ws.jobs_ev[js]));
+        VadFftJob* hj = ws.h_fft_jobs + (size_t)js * ws.fft_jobs_cap;
         for (size_t l = 0; l < n_lanes; ++l) {
             const fvad_lane& L = lanes[l];
-            ws.h_fft_jobs[l] = {jobs[l].d_den - n_rem[l], ws.band + band_off[l],
-                                L.fft_bins ? ws.bins + band_off[l] * NB : nullptr, (long)L.n_fft_frames};
+            hj[l] = {jobs[l].d_den - n_rem[l], ws.band + band_off[l],
+                     L.fft_bins ? ws.bins + band_off[l] * NB : nullptr, (long)L.n_fft_frames};
             max_frames = std::max(max_frames, (long)L.n_fft_frames);
         }
-        if (max_frames) FVAD_HIP(ctx, hipMemcpyAsync(ws.fft_jobs, ws.h_fft_jobs, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice, st));
+        if (max_frames) {
+            FVAD_HIP(ctx, hipMemcpyAsync(ws.fft_jobs, hj, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice, st));
+            FVAD_HIP(ctx, hipEventRecord(ws.jobs_ev[js], st));
+        }
     }
 
     auto outputs_of = [&](size_t l0, size_t l1) -> int {
@@ -1465,12 +1598,12 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
         return FVAD_OK;
     };
 
-    // Opt-in (FVAD_GRAPH=1): capture the sequence into a hipGraph once and replay it while the arguments
+    // Opt-in (fvad_engine_opts.use_graph): capture the sequence into a hipGraph once and replay it while the arguments
     // and the workspace stay the same -- BASELINE config 5's "hipGraph-captured steady-state loop".  A step
     // is ~12 launches per 100 ms of GPU work, so this saves well under 1 % (measured in bench.py's extras).
-    if (getenv("FVAD_GRAPH") && !ctx->timing) {
+    if (opts.use_graph && !ctx->timing) {
         long maxc = opts.max_chunks_per_launch;
-        if (maxc <= 0) { const char* e = getenv("FVAD_MAX_CHUNKS"); maxc = e ? atol(e) : 49152; }
+        if (maxc <= 0) maxc = ctx->tune.max_chunks;
         const long total = (long)(n_lanes * n_chunks);
         if ((rc = ensure_workspace(ctx, std::min(total, maxc), kRowsPerChunk))) return rc; // no allocation while capturing
         if ((rc = ensure_gru_ws(ctx))) return rc;

@@ -81,9 +81,10 @@ struct Workspace {
     float* bins = nullptr; size_t bins_cap = 0;
     LaneCarry* carries = nullptr; size_t carries_cap = 0; // scratch carries (2 per lane)
     // weight-stationary recurrence (kernels_ws.hip): h exchange buffer and the block of polled words
-    // (256 flags per GRU layer + the error word, zeroed by ONE memset in front of every network pass)
+    // (256 flags per GRU layer + the error word, zeroed by zero_words_kernel in front of every network pass)
     float* hx = nullptr; size_t hx_cap = 0;
     unsigned* ws_sync = nullptr;
+    unsigned long long* ws_fallbacks = nullptr; // device counter: network passes in which gru_ws gave up (gru_lat redid the layers)
     VadFftJob* fft_jobs = nullptr; VadFftJob* h_fft_jobs = nullptr; size_t fft_jobs_cap = 0; // host table: two slots of fft_jobs_cap
     hipEvent_t jobs_ev[2] = {nullptr, nullptr}; int jobs_slot = 0; // slot's upload has left the host (no_wait calls)
     // pinned staging ring for large host <-> device transfers (two halves of kPinSlots slots)
@@ -119,6 +120,21 @@ struct KernelTime {
     hipEvent_t e0, e1;
 };
 
+// Testing / tuning aids of a context (fvad_ctx_set_option).  The environment variables FVAD_<NAME> are read ONCE,
+// by fvad_ctx_create, as the initial values; nothing in the data path looks at the environment.
+struct Tuning {
+    int nn_math_force = -1;      // FVAD_NN_MATH at create: overrides fvad_ctx_set_nn_math (-1: none)
+    std::string gru_kernel;      // "" / "v3w12" / "v3w8" / "v3w4" / "v4w8" (gru_lat) / "v5w0" (gru_ws)
+    std::string gemm_kernel;     // "" / "v1" (small-batch GEMM) / "v3" / "v3nofold"
+    int h3_waves = 0;            // 0 / 8 / 12
+    long max_chunks = 49152;     // chunks per launch when the caller passes 0
+    bool no_pipeline = false;    // host-buffer path: single lane group
+    int copy_threads = 8;        // memcpy threads of the pinned staging rings
+    bool trace_kernels = false;  // name every NSNet2 stage on stderr and wait for it
+    bool reproducible = false;   // one kernel family (the large-batch one) at every batch size
+    unsigned long long ws_spin_ticks = 25000000ull; // spin deadline of gru_ws_kernel (100 MHz ticks: 0.25 s)
+};
+
 } // namespace fvad
 
 struct fvad_ctx {
@@ -137,7 +153,9 @@ struct fvad_ctx {
     fvad::HostWeights hw;
     fvad::DeviceModel dm;
     fvad::Workspace ws;
-    int nn_math = 1; // FVAD_NN_MATH_F16X3
+    int nn_math = 0; // FVAD_NN_MATH_F32: the reference's arithmetic (NSNet2.zig:220, ORT CPU EP) at every batch size
+    fvad::Tuning tune;
+    std::string last_nn_path; // what the last NSNet2 pass ran ("f32: panel_gemm3 + gru_rec3<12>", ...)
     // timing
     bool timing = false;
     std::vector<fvad::KernelTime> times;
@@ -166,6 +184,8 @@ int hip_fail(const fvad_ctx* ctx, hipError_t e, const char* what);
     } while (0)
 
 int upload_model(fvad_ctx* ctx);
+// FVAD_NN_MATH_F32 / FVAD_NN_MATH_F16X3: what run_nn uses on this context with the loaded model, at every batch size
+int nn_math_effective(const fvad_ctx* ctx);
 int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T);
 int ensure_gru_ws(fvad_ctx* ctx);
 // tables of the n-point VAD FFT (n = 512 / 1024 / 2048), cached per context

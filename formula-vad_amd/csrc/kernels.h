@@ -95,10 +95,14 @@ int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, f
 // (kernels_ws.hip).  hx: fvad_gru_ws_exchange_floats(n_seq_pad) floats; flags: 256 zeroed words per launch;
 // err: one zeroed word shared by the launches of a network pass.  Returns -1 when the batch is too large.
 void fvad_launch_zero_words(unsigned* p, int n, hipStream_t stream);
+// *counter += (*word != 0): how the context counts the network passes in which gru_ws gave up (a kernel node, so it
+// also works inside a captured graph)
+void fvad_launch_count_word(unsigned long long* counter, const unsigned* word, hipStream_t stream);
 bool fvad_gru_ws_shape(long n_seq_pad, int n_cu, int* RT, int* G);
 size_t fvad_gru_ws_exchange_floats(long n_seq_pad);
 int fvad_launch_gru_ws(const float* gi, const float* R2frag, const float* bR, float* hout, float* hx, unsigned* flags,
-                       unsigned* err, long n_seq_pad, int T, int n_cu, int tile_major, hipStream_t stream);
+                       unsigned* err, long n_seq_pad, int T, int n_cu, int tile_major, unsigned long long spin_ticks,
+                       hipStream_t stream);
 int fvad_launch_gru_rec3(const float* gi, const float* R2frag, const float* bR, float* hout,
                          long n_seq_pad, int T, int waves, hipStream_t stream);
 

@@ -697,25 +697,28 @@ __global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __rest
 
         for (int J = wave; J < GRU_J; J += WAVES) {
             const int Jn = (J + WAVES < GRU_J) ? J + WAVES : wave; // this wave's next tile; after the last one, its first tile of the next step
-            f32x4 az = (f32x4){0.f, 0.f, 0.f, 0.f};
-            f32x4 ar = az, an = az;
+            // two accumulation chains per gate (even / odd super-steps), summed at the end: the order of
+            // gru_ws_kernel, whose fallback this kernel is -- both give the same bits
+            f32x4 az[2], ar[2], an[2];
+            az[0] = az[1] = ar[0] = ar[1] = an[0] = an[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 giz, gir, gin, hp, bz, br, bn;
 #pragma unroll
             for (int S = 0; S < GRU_J; ++S) {
                 const int k = S % D;
+                const int c = S & 1;
                 const f32x4 hv = hreg[S];
-                az = MFMA16(wz[k].x, hv.x, az);
-                ar = MFMA16(wr[k].x, hv.x, ar);
-                an = MFMA16(wn[k].x, hv.x, an);
-                az = MFMA16(wz[k].y, hv.y, az);
-                ar = MFMA16(wr[k].y, hv.y, ar);
-                an = MFMA16(wn[k].y, hv.y, an);
-                az = MFMA16(wz[k].z, hv.z, az);
-                ar = MFMA16(wr[k].z, hv.z, ar);
-                an = MFMA16(wn[k].z, hv.z, an);
-                az = MFMA16(wz[k].w, hv.w, az);
-                ar = MFMA16(wr[k].w, hv.w, ar);
-                an = MFMA16(wn[k].w, hv.w, an);
+                az[c] = MFMA16(wz[k].x, hv.x, az[c]);
+                ar[c] = MFMA16(wr[k].x, hv.x, ar[c]);
+                an[c] = MFMA16(wn[k].x, hv.x, an[c]);
+                az[c] = MFMA16(wz[k].y, hv.y, az[c]);
+                ar[c] = MFMA16(wr[k].y, hv.y, ar[c]);
+                an[c] = MFMA16(wn[k].y, hv.y, an[c]);
+                az[c] = MFMA16(wz[k].z, hv.z, az[c]);
+                ar[c] = MFMA16(wr[k].z, hv.z, ar[c]);
+                an[c] = MFMA16(wn[k].z, hv.z, an[c]);
+                az[c] = MFMA16(wz[k].w, hv.w, az[c]);
+                ar[c] = MFMA16(wr[k].w, hv.w, ar[c]);
+                an[c] = MFMA16(wn[k].w, hv.w, an[c]);
                 // refill the slot with the super-step D ahead; past the end of this tile that is the
                 // next tile's super-step S + D - 25
                 if (S + D < GRU_J) {
@@ -737,12 +740,13 @@ __global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __rest
                     hp = hcur[J * 64];
                 }
             }
+            const f32x4 sz = az[0] + az[1], sr = ar[0] + ar[1], sn = an[0] + an[1];
             f32x4 h;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float z = fast_sigmoid(giz[r] + (az[r] + bz[r]));
-                const float rr = fast_sigmoid(gir[r] + (ar[r] + br[r]));
-                const float n = fast_tanh(gin[r] + rr * (an[r] + bn[r]));
+                const float z = fast_sigmoid(giz[r] + (sz[r] + bz[r]));
+                const float rr = fast_sigmoid(gir[r] + (sr[r] + br[r]));
+                const float n = fast_tanh(gin[r] + rr * (sn[r] + bn[r]));
                 h[r] = (1.0f - z) * n + z * hp[r];
             }
             *reinterpret_cast<f32x4*>(h_out + 16 * J) = h;

@@ -35,7 +35,6 @@
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr unsigned long long WS_SPIN_TICKS = 25000000ull; // s_memrealtime runs at 100 MHz: 0.25 s
 constexpr int WS_AUX_SC1 = 16;                            // buffer cache-policy bit: sc1 (system-coherent level 1)
 
 template <int OWN>
@@ -242,6 +241,14 @@ __global__ void zero_words_kernel(unsigned* p, int n)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0u;
 }
+__global__ void count_word_kernel(unsigned long long* counter, const unsigned* word)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0 && *word != 0u) *counter += 1ull;
+}
+void fvad_launch_count_word(unsigned long long* counter, const unsigned* word, hipStream_t stream)
+{
+    hipLaunchKernelGGL(count_word_kernel, dim3(1), dim3(64), 0, stream, counter, word);
+}
 void fvad_launch_zero_words(unsigned* p, int n, hipStream_t stream)
 {
     hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, n);
@@ -265,12 +272,12 @@ bool fvad_gru_ws_shape(long n_seq_pad, int n_cu, int* RT, int* G)
 size_t fvad_gru_ws_exchange_floats(long n_seq_pad) { return (size_t)2 * (size_t)(n_seq_pad / 16) * GRU_J * 256; }
 
 int fvad_launch_gru_ws(const float* gi, const float* R2frag, const float* bR, float* hout, float* hx, unsigned* flags,
-                       unsigned* err, long n_seq_pad, int T, int n_cu, int tile_major, hipStream_t stream)
+                       unsigned* err, long n_seq_pad, int T, int n_cu, int tile_major, unsigned long long spin_ticks,
+                       hipStream_t stream)
 {
     const int gi_js = tile_major ? 48 : 16, gi_gs = tile_major ? 16 : GRU_H;
-    // FVAD_WS_SPIN_TICKS (100 MHz ticks) overrides the spin deadline: 0 makes every wait that does not succeed at
-    // once give up, which is how the tests drive the gru_lat fallback behind this kernel
-    static const unsigned long long spin_ticks = [] { const char* e = getenv("FVAD_WS_SPIN_TICKS"); return e ? strtoull(e, nullptr, 10) : WS_SPIN_TICKS; }();
+    // spin_ticks (100 MHz ticks; context option ws_spin_ticks, default 0.25 s): 0 makes every wait that does not
+    // succeed at once give up, which is how the tests drive the gru_lat fallback behind this kernel
     int RT = 0, G = 0;
     if (!fvad_gru_ws_shape(n_seq_pad, n_cu, &RT, &G)) return -1;
     const int n_rt = (int)(n_seq_pad / 16);

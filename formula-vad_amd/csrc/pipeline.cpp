@@ -370,6 +370,11 @@ int fvad_pipeline_create(fvad_ctx* ctx, const fvad_pipeline_config* cfg, const f
     if (!(cfg->fft_size == 512 || cfg->fft_size == 1024 || cfg->fft_size == 2048))
         return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "the VAD-side kernel exists for fft_size 512, 1024 (the reference default) and 2048");
     if (cfg->n_channels == 0) return FVAD_ERR_INVALID_ARGUMENT;
+    // pushSamples writes buffer_length / 2 samples per step (AudioPipeline.zig:121-140): below 2 the step is 0 and its
+    // loop never ends, and a ring shorter than one 24000-sample chunk cannot hand VADPipeline.collectInputStep its
+    // slice (MultiRingBuffer.readSlice fails, MultiRingBuffer.zig:175-183)
+    if (cfg->buffer_length && cfg->buffer_length < fvad_nsnet2_chunk_size(cfg->sample_rate))
+        return set_err(ctx, FVAD_ERR_OUT_OF_RANGE, "buffer_length must be 0 (default: 10 s) or at least one 24000-sample chunk");
     if (!ctx->dm.loaded) return set_err(ctx, FVAD_ERR_NO_MODEL, "load the NSNet2 model into the context first");
     auto p = std::unique_ptr<fvad_pipeline>(new (std::nothrow) fvad_pipeline());
     if (!p) return FVAD_ERR_ALLOC_FAILED;

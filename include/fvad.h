@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FVAD_ABI_VERSION 2
+#define FVAD_ABI_VERSION 3
 
 /* ------------------------------------------------------------------ status codes */
 enum {
@@ -197,7 +197,8 @@ void fvad_lane_state_destroy(fvad_lane_state *s);
  * 160-sample input hop, the 4 warm-up feature rows, the overlap-add tail and the upsampler's last sample
  * (NSNet2.zig:27-33,188-203), all functions of the previous chunk and of the 4 last frames of the one before.  A
  * lane that starts TWO chunks early from zero history (this call, sample_index = 24000 * (c0 - 2)) is therefore
- * bit-identical to the unsplit stream from chunk c0 on; the VAD FFT's frame grid stays anchored at sample 0
+ * bit-identical to the unsplit stream from chunk c0 on -- when both runs use the same kernel family (see
+ * fvad_ctx_set_option: "reproducible"; ~1e-6 apart otherwise) --; the VAD FFT's frame grid stays anchored at sample 0
  * (first_frame_index of the next fvad_engine_run says where the lane's first frame starts).  The caller drops
  * the two warm-up chunks and the frames that start before 24000 * c0.  sample_index: a multiple of 24000. */
 int fvad_lane_state_seek(fvad_lane_state *s, uint64_t sample_index, size_t fft_size /* 0 = 1024 */);
@@ -241,6 +242,11 @@ typedef struct {
                                 records on fvad_ctx_stream); the next call may be made at once -- descriptor and job
                                 tables are double-buffered -- so a caller can keep one batch queued behind the running
                                 one.  0 (default) = return when the work has completed */
+    int32_t use_graph;       /* fvad_engine_enqueue_device* only: 1 = the call's launch sequence (K1, the NSNet2 kernels,
+                                K3 per launch, then K4) is captured into a hipGraph the first time and replayed while the
+                                arguments, the model and the workspace stay the same -- the "hipGraph-captured steady-state
+                                frame loop" of a long corpus processed batch after batch through the same buffers.  Results
+                                are bit-identical to direct launches.  The call returns when the work has completed. */
 } fvad_engine_opts;
 void fvad_engine_opts_default(fvad_engine_opts *o);
 
@@ -264,16 +270,42 @@ int fvad_engine_enqueue_device_i16(fvad_ctx *ctx, const int16_t *d_pcm16, size_t
  * Replaces onnx_instance.run() (NSNet2.zig:220) for n_seq independent sequences. */
 int fvad_nsnet2_forward(fvad_ctx *ctx, const float *features, size_t n_seq, size_t T,
                         float *gains);
-/* Arithmetic of the NSNet2 matrix products for large batches (>= 2048 sequences per launch):
- *   FVAD_NN_MATH_F16X3 (default): every f32 operand as two f16 pieces of a power-of-two scaled value, three f16
- *     MFMAs with f32 accumulation per product (kernels_h3.hip) -- 22 significand bits per operand, measured against
- *     float64 as close as the f32 form (tests), at 5.3 x the f32 matrix rate;
- *   FVAD_NN_MATH_F32: v_mfma_f32_16x16x4_f32 throughout (kernels_nn.hip), each output a k-ordered chain of f32 fmas
- *     like the reference's ONNX Runtime CPU kernels (NSNet2.zig:220).
- * Small batches always use the f32 kernels.  The environment variable FVAD_NN_MATH=f32|f16x3 overrides the
- * setting (tuning aid).  Returns the previous mode, or a negative status. */
+/* Arithmetic of the NSNet2 matrix products -- a property of the CONTEXT (and of the loaded model), never of a
+ * launch's size: every launch of a context, large or small, uses the same one.
+ *   FVAD_NN_MATH_F32 (default): v_mfma_f32_16x16x4_f32 throughout (kernels_nn.hip, kernels_ws.hip): f32 operands,
+ *     f32 accumulation, each output a k-ordered chain of f32 fmas -- the arithmetic of the reference's ONNX Runtime
+ *     CPU kernels (NSNet2.zig:220);
+ *   FVAD_NN_MATH_F16X3 (opt-in, an EMULATION that is narrower than f32): every f32 operand as two f16 pieces of a
+ *     power-of-two scaled value (22 significand bits, f32 has 24), three f16 MFMAs with f32 accumulation per product
+ *     (kernels_h3.hip), batches padded to 128 sequences.  Measured against float64 as close as the f32 kernels on the
+ *     models tried (tests), 2.1 x their speed at saturating batches; differs from them by ~1e-6 in the gains.  A
+ *     model whose weights are not finite or whose l1 activation bounds exceed 2^17 is not eligible and keeps f32.
+ * fvad_ctx_set_nn_math returns the previous setting or a negative status.  fvad_ctx_nn_math_effective returns what
+ * the context actually uses with the model it has loaded (the request, demoted to F32 for an ineligible model or
+ * while an f32 kernel variant is forced through fvad_ctx_set_option); fvad_ctx_last_nn_path names the kernels the
+ * last NSNet2 pass ran, e.g. "f32: panel_gemm3 (fc1 folded) + gru_rec3<12>". */
 enum { FVAD_NN_MATH_F32 = 0, FVAD_NN_MATH_F16X3 = 1 };
 int fvad_ctx_set_nn_math(fvad_ctx *ctx, int mode);
+int fvad_ctx_nn_math_effective(const fvad_ctx *ctx);
+const char *fvad_ctx_last_nn_path(const fvad_ctx *ctx);
+/* Bit-reproducibility.  Within one kernel family a chunk's results do not depend on where in a batch it sits, on how
+ * lanes and chunks are split over launches, or on the launch size.  With FVAD_NN_MATH_F32 the engine picks the
+ * family by batch size (weight-stationary / low-latency kernels and an unfolded fc1 below 2048 chunks per launch,
+ * the persistent GEMM with fc1 folded into the first GRU's input projection above): the families agree to ~1e-6,
+ * not bit for bit.  The option "reproducible" = "1" makes every launch use the large-batch family (small launches
+ * are padded to 128 sequences and lose their low-latency kernels), so that a stream pushed in any pieces, split
+ * over any number of launches or time-split over ranks gives the same bits.  FVAD_NN_MATH_F16X3 has one family.
+ *
+ * Testing / tuning aids, none needed in production: name = "reproducible" | "nn_math" ("f32" | "f16x3": overrides
+ * fvad_ctx_set_nn_math) | "gru_kernel" ("v3w12" | "v3w8" | "v3w4" | "v4w8" | "v5w0") | "gemm_kernel" ("v1" | "v3" |
+ * "v3nofold") | "h3_waves" ("8" | "12") | "max_chunks" | "copy_threads" | "no_pipeline" | "trace_kernels" |
+ * "ws_spin_ticks"; value NULL or "" restores the default.  The environment variables FVAD_<NAME> are read ONCE, by
+ * fvad_ctx_create, as initial values (a bad value fails the creation); the data path never reads the environment. */
+int fvad_ctx_set_option(fvad_ctx *ctx, const char *name, const char *value);
+/* Network passes in which the weight-stationary small-batch recurrence (gru_ws_kernel) gave up waiting for a peer
+ * workgroup -- the chip was shared with another process -- and the low-latency kernel redid the GRU layers (same
+ * bits: both accumulate in the same order).  Waits for the context's stream. */
+int fvad_ctx_ws_fallbacks(fvad_ctx *ctx, uint64_t *n);
 /* Per-kernel device time of the last fvad_engine_* call (HIP events on the context's stream):
  * names[i]/ms[i] for i < *n.  Enabled by fvad_ctx_enable_timing(ctx, 1). */
 int fvad_ctx_enable_timing(fvad_ctx *ctx, int on);
@@ -393,7 +425,7 @@ typedef struct {                              /* AudioPipeline.Callbacks, AudioP
 typedef struct {
     size_t sample_rate;                       /* AudioPipeline.Config, AudioPipeline.zig:20-26 */
     size_t n_channels;
-    size_t buffer_length;                     /* 0 = sample_rate * 10 (:46) */
+    size_t buffer_length;                     /* 0 = sample_rate * 10 (:46); otherwise >= one 24000-sample chunk */
     int32_t skip_processing;
     size_t fft_size;                          /* VADPipeline.Config.fft_size = 1024 (:21); 512 and 2048 also have kernels */
     fvad_vad_config vad_machine_config;       /* :22 */
@@ -456,7 +488,9 @@ int fvad_stats_aggregate(const fvad_single_stats *stats, size_t n, fvad_aggregat
  * instances (src/simulator.zig:221-232) in front of report_generator.zig:48-68: every rank hands in the
  * SingleStats of its streams, every rank receives all n_streams of them in PLAN order (stream id = index in
  * the plan), ready for fvad_stats_aggregate -- bit-identical to a single-process run.  Transport: one
- * ncclAllGather over RCCL / xGMI (RCCL is dlopen'ed on first use).  Bootstrap like NCCL's own: rank 0 makes
+ * ncclAllGather over RCCL / xGMI (RCCL is dlopen'ed on first use), behind a header all-gather of {n_streams, local
+ * status}: n_streams must be the same on every rank, and a rank whose arguments are bad still takes part, so every
+ * rank returns an error instead of some of them waiting in the collective.  Bootstrap like NCCL's own: rank 0 makes
  * the 128-byte id and hands it to the other ranks by whatever channel the host has (file, socket, env). */
 #define FVAD_COMM_ID_BYTES 128
 typedef struct fvad_comm fvad_comm;

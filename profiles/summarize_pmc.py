@@ -42,7 +42,30 @@ if os.path.exists(mf):
         gui = mean(v["GRBM_GUI_ACTIVE"]) / 8
         out[k]["clock_GHz"] = gui / mean(v["ns"])
         out[k]["mfma_busy_frac"] = mean(v["SQ_VALU_MFMA_BUSY_CYCLES"]) / (gui * 1024)
-json.dump({"chunks_per_launch": chunks, "kernels": out}, open(os.path.join(here, f"{tag}_pmc_summary.json"), "w"), indent=1)
+# provenance: bench.py prints these next to roofline.traffic and flags a profile whose kernel sources differ from
+# the build it is running (arguments 3 / 4 override: the commit and digest of the build the passes were run on)
+import datetime
+import hashlib
+import subprocess
+
+
+def _digest():
+    h = hashlib.sha256()
+    d = os.path.join(here, "..", "formula-vad_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+try:
+    commit = sys.argv[3] if len(sys.argv) > 3 else subprocess.check_output(["git", "-C", here, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    commit = None
+json.dump({"chunks_per_launch": chunks, "recorded_at": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%M:%SZ"),
+           "source_commit": commit, "kernel_source_digest": sys.argv[4] if len(sys.argv) > 4 else _digest(), "kernels": out},
+          open(os.path.join(here, f"{tag}_pmc_summary.json"), "w"), indent=1)
 for k, v in out.items():
     print(f"{k:45s} {v['hbm_bytes_per_launch'] / 1e9:7.2f} GB/launch corrected, {v['hbm_bytes_per_launch_raw_counters'] / 1e9:7.2f} raw, "
           f"mfma busy {v.get('mfma_busy_frac', 0):.3f}, clock {v.get('clock_GHz', 0):.2f} GHz")

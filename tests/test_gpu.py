@@ -194,22 +194,32 @@ def test_nsnet2_forward_matches_oracle(fv, gpu_ctx, weights7):
     assert np.array_equal(g, g_rev[::-1])
 
 
-@pytest.mark.parametrize("env", [
-    {}, {"FVAD_GRU_KERNEL": "v3w12"}, {"FVAD_GRU_KERNEL": "v3w8"}, {"FVAD_GRU_KERNEL": "v3w4"},
-    {"FVAD_GEMM_KERNEL": "v3nofold"}, {"FVAD_GEMM_KERNEL": "v1"}, {"FVAD_GRU_KERNEL": "v4w8"},
-    {"FVAD_GRU_KERNEL": "v5w0"}, {"FVAD_NN_MATH": "f32"}, {"FVAD_NN_MATH": "f16x3", "FVAD_H3_WAVES": "8"},
-    {"FVAD_NN_MATH": "f16x3", "FVAD_H3_WAVES": "12"}, {"FVAD_NN_MATH": "f32", "FVAD_GRU_KERNEL": "v3w12"},
+@pytest.mark.parametrize("opts", [
+    {}, {"gru_kernel": "v3w12"}, {"gru_kernel": "v3w8"}, {"gru_kernel": "v3w4"},
+    {"gemm_kernel": "v3nofold"}, {"gemm_kernel": "v1"}, {"gru_kernel": "v4w8"},
+    {"gru_kernel": "v5w0"}, {"nn_math": "f32"}, {"nn_math": "f16x3", "h3_waves": "8"},
+    {"nn_math": "f16x3", "h3_waves": "12"}, {"nn_math": "f16x3", "gru_kernel": "v3w12"}, {"reproducible": "1"},
 ], ids=lambda e: "-".join(e.values()) or "default")
-def test_nsnet2_large_batch_kernels_match_oracle(fv, gpu_ctx, weights7, env, monkeypatch):
+def test_nsnet2_large_batch_kernels_match_oracle(fv, gpu_ctx, weights7, opts):
     # 2100 sequences take the large-batch path (LDS-DMA GEMMs, persistent GEMM, multi-wave recurrence);
-    # every kernel variant the engine can pick for other batch sizes is forced in turn and checked
-    # against the oracle on a sample of sequences spread over the batch (first, last, padding edge)
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    # every kernel variant the engine can pick for other batch sizes is forced in turn (fvad_ctx_set_option) and
+    # checked against the oracle on a sample of sequences spread over the batch (first, last, padding edge)
+    env = opts
     rng = np.random.default_rng(11)
     f = rng.uniform(-11, 2, (2100, 54, 161)).astype(np.float32)
     f[::7, :2] = 0.0
-    g = gpu_ctx.nsnet2_forward(f)
+    with gpu_ctx.options(**opts):
+        # the arithmetic is a property of the context: f16x3 only when asked for and no f32 variant is forced
+        want = "f16x3" if opts.get("nn_math") == "f16x3" and "gru_kernel" not in opts else "f32"
+        assert gpu_ctx.nn_math_effective() == want
+        g = gpu_ctx.nsnet2_forward(f)
+        path = gpu_ctx.last_nn_path()
+        assert path.startswith(want + ":"), path
+        if "gru_kernel" in opts:
+            assert {"v3w12": "gru_rec3<12>", "v3w8": "gru_rec3<8>", "v3w4": "gru_rec3<4>", "v4w8": "gru_lat", "v5w0": "gru_ws"}[opts["gru_kernel"]] in path, path
+        if "h3_waves" in opts:
+            assert f"gru_rec_h3<{opts['h3_waves']}>" in path, path
+    assert gpu_ctx.nn_math_effective() == "f32"     # options restored: the default arithmetic is the reference's
     pick = [0, 1, 15, 16, 127, 128, 191, 192, 1023, 1500, 2047, 2048, 2098, 2099]
     ref = np.stack([orc.nsnet2_forward(weights7, f[i]) for i in pick])
     assert_rel(g[pick], ref, 1e-4, floor=1e-2, what=f"gains large batch {env}")
@@ -229,10 +239,12 @@ def test_f16x3_products_are_as_close_to_float64_as_f32(fv, weights7):
     def run(w, mode):
         ctx = fv.Context(0)
         ctx.load_weights(w)
-        assert ctx.set_nn_math(mode) == "f16x3"    # the default
+        assert ctx.set_nn_math(mode) == "f32"      # the default is the reference's arithmetic
+        eff = ctx.nn_math_effective()
         g = ctx.nsnet2_forward(fb)
+        assert ctx.last_nn_path().startswith(eff + ":")
         ctx.close()
-        return g
+        return g, eff
 
     for scale in (1.0, 37.3, 1.0 / 64.0, 1.0e5):       # 1e5: fc2's l1 bound leaves the f16x3 range -> the f32 kernels run
         w = {k: v.copy() for k, v in weights7.items()}
@@ -242,7 +254,9 @@ def test_f16x3_products_are_as_close_to_float64_as_f32(fv, weights7):
         g64 = np.stack([_nsnet2_float64(w, s) for s in f])
         g_orc = np.stack([orc.nsnet2_forward(w, s) for s in f])
         e_orc = np.abs(g_orc - g64).max()
-        g_h3, g_f32 = run(w, "f16x3"), run(w, "f32")
+        (g_h3, eff_h3), (g_f32, eff_f32) = run(w, "f16x3"), run(w, "f32")
+        # a model whose l1 bounds leave the f16x3 range is demoted, and the context says so
+        assert eff_f32 == "f32" and eff_h3 == ("f32" if scale == 1.0e5 else "f16x3")
         e_h3 = max(np.abs(g_h3[:6] - g64).max(), np.abs(g_h3[-6:] - g64).max())
         e_f32 = max(np.abs(g_f32[:6] - g64).max(), np.abs(g_f32[-6:] - g64).max())
         assert e_h3 <= max(2 * e_orc, 2e-6), (scale, e_h3, e_f32, e_orc)
@@ -254,14 +268,16 @@ def test_f16x3_products_are_as_close_to_float64_as_f32(fv, weights7):
     c.close()
 
 
-@pytest.mark.parametrize("n_seq,T", [(2304, 7), (2176, 20), (4000, 54)])
+@pytest.mark.parametrize("n_seq,T", [(2304, 7), (2176, 20), (4000, 54), (3, 54), (130, 54)])
 def test_f16x3_other_sequence_lengths_and_paddings(fv, gpu_ctx, weights7, n_seq, T):
     # the tiled layouts of the f16x3 path group 16 sequences per time step: other sequence lengths than the
     # pipeline's 54 rows, a batch that pads to 128- rather than 192-sequence workgroups (2176), and one that is not
     # a multiple of anything (4000) must come out the same as through the oracle
     rng = np.random.default_rng(100 + T)
     f = rng.uniform(-11, 2, (n_seq, T, 161)).astype(np.float32)
-    g = gpu_ctx.nsnet2_forward(f)
+    with gpu_ctx.options(nn_math="f16x3"):
+        g = gpu_ctx.nsnet2_forward(f)
+        assert gpu_ctx.last_nn_path().startswith("f16x3:")
     pick = [0, 15, 16, 17, n_seq // 2, n_seq - 17, n_seq - 1]
     ref = np.stack([orc.nsnet2_forward(weights7, f[i]) for i in pick])
     assert_rel(g[pick], ref, 1e-4, floor=1e-2, what=f"gains n_seq={n_seq} T={T}")
@@ -274,10 +290,14 @@ def test_f16x3_large_batch_is_deterministic_and_position_independent(fv, gpu_ctx
     rng = np.random.default_rng(5)
     base = rng.uniform(-11, 2, (192, 54, 161)).astype(np.float32)
     f = np.tile(base, (128, 1, 1))
-    g0 = gpu_ctx.nsnet2_forward(f)
-    assert np.array_equal(g0.reshape(128, 192, 54, 161), np.broadcast_to(g0[:192], (128, 192, 54, 161)))
-    for _ in range(2):
-        assert np.array_equal(gpu_ctx.nsnet2_forward(f), g0)
+    with gpu_ctx.options(nn_math="f16x3"):
+        g0 = gpu_ctx.nsnet2_forward(f)
+        assert gpu_ctx.last_nn_path().startswith("f16x3:")
+        assert np.array_equal(g0.reshape(128, 192, 54, 161), np.broadcast_to(g0[:192], (128, 192, 54, 161)))
+        for _ in range(2):
+            assert np.array_equal(gpu_ctx.nsnet2_forward(f), g0)
+        # ... and independent of the batch size: the same sequences alone, in a 128-sequence launch
+        assert np.array_equal(gpu_ctx.nsnet2_forward(base[:5].copy()), g0[:5])
 
 
 def test_get_weights_roundtrip(fv, gpu_ctx, weights7):
@@ -415,8 +435,8 @@ def test_engine_host_buffer_pipelining_is_invisible(fv, gpu_ctx, pkg, monkeypatc
         lanes.append(np.roll(base[0], 4801 * i)[:n].copy())
     assert sum(x.nbytes for x in lanes) > (64 << 20)
     a = gpu_ctx.engine_run(lanes, want_denoised=True)
-    monkeypatch.setenv("FVAD_NO_PIPELINE", "1")
-    b = gpu_ctx.engine_run(lanes, want_denoised=True)
+    with gpu_ctx.options(no_pipeline="1"):
+        b = gpu_ctx.engine_run(lanes, want_denoised=True)
     for x, y in zip(a, b):
         assert x["n_chunks"] == y["n_chunks"] and x["n_fft_frames"] == y["n_fft_frames"]
         assert np.array_equal(x["denoised"], y["denoised"])
@@ -474,6 +494,7 @@ def test_two_contexts_on_two_threads(fv, weights7, pkg):
 
 _GRAPH_SCRIPT = r"""
 import os, sys
+import ctypes as C
 import numpy as np
 import torch                                   # first: this process must use one HIP runtime (torch's)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -485,6 +506,7 @@ ctx = fv.Context(0)
 ctx.load_synth(7)
 dev = torch.device("cuda", 0)
 
+GRAPH = False
 def run(d_pcm, n_samples, bufs=None):
     n_l = d_pcm.shape[0]
     n_ch = n_samples // 24000
@@ -493,8 +515,11 @@ def run(d_pcm, n_samples, bufs=None):
                 torch.zeros((n_l, n_ch), dtype=torch.float32, device=dev),
                 torch.zeros((n_l, n_ch * 24000), dtype=torch.float32, device=dev))
     band, rms, den = bufs
+    opts = fv.EngineOpts()
+    L.fvad_engine_opts_default(C.byref(opts))
+    opts.use_graph = 1 if GRAPH else 0
     fv.check(L.fvad_engine_enqueue_device(ctx.h, d_pcm.data_ptr(), n_l, d_pcm.stride(0), n_samples,
-                                          den.data_ptr(), band.data_ptr(), rms.data_ptr(), None), "enqueue", ctx.h)
+                                          den.data_ptr(), band.data_ptr(), rms.data_ptr(), C.byref(opts)), "enqueue", ctx.h)
     ctx.synchronize()
     return band.cpu().numpy(), rms.cpu().numpy(), den.cpu().numpy()
 
@@ -503,7 +528,7 @@ b, _ = pkg.synth.make_stream(8.0, seed=72)
 xa = torch.from_numpy(np.stack([np.roll(a[0], 997 * i) for i in range(6)])[:, : 16 * 24000].copy()).to(dev)
 xb = torch.from_numpy(np.stack([np.roll(b[0], 991 * i) for i in range(6)])[:, : 16 * 24000].copy()).to(dev)
 ref_a, ref_b, ref_short = run(xa, 16 * 24000), run(xb, 16 * 24000), run(xa, 4 * 24000)
-os.environ["FVAD_GRAPH"] = "1"
+GRAPH = True
 bufs = (torch.zeros((6, 16 * 24000 // 1024), dtype=torch.float32, device=dev),
         torch.zeros((6, 16), dtype=torch.float32, device=dev),
         torch.zeros((6, 16 * 24000), dtype=torch.float32, device=dev))
@@ -522,10 +547,10 @@ x.copy_(xa); torch.cuda.synchronize()
 assert all(np.array_equal(u, v) for u, v in zip(run(x, 16 * 24000, bufs), ref_a))      # cached again
 ctx.load_synth(8)
 got8 = run(x, 16 * 24000, bufs)
-del os.environ["FVAD_GRAPH"]
+GRAPH = False
 ref8 = run(xa, 16 * 24000)
 assert all(np.array_equal(u, v) for u, v in zip(got8, ref8)) and not np.array_equal(ref8[2], ref_a[2])
-os.environ["FVAD_GRAPH"] = "1"
+GRAPH = True
 assert all(np.array_equal(u, v) for u, v in zip(run(x, 16 * 24000, bufs), ref8))       # capture with seed 8
 many = [a[0][: 2 * 24000].copy() for _ in range(40)]                                     # 80 scratch carries, 40 jobs
 ctx.engine_run(many)
@@ -536,7 +561,7 @@ print("GRAPH_OK")
 
 
 def test_graph_replay_equals_direct_launches():
-    # FVAD_GRAPH=1: the device-resident entry point captures its launch sequence into a hipGraph and replays
+    # fvad_engine_opts.use_graph: the device-resident entry point captures its launch sequence into a hipGraph and replays
     # it while arguments and workspace are unchanged.  Same results as launching directly, also after the
     # input buffer's contents change and after a different shape invalidates the cache.  Device buffers come
     # from torch, which has to initialise HIP before the library does: a process of its own.
@@ -1038,6 +1063,106 @@ def test_pcm16_input_equals_host_converted_f32(fv, gpu_ctx, pkg):
         gpu_ctx.device_free(d)
 
 
+# ------------------------------------------------------------------ the arithmetic seam (2048 chunks per launch)
+def _segments_and_margin(fv, band):
+    m = fv.VadMachine()
+    fv.vad_run_many([m], [band[:, None]], [np.ones(band.shape[0], np.float32)], n_threads=1)
+    segs = [(s[0], s[1]) for s in m.segments()]
+    margin = m.audit()[0]
+    m.close()
+    return segs, margin
+
+
+def test_launch_size_does_not_change_the_arithmetic(fv, gpu_ctx, pkg):
+    # 16 streams x 72 s = 2304 chunks, three ways: one launch (above the 2048-chunk line where the f32 engine
+    # changes kernel family), launches of <= 1024 chunks (below it), and two pushes through lane states.
+    #   * f16x3 and f32 + "reproducible": one family at every size -> the three runs agree bit for bit;
+    #   * f32 default: the families differ by round-off only (fc1 folded or not, accumulation order): band sums
+    #     within 1e-5, segment lists identical, and every stream's decision margin (the audit: smallest
+    #     |short_term - threshold| / threshold over its frames) more than 10 x the largest band-sum difference;
+    #   * f16x3 against f32: the same two conditions (the emulation is ~1e-6 away in the gains).
+    n_ch = 144
+    streams = [pkg.synth.make_stream(72.5, seed=9100 + i)[0][0][: n_ch * 24000].copy() for i in range(16)]
+
+    def one(**kw):
+        out = gpu_ctx.engine_run(streams, want_denoised=True, **kw)
+        return gpu_ctx.last_nn_path(), out
+
+    def pushes():
+        sts = [gpu_ctx.lane_state() for _ in streams]
+        a = gpu_ctx.engine_run([x[: 70 * 24000] for x in streams], want_denoised=True, states=sts)
+        b = gpu_ctx.engine_run([x[70 * 24000:] for x in streams], want_denoised=True, states=sts)
+        for st in sts:
+            fv.lib().fvad_lane_state_destroy(st)
+        return [{k: np.concatenate([u[k], v[k]]) for k in ("denoised", "band_sum", "chunk_rms")} for u, v in zip(a, b)]
+
+    def same_bits(x, y, what):
+        for u, v in zip(x, y):
+            for k in ("denoised", "band_sum", "chunk_rms"):
+                assert np.array_equal(u[k], v[k]), (what, k)
+
+    def close_and_same_segments(x, y, what):
+        worst = 0.0
+        for u, v in zip(x, y):
+            d = float((np.abs(u["band_sum"].astype(np.float64) - v["band_sum"]) / np.abs(v["band_sum"])).max())
+            worst = max(worst, d)
+            su, mu = _segments_and_margin(fv, u["band_sum"])
+            sv, mv = _segments_and_margin(fv, v["band_sum"])
+            assert su == sv and len(su) >= 1, what
+            assert min(mu, mv) > 10 * d, (what, mu, mv, d)
+            peak = np.abs(v["denoised"]).max()
+            assert np.abs(u["denoised"].astype(np.float64) - v["denoised"]).max() <= 2e-5 * peak, what
+        assert worst <= 1e-5, (what, worst)
+        return worst
+
+    res = {}
+    for math in ("f32", "f16x3"):
+        with gpu_ctx.options(nn_math=math):
+            assert gpu_ctx.nn_math_effective() == math
+            p1, whole = one()
+            p2, split = one(max_chunks_per_launch=1024)
+            two = pushes()
+            assert p1.startswith(math + ":") and p2.startswith(math + ":")
+            if math == "f16x3":
+                same_bits(whole, split, "f16x3 launch split")
+                same_bits(whole, two, "f16x3 two pushes")
+            else:
+                assert "panel_gemm3" in p1 and "panel_gemm3" not in p2, (p1, p2)   # two kernel families
+                d = close_and_same_segments(split, whole, "f32 launch split")
+                assert d > 0, "the families were expected to differ in the last bits"
+                close_and_same_segments(two, whole, "f32 two pushes")
+                with gpu_ctx.options(reproducible="1"):
+                    q1, whole_r = one()
+                    q2, split_r = one(max_chunks_per_launch=1024)
+                    two_r = pushes()
+                    assert "panel_gemm3" in q1 and "panel_gemm3" in q2, (q1, q2)
+                    same_bits(whole_r, whole, "reproducible == default at a large launch")
+                    same_bits(whole_r, split_r, "reproducible launch split")
+                    same_bits(whole_r, two_r, "reproducible two pushes")
+            res[math] = whole
+    close_and_same_segments(res["f16x3"], res["f32"], "f16x3 against f32")
+
+
+def test_time_split_across_the_family_line_needs_reproducible_mode(fv, gpu_ctx, pkg):
+    # one stream of 2100 chunks runs unsplit above the 2048-chunk line and as two ranks' shares below it: bit for
+    # bit equal with the option "reproducible" (or with f16x3, which has one family), round-off apart without
+    pcm, _ = pkg.synth.make_stream(60.5, seed=56)
+    x = np.tile(pcm[0][: 120 * 24000], 18)[: 2100 * 24000].copy()
+    for opts in ({"reproducible": "1"}, {"nn_math": "f16x3"}):
+        with gpu_ctx.options(**opts):
+            whole = gpu_ctx.engine_run([x], want_denoised=True)[0]
+            parts = [pkg.shard.run_time_split_rank(gpu_ctx, x, c0, c1) for c0, c1 in pkg.shard.split_stream(2100, 2)]
+        for k in ("denoised", "chunk_rms", "band_sum"):
+            assert np.array_equal(np.concatenate([p[k] for p in parts]), whole[k]), (opts, k)
+    whole = gpu_ctx.engine_run([x], want_denoised=True)[0]
+    parts = [pkg.shard.run_time_split_rank(gpu_ctx, x, c0, c1) for c0, c1 in pkg.shard.split_stream(2100, 2)]
+    band = np.concatenate([p["band_sum"] for p in parts])
+    assert band.shape == whole["band_sum"].shape
+    d = float((np.abs(band.astype(np.float64) - whole["band_sum"]) / np.abs(whole["band_sum"])).max())
+    assert 0 < d <= 1e-5, d
+    assert _segments_and_margin(fv, band)[0] == _segments_and_margin(fv, whole["band_sum"])[0]
+
+
 # ------------------------------------------------------------------ time-split sharding of one stream (config 5)
 @pytest.mark.parametrize("world", [2, 3, 5])
 def test_time_split_of_one_stream_is_bit_identical(fv, gpu_ctx, weights7, pkg, world):
@@ -1114,15 +1239,10 @@ def test_nsnet2_saturated_gates_match_oracle(fv, weights7):
     ref = np.stack([orc.nsnet2_forward(w, f[i]) for i in pick])
     g64 = np.stack([_nsnet2_float64(w, f[i]) for i in pick])
     e_orc = np.abs(ref - g64).max()
-    for env in ({}, {"FVAD_GRU_KERNEL": "v4w8"}, {"FVAD_GRU_KERNEL": "v5w0"}):
-        for k, v in env.items():
-            os.environ[k] = v
-        try:
+    for env in ({}, {"gru_kernel": "v4w8"}, {"gru_kernel": "v5w0"}, {"nn_math": "f16x3"}, {"reproducible": "1"}):
+        with ctx.options(**env):
             g_small = ctx.nsnet2_forward(f[:2])
             g_big = ctx.nsnet2_forward(f)
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
         assert_rel(g_small, ref[:2], 1e-4, floor=1e-2, what=f"saturated gains, small batch {env}")
         assert_rel(g_big[pick], ref, 1e-4, floor=1e-2, what=f"saturated gains, large batch {env}")
         assert np.abs(g_big[pick] - g64).max() <= max(3 * e_orc, 5e-6), (env, np.abs(g_big[pick] - g64).max(), e_orc)
@@ -1211,10 +1331,17 @@ import orc
 ctx = fv.Context(0); ctx.load_synth(7)
 W = ctx.weights()
 f = np.random.default_rng(3).uniform(-11, 2, (100, 54, 161)).astype(np.float32)
-g = ctx.nsnet2_forward(f)                       # FVAD_WS_SPIN_TICKS=0: the waits give up, gru_lat redoes both layers
-os.environ["FVAD_GRU_KERNEL"] = "v4w8"
+good = ctx.nsnet2_forward(f)                    # gru_ws at its normal deadline
+assert "gru_ws" in ctx.last_nn_path() and ctx.ws_fallbacks() == 0
+ctx.set_option("ws_spin_ticks", "0")            # every wait that is not already satisfied gives up: gru_lat redoes both layers
+g = ctx.nsnet2_forward(f)
+assert ctx.ws_fallbacks() == 1, ctx.ws_fallbacks()   # ... and the context counts the pass
+ctx.set_option("ws_spin_ticks", None)
+ctx.set_option("gru_kernel", "v4w8")
 lat = ctx.nsnet2_forward(f)                     # the low-latency kernel directly
+assert "gru_lat" in ctx.last_nn_path()
 assert np.array_equal(g, lat), np.abs(g - lat).max()
+assert np.array_equal(g, good), np.abs(g - good).max()   # both recurrences accumulate in the same order: same bits
 ref = np.stack([orc.nsnet2_forward(W, s) for s in f[:3]])
 assert (np.abs(g[:3] - ref) / np.maximum(np.abs(ref), 1e-2)).max() <= 1e-4
 print("FALLBACK_OK")
@@ -1223,10 +1350,12 @@ print("FALLBACK_OK")
 
 def test_weight_stationary_timeout_falls_back_to_gru_lat():
     # every spin of gru_ws_kernel is bounded; a workgroup that gives up raises the error word and the guarded
-    # gru_lat launch behind it redoes the layer.  With a zero deadline the very first wait that is not already
-    # satisfied gives up: the result must be gru_lat's, bit for bit (its own process: the deadline is read once)
+    # gru_lat launch behind it redoes the layer.  With a zero deadline (option ws_spin_ticks) the very first wait that
+    # is not already satisfied gives up: the result must be gru_lat's -- and, since both kernels accumulate in the same
+    # order, gru_ws's own -- bit for bit, and fvad_ctx_ws_fallbacks counts the pass (its own process: a wedged chip
+    # must not take the test session with it)
     import subprocess
     import sys
-    env = dict(os.environ, FVAD_WS_SPIN_TICKS="0")
+    env = dict(os.environ)
     r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + _WS_FALLBACK_SCRIPT], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stderr[-3000:]

@@ -25,7 +25,7 @@ def test_abi_exports_every_declared_symbol(fv):
     missing = [n for n in sorted(declared) if not hasattr(L, n)]
     assert not missing, f"declared in fvad.h but not exported: {missing}"
     assert declared == set(fv.SIGNATURES), (declared ^ set(fv.SIGNATURES))
-    assert L.fvad_abi_version() == 2
+    assert L.fvad_abi_version() == 3
     assert L.fvad_status_name(-8) == b"InvalidInputLength"
 
 

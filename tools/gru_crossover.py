@@ -15,10 +15,7 @@ for n in sizes:
     f = rng.uniform(-11, 2, (n, 54, 161)).astype(np.float32)
     row = []
     for k in ("v5w0", "v4w8", "v3w4", "v3w8", "v3w12", ""):
-        if k:
-            os.environ["FVAD_GRU_KERNEL"] = k
-        else:
-            os.environ.pop("FVAD_GRU_KERNEL", None)
+        ctx.set_option("gru_kernel", k or None)
         try:
             ctx.nsnet2_forward(f)
             ctx.enable_timing(True)

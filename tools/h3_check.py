@@ -1,4 +1,4 @@
-"""Accuracy and per-kernel time of the f16x3 matrix path (FVAD_NN_MATH=f16x3, kernels_h3.hip) against the f32
+"""Accuracy and per-kernel time of the f16x3 matrix path (fvad_ctx_set_nn_math f16x3, kernels_h3.hip) against the f32
 MFMA path, float64 numpy and the oracle, on fvad_nsnet2_forward with a large batch.
   python tools/h3_check.py [n_seq]
 """
@@ -21,8 +21,7 @@ def main():
     f = np.tile(base, (n_seq // 6, 1, 1))
     out = {}
     for math in ("f32", "f16x3"):
-        os.environ["FVAD_NN_MATH"] = math
-        ctx = fv.Context(0); ctx.load_synth(7)
+        ctx = fv.Context(0); ctx.load_synth(7); ctx.set_nn_math(math)
         g = ctx.nsnet2_forward(f)
         ctx.enable_timing(True)
         g = ctx.nsnet2_forward(f)
