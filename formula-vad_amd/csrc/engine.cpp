@@ -55,12 +55,72 @@ static std::vector<float> padded(const float* b, size_t n, size_t n_pad)
     return v;
 }
 
+// A model whose dimensions are not NSNet2-baseline's: every layer packed for the run-time-sized kernels
+// (panel_gemm_kernel<8, .> column blocks of 128, gru_gen_kernel), widths padded with zero weights and biases.
+static int upload_model_generic(fvad_ctx* ctx)
+{
+    const HostWeights& w = ctx->hw;
+    DeviceModel& m = ctx->dm;
+    DeviceModel::GenDims& g = m.gd;
+    g.F1 = w.n_fc1; g.H = w.n_hidden; g.N2 = w.n_fc2; g.N3 = w.n_fc3;
+    g.J = (g.H + 15) / 16;
+    g.Hp = 16 * g.J;
+    auto pad128 = [](int n) { return (n + 127) / 128 * 128; };
+    g.F1p = pad128(g.F1); g.Gp = pad128(3 * g.Hp); g.N2p = pad128(g.N2); g.N3p = pad128(g.N3);
+    std::vector<float> f;
+    int rc;
+    auto dense = [&](const std::vector<float>& W, const std::vector<float>& b, int N, int K, int Np, DevBuf& dw, DevBuf& db) -> int {
+        pack_panel(W.data(), N, K, Np / 128, 8, (K + 15) / 16, f);
+        int r = upload(ctx, dw, f);
+        if (r) return r;
+        return upload(ctx, db, padded(b.data(), (size_t)N, (size_t)Np));
+    };
+    // GRU tensors with every gate padded from H to Hp rows (and R's columns to Hp)
+    auto gru = [&](const std::vector<float>& W, const std::vector<float>& R, const std::vector<float>& B, int K, DevBuf& dw, DevBuf& db,
+                   DevBuf& dr, DevBuf& dbr) -> int {
+        const int H = g.H, Hp = g.Hp;
+        std::vector<float> Wp((size_t)3 * Hp * K, 0.0f), Rp((size_t)3 * Hp * Hp, 0.0f), wb((size_t)g.Gp, 0.0f), rb((size_t)3 * Hp, 0.0f);
+        for (int gate = 0; gate < 3; ++gate)
+            for (int u = 0; u < H; ++u) {
+                std::copy(W.begin() + (size_t)(gate * H + u) * K, W.begin() + (size_t)(gate * H + u + 1) * K, Wp.begin() + (size_t)(gate * Hp + u) * K);
+                std::copy(R.begin() + (size_t)(gate * H + u) * H, R.begin() + (size_t)(gate * H + u + 1) * H, Rp.begin() + (size_t)(gate * Hp + u) * Hp);
+                wb[(size_t)gate * Hp + u] = B[(size_t)gate * H + u];
+                rb[(size_t)gate * Hp + u] = B[(size_t)(3 + gate) * H + u];
+            }
+        pack_panel(Wp.data(), 3 * Hp, K, g.Gp / 128, 8, (K + 15) / 16, f);
+        int r = upload(ctx, dw, f);
+        if (r) return r;
+        if ((r = upload(ctx, db, wb))) return r;
+        pack_gru_r2(Rp.data(), Hp, f);
+        if ((r = upload(ctx, dr, f))) return r;
+        return upload(ctx, dbr, rb);
+    };
+    if ((rc = dense(w.fc1_w, w.fc1_b, g.F1, 161, g.F1p, m.g_fc1_w, m.g_fc1_b))) return rc;
+    if ((rc = gru(w.gru1_w, w.gru1_r, w.gru1_b, g.F1, m.g_gi1_w, m.g_gi1_b, m.g_r1, m.g_br1))) return rc;
+    if ((rc = gru(w.gru2_w, w.gru2_r, w.gru2_b, g.H, m.g_gi2_w, m.g_gi2_b, m.g_r2, m.g_br2))) return rc;
+    if ((rc = dense(w.fc2_w, w.fc2_b, g.N2, g.H, g.N2p, m.g_fc2_w, m.g_fc2_b))) return rc;
+    if ((rc = dense(w.fc3_w, w.fc3_b, g.N3, g.N2, g.N3p, m.g_fc3_w, m.g_fc3_b))) return rc;
+    // fc4: 161 outputs = one block of 11 tiles (the gains rows are 176 floats wide)
+    pack_panel(w.fc4_w.data(), 161, g.N3, 1, 11, (g.N3 + 15) / 16, f);
+    if ((rc = upload(ctx, m.g_fc4_w, f))) return rc;
+    if ((rc = upload(ctx, m.g_fc4_b, padded(w.fc4_b.data(), 161, 176)))) return rc;
+    m.w_a1 = g.F1p; m.w_gi = g.Gp; m.w_h = g.Hp; m.w_f = std::max(g.N2p, g.N3p);
+    m.generic = true;
+    m.h3_ok = false;
+    m.loaded = true;
+    return FVAD_OK;
+}
+
 int upload_model(fvad_ctx* ctx)
 {
     const HostWeights& w = ctx->hw;
     std::string err;
     if (!w.check_dims(err)) return set_err(ctx, FVAD_ERR_MODEL_FORMAT, err);
     DeviceModel& m = ctx->dm;
+    m.loaded = false;
+    if (!w.is_baseline()) return upload_model_generic(ctx);
+    m.generic = false;
+    m.w_a1 = 400; m.w_gi = 1200; m.w_h = 400; m.w_f = 608;
     const int H = 400;
     std::vector<float> f;
     int rc;
@@ -221,7 +281,9 @@ int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
 {
     Workspace& ws = ctx->ws;
     const long need = ((n_chunks + 383) / 384) * 384; // 384 = lcm of the 128- and 192-sequence workgroups
-    if (need <= ws.cap_chunks && T <= ws.T) return FVAD_OK;
+    const DeviceModel& dm = ctx->dm;
+    const bool same_widths = ws.w_a1 == dm.w_a1 && ws.w_gi == dm.w_gi && ws.w_h == dm.w_h && ws.w_f == dm.w_f;
+    if (need <= ws.cap_chunks && T <= ws.T && same_widths) return FVAD_OK;
     hipStreamSynchronize(ctx->stream);
     free_workspace_nn(ws);
     const long G = std::max(need, ws.cap_chunks);
@@ -234,16 +296,19 @@ int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
     // zero-filled: padded rows / padded columns are read by the GEMMs and must stay finite
     if ((rc = dev_alloc(ctx, &ws.feat, rows * kFeatStride, true))) return rc;
     if ((rc = dev_alloc(ctx, &ws.spec, (size_t)G * kFramesPerChunk * kNBins * 2, true))) return rc;
-    if ((rc = dev_alloc(ctx, &ws.a1, rows * 400, true))) return rc;
-    if ((rc = dev_alloc(ctx, &ws.gi, rows * 1200, true))) return rc;
-    if ((rc = dev_alloc(ctx, &ws.h1, rows * 400, true))) return rc;
-    if ((rc = dev_alloc(ctx, &ws.h2, rows * 400, true))) return rc;
-    // f16x3 path: h1 / h2 once more as split f16 fragments, 13 K-steps of 2 KB per 16 rows
-    if ((rc = dev_alloc(ctx, &ws.hs1, rows * 416, true))) return rc;
-    if ((rc = dev_alloc(ctx, &ws.hs2, rows * 416, true))) return rc;
-    if ((rc = dev_alloc(ctx, &ws.f2, rows * 608, true))) return rc;
-    if ((rc = dev_alloc(ctx, &ws.f3, rows * 608, true))) return rc;
+    if ((rc = dev_alloc(ctx, &ws.a1, rows * (size_t)dm.w_a1, true))) return rc;
+    if ((rc = dev_alloc(ctx, &ws.gi, rows * (size_t)dm.w_gi, true))) return rc;
+    if ((rc = dev_alloc(ctx, &ws.h1, rows * (size_t)dm.w_h, true))) return rc;
+    if ((rc = dev_alloc(ctx, &ws.h2, rows * (size_t)dm.w_h, true))) return rc;
+    // f16x3 path (baseline dims only): h1 / h2 once more as split f16 fragments, 13 K-steps of 2 KB per 16 rows
+    if (!dm.generic) {
+        if ((rc = dev_alloc(ctx, &ws.hs1, rows * 416, true))) return rc;
+        if ((rc = dev_alloc(ctx, &ws.hs2, rows * 416, true))) return rc;
+    }
+    if ((rc = dev_alloc(ctx, &ws.f2, rows * (size_t)dm.w_f, true))) return rc;
+    if ((rc = dev_alloc(ctx, &ws.f3, rows * (size_t)dm.w_f, true))) return rc;
     if ((rc = dev_alloc(ctx, &ws.gains, rows * kFeatStride, true))) return rc;
+    ws.w_a1 = dm.w_a1; ws.w_gi = dm.w_gi; ws.w_h = dm.w_h; ws.w_f = dm.w_f;
     ws.cap_chunks = G;
     ws.generation++;
     ws.T = TT;
@@ -334,6 +399,7 @@ static long padded_batch(const fvad_ctx* ctx, long n)
 {
     const long a = (n + 383) / 384 * 384, b = (n + 127) / 128 * 128;
     const Tuning& tn = ctx->tune;
+    if (ctx->dm.generic) return (n + 31) / 32 * 32; // run-time-sized kernels: 64-row GEMM workgroups over 54 n and 50 n rows
     const char* force = tn.gru_kernel.empty() ? nullptr : tn.gru_kernel.c_str();
     const int cu = ctx->n_cu;
     if (nn_math_effective(ctx) == FVAD_NN_MATH_F16X3) {
@@ -450,9 +516,53 @@ static int launch_gru(fvad_ctx* ctx, GruChoice c, const float* gi, const DevBuf&
     return -1;
 }
 
+// NSNet2 of any dimensions (DeviceModel::generic): fc1 -> gi1 -> GRU1 -> gi2 -> GRU2 -> fc2 -> fc3 -> fc4 on the
+// run-time-sized kernels; one kernel family, f32 MFMA throughout
+static int run_nn_generic(fvad_ctx* ctx, long n_pad, int T, int skip)
+{
+    Workspace& ws = ctx->ws;
+    const DeviceModel& m = ctx->dm;
+    const DeviceModel::GenDims& g = m.gd;
+    hipStream_t st = ctx->stream;
+    const long rows = n_pad * T, rows_out = n_pad * (T - skip);
+    if (n_pad % 32) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "batch not padded to 32 sequences");
+    auto S = [](int K) { return (K + 15) / 16; };
+    int rc = 0;
+    ctx->last_nn_path = "f32: panel_gemm<8> + gru_gen (model dims " + std::to_string(g.F1) + "/" + std::to_string(g.H) + "/" +
+                        std::to_string(g.N2) + "/" + std::to_string(g.N3) + ")";
+    time_begin(ctx, "fc1_gemm");
+    rc |= fvad_launch_panel_gemm(ws.feat, kFeatStride, m.g_fc1_w.p, m.g_fc1_b.p, ws.a1, g.F1p, rows, 8, g.F1p / 128, S(161), FVAD_ACT_NONE, 0, 0, st);
+    time_end(ctx);
+    time_begin(ctx, "gru1_in_gemm");
+    rc |= fvad_launch_panel_gemm(ws.a1, g.F1p, m.g_gi1_w.p, m.g_gi1_b.p, ws.gi, g.Gp, rows, 8, g.Gp / 128, S(g.F1), FVAD_ACT_NONE, 0, 0, st);
+    time_end(ctx);
+    time_begin(ctx, "gru1_rec");
+    rc |= fvad_launch_gru_gen(ws.gi, g.Gp, m.g_r1.p, m.g_br1.p, ws.h1, g.Hp, n_pad, T, g.J, st);
+    time_end(ctx);
+    time_begin(ctx, "gru2_in_gemm");
+    rc |= fvad_launch_panel_gemm(ws.h1, g.Hp, m.g_gi2_w.p, m.g_gi2_b.p, ws.gi, g.Gp, rows, 8, g.Gp / 128, g.J, FVAD_ACT_NONE, 0, 0, st);
+    time_end(ctx);
+    time_begin(ctx, "gru2_rec");
+    rc |= fvad_launch_gru_gen(ws.gi, g.Gp, m.g_r2.p, m.g_br2.p, ws.h2, g.Hp, n_pad, T, g.J, st);
+    time_end(ctx);
+    time_begin(ctx, "fc2_gemm");
+    rc |= fvad_launch_panel_gemm(ws.h2, g.Hp, m.g_fc2_w.p, m.g_fc2_b.p, ws.f2, g.N2p, rows_out, 8, g.N2p / 128, g.J, FVAD_ACT_RELU, skip ? T : 0, skip, st);
+    time_end(ctx);
+    time_begin(ctx, "fc3_gemm");
+    rc |= fvad_launch_panel_gemm(ws.f2, g.N2p, m.g_fc3_w.p, m.g_fc3_b.p, ws.f3, g.N3p, rows_out, 8, g.N3p / 128, S(g.N2), FVAD_ACT_RELU, 0, 0, st);
+    time_end(ctx);
+    time_begin(ctx, "fc4_gemm");
+    rc |= fvad_launch_panel_gemm(ws.f3, g.N3p, m.g_fc4_w.p, m.g_fc4_b.p, ws.gains, kFeatStride, rows_out, 11, 1, S(g.N3), FVAD_ACT_SIGMOID, 0, 0, st);
+    time_end(ctx);
+    if (rc) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "no kernel instance for this layer shape");
+    FVAD_HIP(ctx, hipGetLastError());
+    return FVAD_OK;
+}
+
 int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
 {
     if (!ctx->dm.loaded) return set_err(ctx, FVAD_ERR_NO_MODEL, "NSNet2 weights not loaded");
+    if (ctx->dm.generic) return run_nn_generic(ctx, n_pad, T, skip);
     Workspace& ws = ctx->ws;
     const DeviceModel& m = ctx->dm;
     hipStream_t st = ctx->stream;
@@ -869,6 +979,10 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     if (ws.fft_jobs) hipFree(ws.fft_jobs);
     if (ws.h_fft_jobs) hipHostFree(ws.h_fft_jobs);
     DeviceModel& m = ctx->dm;
+    DevBuf* gbufs[] = {&m.g_fc1_w, &m.g_fc1_b, &m.g_gi1_w, &m.g_gi1_b, &m.g_r1, &m.g_br1, &m.g_gi2_w, &m.g_gi2_b, &m.g_r2, &m.g_br2,
+                       &m.g_fc2_w, &m.g_fc2_b, &m.g_fc3_w, &m.g_fc3_b, &m.g_fc4_w, &m.g_fc4_b,
+                       &m.gi1f_h3, &m.gi2_h3, &m.fc2_h3, &m.fc3_h3, &m.fc4_h3, &m.fc2h3_b, &m.fc3h3_b, &m.fc4h3_b, &m.r1_h3, &m.r2_h3};
+    for (DevBuf* b : gbufs) if (b->p) hipFree(b->p);
     DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.gi1_w, &m.gi1_b, &m.br1, &m.gi2_w, &m.gi2_b, &m.br2,
                       &m.fc2_w, &m.fc2_b, &m.fc3_w, &m.fc3_b, &m.fc4_w, &m.fc4_b, &m.r1v2, &m.r2v2, &m.gi1f_w, &m.gi1f_b, &m.gi1v2_w, &m.gi2v2_w, &m.gi1f_bzr, &m.gi2_bzr, &m.gi1_btm, &m.gi2_btm, &m.fc2v3_w, &m.fc3v3_w, &m.fc2v3_b, &m.fc3v3_b};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);

@@ -30,7 +30,8 @@ struct HostWeights {
         fc3_w, fc3_b, fc4_w, fc4_b;
     void view(fvad_nsnet2_weights* out) const;
     bool from_view(const fvad_nsnet2_weights* in, std::string& err);
-    bool check_dims(std::string& err) const;
+    bool check_dims(std::string& err) const;  // dims this build can run at all
+    bool is_baseline() const { return n_bins == 161 && n_fc1 == 400 && n_hidden == 400 && n_fc2 == 600 && n_fc3 == 600; }
 };
 void synth_weights(uint64_t seed, HostWeights& w);
 int read_onnx_nsnet2(const char* path, HostWeights& w, std::string& err);
@@ -62,11 +63,25 @@ struct DeviceModel {
     H3Scale h3_gi1f, h3_gi2, h3_fc2, h3_fc3, h3_fc4, h3_r1, h3_r2;
     bool h3_ok = false; // every weight and bound finite: the f16x3 kernels may be used
     bool loaded = false;
+    // A model of other dimensions than NSNet2-baseline's 161/400/400/600/600 (NSNet2.init binds whatever file the
+    // configuration names, NSNet2.zig:53-112): run by run_nn_generic on kernels that take their sizes at run time.
+    // Every width is padded: GEMM outputs to blocks of 8 tiles (128 columns), the hidden size to 16 J.
+    bool generic = false;
+    struct GenDims {
+        int F1 = 0, H = 0, N2 = 0, N3 = 0;            // n_fc1, n_hidden, n_fc2, n_fc3
+        int J = 0;                                     // unit tiles of the padded hidden size
+        int F1p = 0, Hp = 0, Gp = 0, N2p = 0, N3p = 0; // row strides of a1, h, gi, f2, f3
+    } gd;
+    DevBuf g_fc1_w, g_fc1_b, g_gi1_w, g_gi1_b, g_r1, g_br1, g_gi2_w, g_gi2_b, g_r2, g_br2,
+        g_fc2_w, g_fc2_b, g_fc3_w, g_fc3_b, g_fc4_w, g_fc4_b;
+    // floats per row of the workspace buffers for this model (baseline: 400 / 1200 / 400 / 608)
+    int w_a1 = 400, w_gi = 1200, w_h = 400, w_f = 608;
 };
 
 struct Workspace {
     long cap_chunks = 0; // padded chunk capacity (multiple of 384)
     int T = 0;
+    int w_a1 = 0, w_gi = 0, w_h = 0, w_f = 0; // row widths the buffers were allocated for (DeviceModel::w_*)
     ChunkDesc* descs = nullptr;
     ChunkDesc* h_descs = nullptr; // pinned, two slots of cap_chunks descriptors
     hipEvent_t desc_ev[2] = {nullptr, nullptr}; // slot's upload has left the host

@@ -103,6 +103,10 @@ size_t fvad_gru_ws_exchange_floats(long n_seq_pad);
 int fvad_launch_gru_ws(const float* gi, const float* R2frag, const float* bR, float* hout, float* hx, unsigned* flags,
                        unsigned* err, long n_seq_pad, int T, int n_cu, int tile_major, unsigned long long spin_ticks,
                        hipStream_t stream);
+// any hidden size (16 J padded units, J <= 64): gi rows of gi_ld floats with gate g of unit tile j at g * 16 J + 16 j,
+// bR [3][16 J], R2frag = pack_gru_r2 of the padded matrix, hout rows of h_ld floats
+int fvad_launch_gru_gen(const float* gi, int gi_ld, const float* R2frag, const float* bR, float* hout, int h_ld,
+                        long n_seq_pad, int T, int J, hipStream_t stream);
 int fvad_launch_gru_rec3(const float* gi, const float* R2frag, const float* bR, float* hout,
                          long n_seq_pad, int T, int waves, hipStream_t stream);
 

@@ -154,6 +154,9 @@ int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const fl
     CASE(25, FVAD_ACT_NONE)
     CASE(19, FVAD_ACT_RELU)
     CASE(11, FVAD_ACT_SIGMOID)
+    // models of other dimensions than NSNet2-baseline's (run_nn_generic): any width as blocks of 8 tiles
+    CASE(8, FVAD_ACT_NONE)
+    CASE(8, FVAD_ACT_RELU)
 #undef CASE
     return -1;
 }
@@ -763,6 +766,119 @@ int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, f
     if (n_seq_pad % 16) return -1;
     hipLaunchKernelGGL((gru_lat_kernel<8>), dim3((unsigned)(n_seq_pad / 16)), dim3(512), 0, stream, gi, R2frag, bR, hout, T, guard,
                        tile_major ? 48 : 16, tile_major ? 16 : GRU_H);
+    return 0;
+}
+
+// ------------------------------------------------------------------ GRU recurrence, any hidden size
+// NSNet2.init binds whatever ONNX file the configuration names (src/NSNet2.zig:53-112, VADPipeline.zig:25); the
+// kernels above are specialised for the baseline's H = 400.  This one takes the hidden size from the file: H padded
+// to J unit tiles of 16 (padded units have zero weights and biases: z = 1/2, n = 0, so they stay 0 from h_0 = 0 on).
+// gru_lat_kernel's scheme with run-time loops: one workgroup = 16 sequences, its 8 wavefronts share the J unit tiles
+// of a step, h_{t-1} sits in LDS in operand layout (double-buffered, one barrier per step), weight fragments come
+// straight from L2 one super-step ahead, two accumulation chains per gate.
+//   gi   [n_seq_pad * T][gi_ld]: gate g of unit tile j at g * 16 J + 16 j (Wx + Wb);  bR [3][16 J] (Rb, padded)
+//   R2frag [J][3 g][J S][64][4] (pack_gru_r2 of the padded matrix);  hout [n_seq_pad * T][h_ld]
+__global__ __launch_bounds__(512) void gru_gen_kernel(const float* __restrict__ gi, int gi_ld,
+                                                      const float* __restrict__ R2frag, const float* __restrict__ bR,
+                                                      float* hout, int h_ld, int T, int J)
+{
+    extern __shared__ __attribute__((aligned(16))) float hs_dyn[]; // [2][J][64] float4
+    typedef const __attribute__((address_space(1))) f32x4* gptr4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15;
+    const int q = lane >> 4;
+    const int Hp = 16 * J;
+    const size_t seq = (size_t)blockIdx.x * 16 + m;
+    const float* gi_seq = gi + seq * T * (size_t)gi_ld + 4 * q;
+    float* h_seq = hout + seq * T * (size_t)h_ld + 4 * q;
+    const float* bR_q = bR + 4 * q;
+    f32x4* hs = reinterpret_cast<f32x4*>(hs_dyn);
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int j = wave; j < J; j += 8) { // t = 0: h_{-1} = 0, so R h + Rb = Rb
+        const f32x4 giz = *reinterpret_cast<const f32x4*>(gi_seq + 16 * j);
+        const f32x4 gir = *reinterpret_cast<const f32x4*>(gi_seq + Hp + 16 * j);
+        const f32x4 gin = *reinterpret_cast<const f32x4*>(gi_seq + 2 * Hp + 16 * j);
+        const f32x4 bz = *reinterpret_cast<const f32x4*>(bR_q + 16 * j);
+        const f32x4 br = *reinterpret_cast<const f32x4*>(bR_q + Hp + 16 * j);
+        const f32x4 bn = *reinterpret_cast<const f32x4*>(bR_q + 2 * Hp + 16 * j);
+        f32x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float z = fast_sigmoid(giz[r] + bz[r]);
+            const float rr = fast_sigmoid(gir[r] + br[r]);
+            const float n = fast_tanh(gin[r] + rr * bn[r]);
+            h[r] = (1.0f - z) * n + z * 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(h_seq + 16 * j) = h;
+        hs[j * 64 + lane] = h;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int t = 1; t < T; ++t) {
+        const float* gi_t = gi_seq + (size_t)t * gi_ld;
+        float* h_out = h_seq + (size_t)t * h_ld;
+        const f32x4* hcur = hs + cur * (J * 64) + lane;
+        f32x4* hnxt = hs + (cur ^ 1) * (J * 64) + lane;
+        for (int j = wave; j < J; j += 8) {
+            gptr4 fz = (gptr4)(R2frag + ((size_t)(j * 3 + 0) * J) * 256 + lane * 4);
+            gptr4 fr = (gptr4)(R2frag + ((size_t)(j * 3 + 1) * J) * 256 + lane * 4);
+            gptr4 fn = (gptr4)(R2frag + ((size_t)(j * 3 + 2) * J) * 256 + lane * 4);
+            const f32x4 giz = *reinterpret_cast<const f32x4*>(gi_t + 16 * j);
+            const f32x4 gir = *reinterpret_cast<const f32x4*>(gi_t + Hp + 16 * j);
+            const f32x4 gin = *reinterpret_cast<const f32x4*>(gi_t + 2 * Hp + 16 * j);
+            f32x4 az[2] = {zero4, zero4}, ar[2] = {zero4, zero4}, an[2] = {zero4, zero4};
+            f32x4 wz = fz[0], wr = fr[0], wn = fn[0];
+            for (int S = 0; S < J; ++S) {
+                const int Sn = (S + 1 < J) ? S + 1 : S;
+                const f32x4 wz1 = fz[Sn * 64], wr1 = fr[Sn * 64], wn1 = fn[Sn * 64]; // one super-step ahead
+                const f32x4 hv = hcur[S * 64];
+                const int c = S & 1;
+                az[c] = MFMA16(wz.x, hv.x, az[c]);
+                ar[c] = MFMA16(wr.x, hv.x, ar[c]);
+                an[c] = MFMA16(wn.x, hv.x, an[c]);
+                az[c] = MFMA16(wz.y, hv.y, az[c]);
+                ar[c] = MFMA16(wr.y, hv.y, ar[c]);
+                an[c] = MFMA16(wn.y, hv.y, an[c]);
+                az[c] = MFMA16(wz.z, hv.z, az[c]);
+                ar[c] = MFMA16(wr.z, hv.z, ar[c]);
+                an[c] = MFMA16(wn.z, hv.z, an[c]);
+                az[c] = MFMA16(wz.w, hv.w, az[c]);
+                ar[c] = MFMA16(wr.w, hv.w, ar[c]);
+                an[c] = MFMA16(wn.w, hv.w, an[c]);
+                wz = wz1; wr = wr1; wn = wn1;
+            }
+            const f32x4 bz = *reinterpret_cast<const f32x4*>(bR_q + 16 * j);
+            const f32x4 br = *reinterpret_cast<const f32x4*>(bR_q + Hp + 16 * j);
+            const f32x4 bn = *reinterpret_cast<const f32x4*>(bR_q + 2 * Hp + 16 * j);
+            const f32x4 hp = hcur[j * 64];
+            const f32x4 sz = az[0] + az[1], sr = ar[0] + ar[1], sn = an[0] + an[1];
+            f32x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = fast_sigmoid(giz[r] + (sz[r] + bz[r]));
+                const float rr = fast_sigmoid(gir[r] + (sr[r] + br[r]));
+                const float n = fast_tanh(gin[r] + rr * (sn[r] + bn[r]));
+                h[r] = (1.0f - z) * n + z * hp[r];
+            }
+            *reinterpret_cast<f32x4*>(h_out + 16 * j) = h;
+            hnxt[j * 64] = h;
+        }
+        __syncthreads(); // h_t complete in the other buffer; everyone has read this one
+        cur ^= 1;
+    }
+}
+
+int fvad_launch_gru_gen(const float* gi, int gi_ld, const float* R2frag, const float* bR, float* hout, int h_ld,
+                        long n_seq_pad, int T, int J, hipStream_t stream)
+{
+    if (n_seq_pad % 16 || J < 1 || J > 64) return -1;
+    const size_t lds = (size_t)2 * J * 1024;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)gru_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+    hipLaunchKernelGGL(gru_gen_kernel, dim3((unsigned)(n_seq_pad / 16)), dim3(512), lds, stream, gi, gi_ld, R2frag, bR, hout, h_ld, T, J);
     return 0;
 }
 

@@ -89,11 +89,14 @@ void HostWeights::view(fvad_nsnet2_weights* o) const
 
 bool HostWeights::check_dims(std::string& err) const
 {
-    // the gfx950 kernels are specialised for the NSNet2-baseline shape
-    if (n_bins != 161 || n_fc1 != 400 || n_hidden != 400 || n_fc2 != 600 || n_fc3 != 600) {
-        char b[160];
+    // The spectral front end fixes the input and output width (n_fft = 320 -> 161 bins, NSNet2.zig:12,379-381); the
+    // hidden widths come from the file.  NSNet2-baseline's 400/400/600/600 run on the specialised kernels, anything
+    // else on the run-time-sized ones (engine.cpp run_nn_generic), within their limits.
+    if (n_bins != 161 || n_fc1 < 1 || n_hidden < 1 || n_fc2 < 1 || n_fc3 < 1 || n_hidden > 1024 || n_fc1 > 8192 ||
+        n_fc2 > 8192 || n_fc3 > 8192) {
+        char b[200];
         snprintf(b, sizeof b, "unsupported NSNet2 dims bins=%d fc1=%d hidden=%d fc2=%d fc3=%d "
-                 "(kernels are built for 161/400/400/600/600)", n_bins, n_fc1, n_hidden, n_fc2, n_fc3);
+                 "(bins must be 161; hidden <= 1024; fc widths <= 8192)", n_bins, n_fc1, n_hidden, n_fc2, n_fc3);
         err = b;
         return false;
     }

@@ -278,7 +278,7 @@ def test_f16x3_other_sequence_lengths_and_paddings(fv, gpu_ctx, weights7, n_seq,
     with gpu_ctx.options(nn_math="f16x3"):
         g = gpu_ctx.nsnet2_forward(f)
         assert gpu_ctx.last_nn_path().startswith("f16x3:")
-    pick = [0, 15, 16, 17, n_seq // 2, n_seq - 17, n_seq - 1]
+    pick = sorted({i for i in (0, 15, 16, 17, n_seq // 2, n_seq - 17, n_seq - 1) if 0 <= i < n_seq})
     ref = np.stack([orc.nsnet2_forward(weights7, f[i]) for i in pick])
     assert_rel(g[pick], ref, 1e-4, floor=1e-2, what=f"gains n_seq={n_seq} T={T}")
 
@@ -304,6 +304,50 @@ def test_get_weights_roundtrip(fv, gpu_ctx, weights7):
     got = gpu_ctx.weights()
     for k in fv.WEIGHT_NAMES:
         assert np.array_equal(got[k], weights7[k])
+
+
+# ------------------------------------------------------------------ model dimensions come from the file
+@pytest.mark.parametrize("dims", [(96, 72, 200, 136), (400, 400, 600, 600), (33, 16, 17, 1000), (512, 1024, 130, 64)],
+                         ids=lambda d: "x".join(map(str, d)))
+def test_model_dims_come_from_the_onnx_file(fv, weights7, pkg, tmp_path, dims):
+    # NSNet2.init binds whatever ONNX file the configuration names (NSNet2.zig:53-112, VADPipeline.zig:25).  A torch
+    # module of the NSNet2 architecture with other widths than the baseline's (hidden size not a multiple of 16,
+    # fc1 != hidden, a square and a very wide layer) is exported by PyTorch's own ONNX exporter, loaded through
+    # fvad_load_nsnet2_onnx and run: gains against torch's own forward pass and the oracle, then a whole stream
+    # through the engine against the oracle pipeline, segments included.  The baseline dims take the specialised
+    # kernels, everything else the run-time-sized ones.
+    from torch_export import export_nsnet2
+    path = str(tmp_path / "model.onnx")
+    model, x, y = export_nsnet2(path, *dims, seed=3)
+    ctx = fv.Context(0)
+    ctx.load_onnx(path)
+    w = ctx.weights()
+    assert (w["fc1_w"].shape[0], w["gru1_r"].shape[1], w["fc2_w"].shape[0], w["fc3_w"].shape[0]) == dims
+    rng = np.random.default_rng(17)
+    f = np.concatenate([x, rng.uniform(-11, 2, (70, 54, 161)).astype(np.float32)])
+    g = ctx.nsnet2_forward(f)
+    baseline = dims == (400, 400, 600, 600)
+    assert ("gru_gen" in ctx.last_nn_path()) != baseline, ctx.last_nn_path()
+    assert np.abs(g[0] - y[0]).max() <= 2e-5, np.abs(g[0] - y[0]).max()          # torch's forward pass of the same module
+    ref = np.stack([orc.nsnet2_forward(w, s) for s in f[:9]])
+    assert_rel(g[:9], ref, 1e-4, floor=1e-2, what=f"gains, dims {dims}")
+    ctx.set_nn_math("f16x3")                                                      # the emulation is built for the baseline dims only
+    assert ctx.nn_math_effective() == ("f16x3" if baseline else "f32")
+    ctx.set_nn_math("f32")
+    pcm, _ = pkg.synth.make_stream(12.3, seed=77)
+    out = ctx.engine_run([pcm[0].copy()], want_denoised=True)[0]
+    p = orc.Pipeline(w, n_channels=1, keep_denoised=True)
+    p.push(pcm[0][None])
+    assert_audio(out["denoised"], p.denoised()[0], what=f"denoised, dims {dims}")
+    assert_rel(out["band_sum"], p.band_volumes()[:, 0], 1e-4, what=f"band sums, dims {dims}")
+    # a context can change models: back to the baseline-shaped synthetic weights (workspace re-sized), same results as a fresh context
+    ctx.load_weights(weights7)
+    g7 = ctx.nsnet2_forward(f[:40])
+    fresh = fv.Context(0)
+    fresh.load_weights(weights7)
+    assert np.array_equal(g7, fresh.nsnet2_forward(f[:40]))
+    fresh.close()
+    ctx.close()
 
 
 # ------------------------------------------------------------------ B2: NSNet2.denoise streaming
@@ -854,6 +898,31 @@ def test_bench_cfg4_one_rank_equals_two_rank_rehearsal():
     assert a["n_gpus"] == 1 and b["n_gpus"] == 2
     assert a["aggregate"]["tpr"] == b["aggregate"]["tpr"] and a["aggregate"]["ppv"] == b["aggregate"]["ppv"]
     assert 0.5 < a["aggregate"]["tpr"] <= 1.0 and a["aggregate"]["n_streams"] == 21
+
+
+def test_bench_gpus_2_launches_two_ranks_itself():
+    # `python bench.py --gpus 2` with no launcher around it starts the two ranks itself (children of a process that
+    # never touches the GPU) and prints ONE line with n_gpus = 2; here as a gloo rehearsal on the one GPU of the box.
+    # The headline is on the reference's f32 arithmetic, the f16x3 emulation sits in its own block.
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--lanes", "16", "--seconds", "64",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"]["launched"] == 2 and len(d["ranks"]["ms_per_step_per_rank"]) == 2
+    assert d["dtype"] == "f32" and d["nn_math_effective"] == "f32" and d["roofline"]["peak"] == 157.3
+    assert d["self_check"]["ok"] and d["emulated"]["nn_math"] == "f16x3" and d["emulated"]["self_check"]["ok"]
+    assert d["aggregate"]["n_streams"] == 32
+    # a launcher that starts another number of ranks than --gpus says is an error, not a silent 1-rank run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1"], capture_output=True, text=True,
+                         timeout=300, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode == 2 and "rank" in bad.stderr
 
 
 # ------------------------------------------------------------------ K1's own outputs (NSNet2.zig:239-287)

@@ -358,6 +358,24 @@ def test_onnx_reader_roundtrip(fv, weights7, tmp_path, gemm):
         assert np.array_equal(got[k], weights7[k]), k
 
 
+@pytest.mark.parametrize("dims", [(400, 400, 600, 600), (96, 72, 200, 136), (64, 48, 64, 64)], ids=lambda d: "x".join(map(str, d)))
+def test_onnx_reader_on_a_file_written_by_pytorchs_exporter(fv, tmp_path, dims):
+    # the reader against a graph a real exporter wrote (tests/torch_export.py: torch.onnx.export of an nn.Module of
+    # the NSNet2 architecture): MatMul + Add with transposed initializers, GRU W / R / B in ONNX gate order, PyTorch's
+    # node and initializer names; square layers (64 x 64) cannot be told apart by shape.  The weights it returns,
+    # run through the oracle, must reproduce torch's own forward pass.
+    from torch_export import export_nsnet2
+    path = str(tmp_path / "exported.onnx")
+    _, x, y = export_nsnet2(path, *dims, seed=5)
+    w = fv.read_onnx(path)
+    assert w["fc1_w"].shape == (dims[0], 161) and w["gru1_w"].shape == (3 * dims[1], dims[0])
+    assert w["gru2_r"].shape == (3 * dims[1], dims[1]) and w["gru1_b"].shape == (6 * dims[1],)
+    assert w["fc3_w"].shape == (dims[3], dims[2]) and w["fc4_w"].shape == (161, dims[3])
+    g = orc.nsnet2_forward(w, x[0])
+    assert np.abs(g - y[0]).max() <= 2e-6, np.abs(g - y[0]).max()
+    assert y.min() < 0.2 and y.max() > 0.8             # the module is not stuck around 0.5
+
+
 def test_onnx_reader_weights_as_constant_nodes(fv, weights7, tmp_path):
     path = tmp_path / "const.onnx"
     path.write_bytes(_make_onnx(weights7, const_nodes=True))
