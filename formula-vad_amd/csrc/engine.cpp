@@ -120,7 +120,7 @@ int upload_model(fvad_ctx* ctx)
     m.loaded = false;
     if (!w.is_baseline()) return upload_model_generic(ctx);
     m.generic = false;
-    m.w_a1 = 400; m.w_gi = 1200; m.w_h = 400; m.w_f = 608;
+    m.w_a1 = 400; m.w_gi = 1200; m.w_h = 400; m.w_f = 640;
     const int H = 400;
     std::vector<float> f;
     int rc;
@@ -128,16 +128,10 @@ int upload_model(fvad_ctx* ctx)
     pack_panel(w.fc1_w.data(), 400, 161, 1, 25, 11, f);
     if ((rc = upload(ctx, m.fc1_w, f))) return rc;
     if ((rc = upload(ctx, m.fc1_b, w.fc1_b))) return rc;
-    // GRU input projections: 400 -> 1200 as 3 blocks (z, r, h) of 25 tiles; bias = Wb
-    pack_panel(w.gru1_w.data(), 1200, 400, 3, 25, 25, f);
-    if ((rc = upload(ctx, m.gi1_w, f))) return rc;
-    if ((rc = upload(ctx, m.gi1_b, std::vector<float>(w.gru1_b.begin(), w.gru1_b.begin() + 3 * H)))) return rc;
+    // recurrent biases Rb and recurrent weights as one 75 KB slab per unit tile
     if ((rc = upload(ctx, m.br1, std::vector<float>(w.gru1_b.begin() + 3 * H, w.gru1_b.end())))) return rc;
     pack_gru_r2(w.gru1_r.data(), H, f);
     if ((rc = upload(ctx, m.r1v2, f))) return rc;
-    pack_panel(w.gru2_w.data(), 1200, 400, 3, 25, 25, f);
-    if ((rc = upload(ctx, m.gi2_w, f))) return rc;
-    if ((rc = upload(ctx, m.gi2_b, std::vector<float>(w.gru2_b.begin(), w.gru2_b.begin() + 3 * H)))) return rc;
     if ((rc = upload(ctx, m.br2, std::vector<float>(w.gru2_b.begin() + 3 * H, w.gru2_b.end())))) return rc;
     pack_gru_r2(w.gru2_r.data(), H, f);
     if ((rc = upload(ctx, m.r2v2, f))) return rc;
@@ -180,6 +174,11 @@ int upload_model(fvad_ctx* ctx)
         }
         pack_panel(tile_major_rows(wf.data(), 161).data(), 1200, 161, 5, 15, 11, f);
         if ((rc = upload(ctx, m.gi1f_w, f))) return rc;
+        // small batches: the same matrices cut into 15 column blocks of 5 tiles (more, lighter workgroups)
+        pack_panel(tile_major_rows(wf.data(), 161).data(), 1200, 161, 15, 5, 11, f);
+        if ((rc = upload(ctx, m.s_gi1f_w, f))) return rc;
+        pack_panel(tile_major_rows(w.gru2_w.data(), 400).data(), 1200, 400, 15, 5, 25, f);
+        if ((rc = upload(ctx, m.s_gi2_w, f))) return rc;
         if ((rc = upload(ctx, m.gi1f_b, tile_major_rows(bf.data(), 1)))) return rc;
         // f16x3 form of the same folded layer; its input, the log-power features, is bounded by log10 of the
         // largest f32 squared (NSNet2.zig:266-287)
@@ -198,14 +197,17 @@ int upload_model(fvad_ctx* ctx)
         for (int o = 0; o < 2 * H; ++o) b2[o] += w.gru2_b[3 * H + o];
         if ((rc = upload(ctx, m.gi2_bzr, tile_major_rows(b2.data(), 1)))) return rc;
     }
-    // fc2: 400 -> 600 (N padded to 608 = 2 blocks of 19 tiles)
-    pack_panel(w.fc2_w.data(), 600, 400, 2, 19, 25, f);
+    // small batches: fc2 400 -> 600 and fc3 600 -> 600 as 8 column blocks of 5 tiles (rows of 640 floats, K of fc3
+    // padded to 608 = 38 super-steps), fc4 600 -> 161 as 2 blocks of 6 tiles of which 11 are stored
+    pack_panel(w.fc2_w.data(), 600, 400, 8, 5, 25, f);
     if ((rc = upload(ctx, m.fc2_w, f))) return rc;
-    if ((rc = upload(ctx, m.fc2_b, padded(w.fc2_b.data(), 600, 608)))) return rc;
-    // fc3: 600 -> 600 (K padded to 608 = 38 super-steps)
-    pack_panel(w.fc3_w.data(), 600, 600, 2, 19, 38, f);
+    if ((rc = upload(ctx, m.fc2_b, padded(w.fc2_b.data(), 600, 640)))) return rc;
+    pack_panel(w.fc3_w.data(), 600, 600, 8, 5, 38, f);
     if ((rc = upload(ctx, m.fc3_w, f))) return rc;
-    if ((rc = upload(ctx, m.fc3_b, padded(w.fc3_b.data(), 600, 608)))) return rc;
+    if ((rc = upload(ctx, m.fc3_b, padded(w.fc3_b.data(), 600, 640)))) return rc;
+    pack_panel(w.fc4_w.data(), 161, 600, 2, 6, 38, f);
+    if ((rc = upload(ctx, m.s_fc4_w, f))) return rc;
+    if ((rc = upload(ctx, m.s_fc4_b, padded(w.fc4_b.data(), 161, 192)))) return rc;
     // the same two layers as 3 blocks of 13 tiles (39 tiles, the 39th is padding and never stored):
     // 104 accumulator + 52 fragment registers fit the persistent kernel, 19-tile blocks do not
     pack_panel(w.fc2_w.data(), 600, 400, 3, 13, 25, f);
@@ -660,32 +662,32 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
         FVAD_HIP(ctx, hipGetLastError());
         return FVAD_OK;
     }
-    time_begin(ctx, "fc1_gemm");
-    rc |= fvad_launch_panel_gemm(ws.feat, kFeatStride, m.fc1_w.p, m.fc1_b.p, ws.a1, 400, rows, 25, 1, 11, FVAD_ACT_NONE, 0, 0, st);
-    time_end(ctx);
-    time_begin(ctx, "gru1_in_gemm");
-    rc |= fvad_launch_panel_gemm(ws.a1, 400, m.gi1_w.p, m.gi1_b.p, ws.gi, 1200, rows, 25, 3, 25, FVAD_ACT_NONE, 0, 0, st);
+    // ---- small batches: a handful of 64-row panels per launch, so every layer is cut into narrow column blocks
+    // (5 or 6 tiles) that put several wavefronts on every SIMD; fc1 is folded into the first GRU's input projection
+    // like in the large-batch family; gi rows are tile-major
+    time_begin(ctx, "gru1_in_gemm_fc1folded");
+    rc |= fvad_launch_panel_gemm(ws.feat, kFeatStride, m.s_gi1f_w.p, m.gi1f_b.p, ws.gi, 1200, rows, 5, 15, 11, FVAD_ACT_NONE, 0, 0, st);
     time_end(ctx);
     const GruChoice gcs = pick_gru(ctx, n_pad, false);
     if (gcs.version == 5 && (rc = prepare_gru_ws(ctx, n_pad))) return rc;
-    ctx->last_nn_path = std::string("f32: panel_gemm + ") + (gcs.version == 5 ? "gru_ws" : "gru_lat");
+    ctx->last_nn_path = std::string("f32: panel_gemm (fc1 folded) + ") + (gcs.version == 5 ? "gru_ws" : "gru_lat");
     time_begin(ctx, "gru1_rec");
-    rc |= launch_gru(ctx, gcs, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T, 0, 0);
+    rc |= launch_gru(ctx, gcs, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T, 0, 1);
     time_end(ctx);
     time_begin(ctx, "gru2_in_gemm");
-    rc |= fvad_launch_panel_gemm(ws.h1, 400, m.gi2_w.p, m.gi2_b.p, ws.gi, 1200, rows, 25, 3, 25, FVAD_ACT_NONE, 0, 0, st);
+    rc |= fvad_launch_panel_gemm(ws.h1, 400, m.s_gi2_w.p, m.gi2_btm.p, ws.gi, 1200, rows, 5, 15, 25, FVAD_ACT_NONE, 0, 0, st);
     time_end(ctx);
     time_begin(ctx, "gru2_rec");
-    rc |= launch_gru(ctx, gcs, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T, 1, 0);
+    rc |= launch_gru(ctx, gcs, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T, 1, 1);
     time_end(ctx);
     time_begin(ctx, "fc2_gemm");
-    rc |= fvad_launch_panel_gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 608, rows_out, 19, 2, 25, FVAD_ACT_RELU, skip ? T : 0, skip, st);
+    rc |= fvad_launch_panel_gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 640, rows_out, 5, 8, 25, FVAD_ACT_RELU, skip ? T : 0, skip, st);
     time_end(ctx);
     time_begin(ctx, "fc3_gemm");
-    rc |= fvad_launch_panel_gemm(ws.f2, 608, m.fc3_w.p, m.fc3_b.p, ws.f3, 608, rows_out, 19, 2, 38, FVAD_ACT_RELU, 0, 0, st);
+    rc |= fvad_launch_panel_gemm(ws.f2, 640, m.fc3_w.p, m.fc3_b.p, ws.f3, 640, rows_out, 5, 8, 38, FVAD_ACT_RELU, 0, 0, st);
     time_end(ctx);
     time_begin(ctx, "fc4_gemm");
-    rc |= fvad_launch_panel_gemm(ws.f3, 608, m.fc4_w.p, m.fc4_b.p, ws.gains, kFeatStride, rows_out, 11, 1, 38, FVAD_ACT_SIGMOID, 0, 0, st);
+    rc |= fvad_launch_panel_gemm(ws.f3, 640, m.s_fc4_w.p, m.s_fc4_b.p, ws.gains, kFeatStride, rows_out, 6, 2, 38, FVAD_ACT_SIGMOID, 0, 0, st, 11);
     time_end(ctx);
     if (rc) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "no kernel instance for this layer shape");
     FVAD_HIP(ctx, hipGetLastError());
@@ -983,7 +985,7 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
                        &m.g_fc2_w, &m.g_fc2_b, &m.g_fc3_w, &m.g_fc3_b, &m.g_fc4_w, &m.g_fc4_b,
                        &m.gi1f_h3, &m.gi2_h3, &m.fc2_h3, &m.fc3_h3, &m.fc4_h3, &m.fc2h3_b, &m.fc3h3_b, &m.fc4h3_b, &m.r1_h3, &m.r2_h3};
     for (DevBuf* b : gbufs) if (b->p) hipFree(b->p);
-    DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.gi1_w, &m.gi1_b, &m.br1, &m.gi2_w, &m.gi2_b, &m.br2,
+    DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.s_gi1f_w, &m.s_gi2_w, &m.s_fc4_w, &m.s_fc4_b, &m.br1, &m.br2,
                       &m.fc2_w, &m.fc2_b, &m.fc3_w, &m.fc3_b, &m.fc4_w, &m.fc4_b, &m.r1v2, &m.r2v2, &m.gi1f_w, &m.gi1f_b, &m.gi1v2_w, &m.gi2v2_w, &m.gi1f_bzr, &m.gi2_bzr, &m.gi1_btm, &m.gi2_btm, &m.fc2v3_w, &m.fc3v3_w, &m.fc2v3_b, &m.fc3v3_b};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (ctx->d_tables) hipFree(ctx->d_tables);

@@ -72,7 +72,8 @@ struct VadFftPlan {
 
 int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
                            int ldc, long rows, int nt, int n_blocks, int S_steps, int act,
-                           int map_T, int map_skip, hipStream_t stream);
+                           int map_T, int map_skip, hipStream_t stream, int n_valid_tiles = 0,
+                           const unsigned* guard = nullptr);
 int fvad_launch_panel_gemm3(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
                             int ldc, long rows, int nt, int n_blocks, int S_steps, int K, int act,
                             int n_valid_tiles, int map_T, int map_skip, int n_wg, hipStream_t stream);

@@ -38,9 +38,11 @@ template <int NT, int ACT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void panel_gemm_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ Wfrag,
     const float* __restrict__ bias, float* __restrict__ C, int ldc, int S_steps, int row_map_T,
-    int row_map_skip)
+    int row_map_skip, int n_valid_tiles, const unsigned* guard)
 {
     __shared__ __attribute__((aligned(16))) float slab[2][NT * 256];
+    // launched behind gru_ws2_kernel as part of its fallback chain: runs only if that kernel raised *guard
+    if (guard && *guard == 0) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -95,13 +97,23 @@ __global__ __launch_bounds__(WAVES * 64) void panel_gemm_kernel(
             a_next = *reinterpret_cast<const f32x4*>(a_ptr + 16 * (S + 1));
         }
         const f32x4* wl = reinterpret_cast<const f32x4*>(slab[cur]) + lane;
+        // consecutive MFMAs go to different accumulators: a dependent v_mfma_f32_16x16x4_f32 issues every 40 cycles,
+        // an independent one every 32 (each accumulator still sees its k in order)
+        constexpr int TG = NT <= 12 ? NT : 5; // tiles per interleaved group (register budget); instances: 5, 6, 8, 11, 25
+        static_assert(NT % TG == 0, "tile groups");
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const f32x4 w4 = wl[t * 64];
-            acc[t] = MFMA16(w4.x, a_cur.x, acc[t]);
-            acc[t] = MFMA16(w4.y, a_cur.y, acc[t]);
-            acc[t] = MFMA16(w4.z, a_cur.z, acc[t]);
-            acc[t] = MFMA16(w4.w, a_cur.w, acc[t]);
+        for (int t0 = 0; t0 < NT; t0 += TG) {
+            f32x4 w4[TG];
+#pragma unroll
+            for (int t = 0; t < TG; ++t) w4[t] = wl[(t0 + t) * 64];
+#pragma unroll
+            for (int t = 0; t < TG; ++t) acc[t0 + t] = MFMA16(w4[t].x, a_cur.x, acc[t0 + t]);
+#pragma unroll
+            for (int t = 0; t < TG; ++t) acc[t0 + t] = MFMA16(w4[t].y, a_cur.y, acc[t0 + t]);
+#pragma unroll
+            for (int t = 0; t < TG; ++t) acc[t0 + t] = MFMA16(w4[t].z, a_cur.z, acc[t0 + t]);
+#pragma unroll
+            for (int t = 0; t < TG; ++t) acc[t0 + t] = MFMA16(w4[t].w, a_cur.w, acc[t0 + t]);
         }
         if (more) {
 #pragma unroll
@@ -116,8 +128,10 @@ __global__ __launch_bounds__(WAVES * 64) void panel_gemm_kernel(
 
     float* c_ptr = C + (size_t)row * (size_t)ldc + nblk * (NT * 16) + 4 * q;
     const float* b_ptr = bias + nblk * (NT * 16) + 4 * q;
+    const int valid_t = n_valid_tiles - nblk * NT; // tiles past the output's width are computed but not stored
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+        if (t >= valid_t) break;
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(b_ptr + 16 * t);
         f32x4 v = acc[t] + b4;
         if (ACT == FVAD_ACT_RELU) {
@@ -132,31 +146,38 @@ __global__ __launch_bounds__(WAVES * 64) void panel_gemm_kernel(
 template <int NT, int ACT>
 static void launch_panel(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
                          int ldc, long rows, int n_blocks, int S_steps, int map_T, int map_skip,
-                         hipStream_t stream)
+                         int n_valid_tiles, const unsigned* guard, hipStream_t stream)
 {
     constexpr int WAVES = 4;
     dim3 grid((unsigned)(rows / (16 * WAVES)), (unsigned)n_blocks);
     hipLaunchKernelGGL((panel_gemm_kernel<NT, ACT, WAVES>), grid, dim3(WAVES * 64), 0, stream, A,
-                       lda, Wfrag, bias, C, ldc, S_steps, map_T, map_skip);
+                       lda, Wfrag, bias, C, ldc, S_steps, map_T, map_skip, n_valid_tiles, guard);
 }
 
-// rows must be a multiple of 64; NT selects the per-block width (16*NT units).
+// rows must be a multiple of 64; NT selects the per-block width (16*NT units); n_valid_tiles <= 0: every tile of
+// every block is stored; guard != nullptr: the kernel returns at once unless *guard != 0.
 int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
                            int ldc, long rows, int nt, int n_blocks, int S_steps, int act,
-                           int map_T, int map_skip, hipStream_t stream)
+                           int map_T, int map_skip, hipStream_t stream, int n_valid_tiles, const unsigned* guard)
 {
+    if (n_valid_tiles <= 0) n_valid_tiles = nt * n_blocks;
 #define CASE(NT_, ACT_)                                                                          \
     if (nt == NT_ && act == ACT_) {                                                              \
         launch_panel<NT_, ACT_>(A, lda, Wfrag, bias, C, ldc, rows, n_blocks, S_steps, map_T,     \
-                                map_skip, stream);                                               \
+                                map_skip, n_valid_tiles, guard, stream);                         \
         return 0;                                                                                \
     }
     CASE(25, FVAD_ACT_NONE)
-    CASE(19, FVAD_ACT_RELU)
     CASE(11, FVAD_ACT_SIGMOID)
     // models of other dimensions than NSNet2-baseline's (run_nn_generic): any width as blocks of 8 tiles
     CASE(8, FVAD_ACT_NONE)
     CASE(8, FVAD_ACT_RELU)
+    // small batches (a push of a few chunks, BASELINE config 3's 82): a launch is a handful of 64-row panels, so the
+    // columns are cut into narrow blocks -- 5 or 6 tiles -- to put several wavefronts on every SIMD of the chip:
+    // 1200 = 15 x 5 tiles, 600 -> 8 x 5 tiles (rows of 640 floats), 161 -> 2 x 6 tiles of which 11 are stored
+    CASE(5, FVAD_ACT_NONE)
+    CASE(5, FVAD_ACT_RELU)
+    CASE(6, FVAD_ACT_SIGMOID)
 #undef CASE
     return -1;
 }

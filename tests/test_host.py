@@ -364,9 +364,9 @@ def test_onnx_reader_on_a_file_written_by_pytorchs_exporter(fv, tmp_path, dims):
     # the NSNet2 architecture): MatMul + Add with transposed initializers, GRU W / R / B in ONNX gate order, PyTorch's
     # node and initializer names; square layers (64 x 64) cannot be told apart by shape.  The weights it returns,
     # run through the oracle, must reproduce torch's own forward pass.
-    from torch_export import export_nsnet2
+    from torch_export import export_in_subprocess
     path = str(tmp_path / "exported.onnx")
-    _, x, y = export_nsnet2(path, *dims, seed=5)
+    x, y = export_in_subprocess(path, dims, seed=5)
     w = fv.read_onnx(path)
     assert w["fc1_w"].shape == (dims[0], 161) and w["gru1_w"].shape == (3 * dims[1], dims[0])
     assert w["gru2_r"].shape == (3 * dims[1], dims[1]) and w["gru1_b"].shape == (6 * dims[1],)

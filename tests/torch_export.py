@@ -6,7 +6,14 @@ real exporter writes them -- so that the library's ONNX reader is tested on a fi
 The `onnx` Python package is not installed in this image.  torch's TorchScript exporter serialises the protobuf in
 C++ and needs that package only for a post-processing hook that splices onnxscript custom functions into the
 model (none here): the hook is bypassed, nothing else is touched.  (The dynamo exporter needs `onnxscript`, which
-is absent too.)"""
+is absent too.)
+
+Run as a script in a process of its own -- torch brings its own copy of the ROCm runtime, and once it is loaded
+into a process the system librccl no longer finds the GPU ("no ROCm-capable device is detected"), so the test
+session itself must not import torch:
+    python tests/torch_export.py out.onnx out.npz n_fc1 n_hidden n_fc2 n_fc3 seed
+writes the ONNX file and an .npz with the input `x` [1, 54, 161] and torch's own output `y`."""
+import sys
 import warnings
 
 import numpy as np
@@ -49,3 +56,23 @@ def export_nsnet2(path, n_fc1=400, n_hidden=400, n_fc2=600, n_fc3=600, seed=0, T
     with torch.no_grad():
         y = model(x)
     return model, x.numpy().astype(np.float32), y.numpy().astype(np.float32)
+
+
+def export_in_subprocess(path, dims, seed=0):
+    """export_nsnet2 in a child interpreter; returns (x, y) as numpy arrays"""
+    import os
+    import subprocess
+    npz = path + ".npz"
+    cmd = [sys.executable, os.path.abspath(__file__), path, npz] + [str(d) for d in dims] + [str(seed)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError("torch ONNX export failed:\n" + r.stderr[-3000:])
+    d = np.load(npz)
+    return d["x"], d["y"]
+
+
+if __name__ == "__main__":
+    out_onnx, out_npz = sys.argv[1], sys.argv[2]
+    f1, h, f2, f3, seed_ = (int(v) for v in sys.argv[3:8])
+    _, x_, y_ = export_nsnet2(out_onnx, f1, h, f2, f3, seed=seed_)
+    np.savez(out_npz, x=x_, y=y_)
