@@ -179,6 +179,10 @@ int upload_model(fvad_ctx* ctx)
         if ((rc = upload(ctx, m.s_gi1f_w, f))) return rc;
         pack_panel(tile_major_rows(w.gru2_w.data(), 400).data(), 1200, 400, 15, 5, 25, f);
         if ((rc = upload(ctx, m.s_gi2_w, f))) return rc;
+        // gru_ws2_kernel computes layer 2's input projection itself: W_ih2 as stationary fragments like R, Wb gate-major
+        pack_gru_r2(w.gru2_w.data(), H, f);
+        if ((rc = upload(ctx, m.s_w2frag, f))) return rc;
+        if ((rc = upload(ctx, m.s_bw2, std::vector<float>(w.gru2_b.begin(), w.gru2_b.begin() + 3 * H)))) return rc;
         if ((rc = upload(ctx, m.gi1f_b, tile_major_rows(bf.data(), 1)))) return rc;
         // f16x3 form of the same folded layer; its input, the log-power features, is bounded by log10 of the
         // largest f32 squared (NSNet2.zig:266-287)
@@ -374,6 +378,15 @@ static double gru_ws_cost(long n_pad, int n_cu)
     return 6.2e3 + 9.4e3 * RT;
 }
 
+// both layers pipelined in one launch (gru_ws2_kernel): 55 steps instead of 2 x 54 and no input-projection GEMM for
+// layer 2; a step costs about what gru_ws's does at the same row tiles per group (fewer groups fit: 26 workgroups each)
+static double gru_ws2_cost_both_layers(long n_pad, int n_cu)
+{
+    int RT = 0, G = 0;
+    if (!fvad_gru_ws2_shape(n_pad, n_cu, &RT, &G)) return 1e30;
+    return 55.0 * (6.2e3 + 9.4e3 * RT);
+}
+
 static double gru_cost(long n_pad, int waves, int n_cu)
 {
     const double per_step = waves == 12 ? 25 * 32.3e3 : waves == 8 ? 25 * 23.4e3 : waves == 4 ? 25 * 13.0e3 : 120e3;
@@ -415,8 +428,8 @@ static long padded_batch(const fvad_ctx* ctx, long n)
     // the weight-stationary recurrence and the small-batch GEMMs (64-row workgroups over 54 n and 50 n rows)
     // only need a multiple of 32 sequences
     const long c = (n + 31) / 32 * 32;
-    if (!tn.reproducible && (!force || force[1] == '5') && tn.gemm_kernel.empty() && c < 2048 &&
-        gru_ws_cost(c, cu) < std::min(gru_cost(b, 0, cu), gru_cost(b, 4, cu)))
+    if (!tn.reproducible && (!force || force[1] == '5' || force[1] == '6') && tn.gemm_kernel.empty() && c < 2048 &&
+        std::min(gru_ws_cost(c, cu), gru_ws2_cost_both_layers(c, cu) / 108.0) < std::min(gru_cost(b, 0, cu), gru_cost(b, 4, cu)))
         return c;
     if (force || a == b) return a;
     const double cost_a = std::min(std::min(gru_cost(a, 12, cu), gru_cost(a, 8, cu)), std::min(gru_cost(a, 4, cu), gru_cost(a, 0, cu)));
@@ -430,6 +443,7 @@ static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, bool allow_v3)
     if (force) {
         GruChoice c{force[1] - '0', atoi(force + 3)};
         if (c.version == 3 && !allow_v3) c = {4, 8}; // gru_rec3 needs the folded biases of the large-batch path
+        if (c.version == 6 && allow_v3) c = {5, 0};  // the pipelined kernel belongs to the small-batch sequence
         return c;
     }
     const int cu = ctx->n_cu;
@@ -444,7 +458,13 @@ static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, bool allow_v3)
     if (n_pad % 64 == 0 && gru_cost(n_pad, 4, cu) < gru_cost(n_pad, best, cu)) best = 4;
     if (n_pad % 128 == 0 && gru_cost(n_pad, 8, cu) < gru_cost(n_pad, best, cu)) best = 8;
     if (n_pad % 192 == 0 && gru_cost(n_pad, 12, cu) < gru_cost(n_pad, best, cu)) best = 12;
-    if (!allow_v3 && gru_ws_cost(n_pad, cu) < gru_cost(n_pad, best, cu)) return {5, 0}; // small-batch GEMM path only
+    if (!allow_v3) { // small-batch GEMM path only
+        // per layer: 54 steps of gru_ws (+ layer 2's share of its input-projection GEMM, ~1.5k cycles a step)
+        const double ws = 54.0 * gru_ws_cost(n_pad, cu), ws2 = gru_ws2_cost_both_layers(n_pad, cu);
+        const double other = 54.0 * gru_cost(n_pad, best, cu);
+        if (ws2 < 2.0 * std::min(ws, other) + 54.0 * 1.5e3) return {6, 0};
+        if (ws < other) return {5, 0};
+    }
     if (best == 0 || !allow_v3) return {4, 8};
     return {3, best};
 }
@@ -454,7 +474,7 @@ static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, bool allow_v3)
 int ensure_gru_ws(fvad_ctx* ctx)
 {
     Workspace& ws = ctx->ws;
-    const size_t need = fvad_gru_ws_exchange_floats(2560);
+    const size_t need = std::max(fvad_gru_ws_exchange_floats(2560), fvad_gru_ws2_exchange_floats(2304));
     if (!ws.hx) {
         FVAD_HIP(ctx, hipMalloc((void**)&ws.hx, need * sizeof(float)));
         ws.hx_cap = need;
@@ -478,9 +498,29 @@ static int prepare_gru_ws(fvad_ctx* ctx, long n_pad)
 {
     int rc = ensure_gru_ws(ctx);
     if (rc) return rc;
-    if (fvad_gru_ws_exchange_floats(n_pad) > ctx->ws.hx_cap) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "batch too large for gru_ws");
+    if (std::max(fvad_gru_ws_exchange_floats(n_pad), fvad_gru_ws2_exchange_floats(n_pad)) > ctx->ws.hx_cap)
+        return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "batch too large for gru_ws");
     fvad_launch_zero_words(ctx->ws.ws_sync, (int)kWsSyncWords, ctx->stream);
     return FVAD_OK;
+}
+
+// Launches of the weight-stationary kernels spin on each other's flags, so two of them must not share the chip
+// half-resident: within a process every such launch waits (on the GPU) for the previous one on the same device
+template <class F> static int ws_serialised(fvad_ctx* ctx, F&& launch)
+{
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(ctx->stream, &cap);
+    const bool serialise = cap == hipStreamCaptureStatusNone && ctx->device >= 0 && ctx->device < 64;
+    std::unique_lock<std::mutex> lk(g_ws_mu, std::defer_lock);
+    if (serialise) {
+        lk.lock();
+        hipEvent_t& ev = g_ws_ev[ctx->device];
+        if (!ev) { if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return -1; }
+        else if (hipStreamWaitEvent(ctx->stream, ev, 0) != hipSuccess) return -1;
+    }
+    const int rc = launch();
+    if (serialise && hipEventRecord(g_ws_ev[ctx->device], ctx->stream) != hipSuccess) return -1;
+    return rc;
 }
 
 static int launch_gru(fvad_ctx* ctx, GruChoice c, const float* gi, const DevBuf& r_v2, const float* bR,
@@ -490,22 +530,10 @@ static int launch_gru(fvad_ctx* ctx, GruChoice c, const float* gi, const DevBuf&
     if (c.version == 5) {
         Workspace& ws = ctx->ws;
         unsigned* err = ws.ws_sync + 512;
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(ctx->stream, &cap);
-        const bool serialise = cap == hipStreamCaptureStatusNone && ctx->device >= 0 && ctx->device < 64;
-        int rc;
-        {
-            std::unique_lock<std::mutex> lk(g_ws_mu, std::defer_lock);
-            if (serialise) {
-                lk.lock();
-                hipEvent_t& ev = g_ws_ev[ctx->device];
-                if (!ev) { if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return -1; }
-                else if (hipStreamWaitEvent(ctx->stream, ev, 0) != hipSuccess) return -1;
-            }
-            rc = fvad_launch_gru_ws(gi, r_v2.p, bR, hout, ws.hx, ws.ws_sync + 256 * layer, err, n_pad, T, ctx->n_cu, tile_major,
-                                    ctx->tune.ws_spin_ticks, ctx->stream);
-            if (serialise && hipEventRecord(g_ws_ev[ctx->device], ctx->stream) != hipSuccess) return -1;
-        }
+        int rc = ws_serialised(ctx, [&] {
+            return fvad_launch_gru_ws(gi, r_v2.p, bR, hout, ws.hx, ws.ws_sync + 256 * layer, err, n_pad, T, ctx->n_cu, tile_major,
+                                      ctx->tune.ws_spin_ticks, ctx->stream);
+        });
         if (rc) return rc;
         // fallback behind it: returns at once unless a workgroup of the launch above gave up waiting; the last layer
         // of a pass adds the error word to the context's fallback counter (fvad_ctx_ws_fallbacks)
@@ -669,17 +697,33 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     rc |= fvad_launch_panel_gemm(ws.feat, kFeatStride, m.s_gi1f_w.p, m.gi1f_b.p, ws.gi, 1200, rows, 5, 15, 11, FVAD_ACT_NONE, 0, 0, st);
     time_end(ctx);
     const GruChoice gcs = pick_gru(ctx, n_pad, false);
-    if (gcs.version == 5 && (rc = prepare_gru_ws(ctx, n_pad))) return rc;
-    ctx->last_nn_path = std::string("f32: panel_gemm (fc1 folded) + ") + (gcs.version == 5 ? "gru_ws" : "gru_lat");
-    time_begin(ctx, "gru1_rec");
-    rc |= launch_gru(ctx, gcs, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T, 0, 1);
-    time_end(ctx);
-    time_begin(ctx, "gru2_in_gemm");
-    rc |= fvad_launch_panel_gemm(ws.h1, 400, m.s_gi2_w.p, m.gi2_btm.p, ws.gi, 1200, rows, 5, 15, 25, FVAD_ACT_NONE, 0, 0, st);
-    time_end(ctx);
-    time_begin(ctx, "gru2_rec");
-    rc |= launch_gru(ctx, gcs, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T, 1, 1);
-    time_end(ctx);
+    if (gcs.version >= 5 && (rc = prepare_gru_ws(ctx, n_pad))) return rc;
+    ctx->last_nn_path = std::string("f32: panel_gemm (fc1 folded) + ") + (gcs.version == 6 ? "gru_ws2 (layers pipelined)" : gcs.version == 5 ? "gru_ws" : "gru_lat");
+    if (gcs.version == 6) {
+        // both GRU layers in one launch, layer 2 a step behind layer 1, its input projection computed inside; behind
+        // it the guarded fallback chain, every link of which returns at once unless the error word was raised
+        unsigned* err = ws.ws_sync + 512;
+        time_begin(ctx, "gru12_rec_pipelined");
+        rc |= ws_serialised(ctx, [&] {
+            return fvad_launch_gru_ws2(ws.gi, m.r1v2.p, m.br1.p, m.s_w2frag.p, m.s_bw2.p, m.r2v2.p, m.br2.p, ws.h2, ws.hx, ws.ws_sync, err,
+                                       n_pad, T, ctx->n_cu, tn.ws_spin_ticks, st);
+        });
+        rc |= fvad_launch_gru_lat(ws.gi, m.r1v2.p, m.br1.p, ws.h1, n_pad, T, err, 1, st);
+        rc |= fvad_launch_panel_gemm(ws.h1, 400, m.s_gi2_w.p, m.gi2_btm.p, ws.gi, 1200, rows, 5, 15, 25, FVAD_ACT_NONE, 0, 0, st, 0, err);
+        rc |= fvad_launch_gru_lat(ws.gi, m.r2v2.p, m.br2.p, ws.h2, n_pad, T, err, 1, st);
+        fvad_launch_count_word(ws.ws_fallbacks, err, st);
+        time_end(ctx);
+    } else {
+        time_begin(ctx, "gru1_rec");
+        rc |= launch_gru(ctx, gcs, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T, 0, 1);
+        time_end(ctx);
+        time_begin(ctx, "gru2_in_gemm");
+        rc |= fvad_launch_panel_gemm(ws.h1, 400, m.s_gi2_w.p, m.gi2_btm.p, ws.gi, 1200, rows, 5, 15, 25, FVAD_ACT_NONE, 0, 0, st);
+        time_end(ctx);
+        time_begin(ctx, "gru2_rec");
+        rc |= launch_gru(ctx, gcs, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T, 1, 1);
+        time_end(ctx);
+    }
     time_begin(ctx, "fc2_gemm");
     rc |= fvad_launch_panel_gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 640, rows_out, 5, 8, 25, FVAD_ACT_RELU, skip ? T : 0, skip, st);
     time_end(ctx);
@@ -827,7 +871,7 @@ static int apply_option(fvad_ctx* ctx, const std::string& name, const char* valu
         else if (v == "f16x3") tn.nn_math_force = FVAD_NN_MATH_F16X3;
         else return FVAD_ERR_INVALID_ARGUMENT;
     } else if (name == "gru_kernel") {
-        if (!unset && v != "v3w12" && v != "v3w8" && v != "v3w4" && v != "v4w8" && v != "v5w0") return FVAD_ERR_INVALID_ARGUMENT;
+        if (!unset && v != "v3w12" && v != "v3w8" && v != "v3w4" && v != "v4w8" && v != "v5w0" && v != "v6w0") return FVAD_ERR_INVALID_ARGUMENT;
         tn.gru_kernel = v;
     } else if (name == "gemm_kernel") {
         if (!unset && v != "v1" && v != "v3" && v != "v3nofold") return FVAD_ERR_INVALID_ARGUMENT;
@@ -985,7 +1029,7 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
                        &m.g_fc2_w, &m.g_fc2_b, &m.g_fc3_w, &m.g_fc3_b, &m.g_fc4_w, &m.g_fc4_b,
                        &m.gi1f_h3, &m.gi2_h3, &m.fc2_h3, &m.fc3_h3, &m.fc4_h3, &m.fc2h3_b, &m.fc3h3_b, &m.fc4h3_b, &m.r1_h3, &m.r2_h3};
     for (DevBuf* b : gbufs) if (b->p) hipFree(b->p);
-    DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.s_gi1f_w, &m.s_gi2_w, &m.s_fc4_w, &m.s_fc4_b, &m.br1, &m.br2,
+    DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.s_gi1f_w, &m.s_gi2_w, &m.s_fc4_w, &m.s_fc4_b, &m.s_w2frag, &m.s_bw2, &m.br1, &m.br2,
                       &m.fc2_w, &m.fc2_b, &m.fc3_w, &m.fc3_b, &m.fc4_w, &m.fc4_b, &m.r1v2, &m.r2v2, &m.gi1f_w, &m.gi1f_b, &m.gi1v2_w, &m.gi2v2_w, &m.gi1f_bzr, &m.gi2_bzr, &m.gi1_btm, &m.gi2_btm, &m.fc2v3_w, &m.fc3v3_w, &m.fc2v3_b, &m.fc3v3_b};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (ctx->d_tables) hipFree(ctx->d_tables);

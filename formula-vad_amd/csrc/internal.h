@@ -53,7 +53,7 @@ struct DevBuf {
 
 struct DeviceModel {
     DevBuf fc1_w, fc1_b, br1, br2, fc2_w, fc2_b, fc3_w, fc3_b, // fc2 / fc3: the small-batch layout (8 blocks of 5 tiles)
-        s_gi1f_w, s_gi2_w, s_fc4_w, s_fc4_b,                   // small-batch layouts of the input projections and fc4
+        s_gi1f_w, s_gi2_w, s_fc4_w, s_fc4_b, s_w2frag, s_bw2,                   // small-batch layouts of the input projections and fc4
         fc4_w, fc4_b, r1v2, r2v2, gi1f_w, gi1f_b, gi1v2_w, gi2v2_w,
         fc2v3_w, fc3v3_w, fc2v3_b, fc3v3_b, // fc2/fc3 as 3 column blocks of 13 tiles for panel_gemm3
         gi1f_bzr, gi2_bzr, // input-projection biases with the recurrent z/r biases folded in (gru_rec3)
@@ -140,7 +140,7 @@ struct KernelTime {
 // by fvad_ctx_create, as the initial values; nothing in the data path looks at the environment.
 struct Tuning {
     int nn_math_force = -1;      // FVAD_NN_MATH at create: overrides fvad_ctx_set_nn_math (-1: none)
-    std::string gru_kernel;      // "" / "v3w12" / "v3w8" / "v3w4" / "v4w8" (gru_lat) / "v5w0" (gru_ws)
+    std::string gru_kernel;      // "" / "v3w12" / "v3w8" / "v3w4" / "v4w8" (gru_lat) / "v5w0" (gru_ws) / "v6w0" (gru_ws2)
     std::string gemm_kernel;     // "" / "v1" (small-batch GEMM) / "v3" / "v3nofold"
     int h3_waves = 0;            // 0 / 8 / 12
     long max_chunks = 49152;     // chunks per launch when the caller passes 0

@@ -106,6 +106,14 @@ int fvad_launch_gru_ws(const float* gi, const float* R2frag, const float* bR, fl
                        hipStream_t stream);
 // any hidden size (16 J padded units, J <= 64): gi rows of gi_ld floats with gate g of unit tile j at g * 16 J + 16 j,
 // bR [3][16 J], R2frag = pack_gru_r2 of the padded matrix, hout rows of h_ld floats
+// both GRU layers in one launch, pipelined layer over layer (kernels_ws.hip gru_ws2_kernel): gi1 tile-major rows
+// (layer 1's input projection), W2frag = pack_gru_r2 of layer 2's input weights, bW2 = its bias Wb [3][400];
+// hx: fvad_gru_ws2_exchange_floats floats; flags: 512 zeroed words; returns -1 when the batch does not fit
+bool fvad_gru_ws2_shape(long n_seq_pad, int n_cu, int* RT, int* G);
+size_t fvad_gru_ws2_exchange_floats(long n_seq_pad);
+int fvad_launch_gru_ws2(const float* gi1, const float* R1frag, const float* bR1, const float* W2frag, const float* bW2,
+                        const float* R2frag, const float* bR2, float* hout2, float* hx, unsigned* flags, unsigned* err,
+                        long n_seq_pad, int T, int n_cu, unsigned long long spin_ticks, hipStream_t stream);
 int fvad_launch_gru_gen(const float* gi, int gi_ld, const float* R2frag, const float* bR, float* hout, int h_ld,
                         long n_seq_pad, int T, int J, hipStream_t stream);
 int fvad_launch_gru_rec3(const float* gi, const float* R2frag, const float* bR, float* hout,

@@ -337,11 +337,16 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
     // ---- load + decimate + sum of squares
     float ss = 0.0f;
     {
-        const int hist = d.first ? 0 : (kWarmupRows + 1) * kNHop * kDown; // 2400 raw samples
-        const int dec0 = d.first ? (kWarmupRows + 1) * kNHop : 0;          // 800
+        // [2400 raw samples of history | chunk]: the history of the first chunk of a launch is not in memory (its
+        // decimated tail comes from the carry below), so its float4s are skipped -- but the sample -> thread
+        // assignment is the SAME for every chunk, first or not: the order of the RMS sum, and with it the RMS bits,
+        // must not depend on where a launch or a push happens to start
+        constexpr int hist = (kWarmupRows + 1) * kNHop * kDown; // 2400
+        const int dec0 = (kWarmupRows + 1) * kNHop;             // 800: where the chunk's own decimated samples start
+        const int i4_begin = d.first ? hist / 4 : 0;
         auto take = [&](unsigned s, float x) { // sample s of [history | chunk]
             const unsigned s3 = s / 3u;
-            if (s3 * 3u == s) dec[dec0 + s3] = x;
+            if (s3 * 3u == s) dec[s3] = x;
             if ((int)s >= hist) ss += x * x;
         };
         // batches of 9 independent loads per thread are issued before any is consumed, so the chunk's
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
 #pragma unroll
                 for (int b = 0; b < LD_BATCH; ++b) {
                     const int i4 = base + b * K1_THREADS + tid;
-                    r[b] = (i4 < n4) ? src16[i4] : (s16x4){0, 0, 0, 0};
+                    r[b] = (i4 < n4 && i4 >= i4_begin) ? src16[i4] : (s16x4){0, 0, 0, 0};
                 }
 #pragma unroll
                 for (int b = 0; b < LD_BATCH; ++b)
@@ -372,13 +377,13 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
 #pragma unroll
                 for (int b = 0; b < LD_BATCH; ++b) {
                     const int i4 = base + b * K1_THREADS + tid;
-                    v[b] = (i4 < n4) ? src4[i4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    v[b] = (i4 < n4 && i4 >= i4_begin) ? src4[i4] : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
 #pragma unroll
             for (int b = 0; b < LD_BATCH; ++b) {
                 const int i4 = base + b * K1_THREADS + tid;
-                if (i4 < n4) {
+                if (i4 < n4 && i4 >= i4_begin) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) take(4u * i4 + e, v[b][e]);
                 }

@@ -236,6 +236,325 @@ __global__ __launch_bounds__(256) void gru_ws_kernel(const float* __restrict__ g
     }
 }
 
+// ------------------------------------------------------------------ both GRU layers in one launch, pipelined
+// gru_ws_kernel runs the two layers one after the other: 2 x 54 exchange-bound steps (~5.3 us each) with the second
+// layer's input projection (a GEMM launch) between them -- 0.63 of BASELINE config 3's 0.85 ms at its literal
+// 82-chunk batch.  Layer 2's step t needs only h1_t and h2_{t-1}, so it can run beside layer 1's step t + 1: here a
+// group of 38 workgroups serves one set of row tiles, 13 for layer 1 and 25 for layer 2, and the chain is 55 steps.
+//   * a workgroup has 8 wavefronts in two halves (0-2 / 4-6 gate wavefronts, 3 / 7 helpers); every gate wavefront
+//     keeps one gate's 25 fragment blocks of one matrix tile in 100 VGPRs for the whole launch.  A layer-1 workgroup
+//     owns TWO unit tiles of R1 (2 pair, 2 pair + 1, one per half; the 13th workgroup's second half idles).  A
+//     layer-2 workgroup owns ONE unit tile and both of its matrices -- W_ih in the first half, R in the second: layer 2
+//     computes its own input projection gi2_t = W_ih h1_t instead of reading it from a GEMM (both matrices of two
+//     tiles would be 200 VGPRs per wavefront: spills);
+//   * the hand-off is gru_ws_kernel's (sc1 write-through payload, every storing wave drains vmcnt, workgroup barrier,
+//     one lane raises the workgroup's monotonic flag; one wavefront polls, the others load after a barrier it joins),
+//     with one flag per workgroup (13 + 25 per group) and two exchange rings: h1 in FOUR slots (step % 4) because
+//     layer 1 may run ahead of its reader -- it waits until every layer-2 workgroup of its group has published h2 of
+//     step t - 4, i.e. has consumed h1_{t-4}, before it overwrites that slot -- and h2 in two (step parity);
+//   * layer 2's step t: wait for h1_t and h2_{t-1} -> fetch both -> W_ih h1_t on the first half's gate wavefronts
+//     BESIDE R h2_{t-1} on the second half's -> gates -> publish h2_t: the input projection costs a second 25 KB fetch,
+//     not a second product phase (a first version did the two products one after the other: 7.6 us per step
+//     against 5.3 us for gru_ws_kernel).
+// Bounded spins and the error word as in gru_ws_kernel; behind this kernel the engine queues the guarded fallback
+// chain gru_lat (layer 1) -> input-projection GEMM -> gru_lat (layer 2), each of which returns at once unless the
+// error word was raised.
+// Arithmetic: per output the same two accumulation chains (even / odd super-steps) as gru_ws_kernel; gi2 is
+// (W_ih h1 chains) + Wb instead of a GEMM's bias-last chain, so this family differs from the others in the last bits.
+__global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ gi1, const float* __restrict__ R1frag,
+                                                      const float* __restrict__ bR1, const float* __restrict__ W2frag,
+                                                      const float* __restrict__ bW2, const float* __restrict__ R2frag,
+                                                      const float* __restrict__ bR2, float* __restrict__ hout2,
+                                                      float* hx1, float* hx2, unsigned* flags1, unsigned* flags2,
+                                                      unsigned* err, int T, int RT, int n_rt, unsigned long long spin_ticks)
+{
+    // dynamic LDS, in float4s: hbuf[2][2][25][64] (one row tile of h1 and one of h2, double-buffered); per (row tile, tile of the pair):
+    // xch[3 gates][64] recurrent products, xci[3][64] layer 2's input projection / layer 1's gi of this step,
+    // hpv[64] the previous h of the tile; one int
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* hbuf = reinterpret_cast<f32x4*>(smem);
+    f32x4* xch = hbuf + 4 * GRU_J * 64;
+    f32x4* xci = xch + (size_t)RT * 6 * 64;
+    f32x4* hpv = xci + (size_t)RT * 6 * 64;
+    volatile int* s_dead = reinterpret_cast<volatile int*>(hpv + (size_t)RT * 2 * 64);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ws = wave >> 2;  // half of the workgroup
+    const int wg = wave & 3;   // gate wavefront (0..2) or the half's helper (3)
+    const int q = lane >> 4;
+    const int g = blockIdx.x / 38;
+    const int r38 = blockIdx.x - g * 38;
+    const int layer = r38 >= 13;
+    const int pair = layer ? r38 - 13 : r38;   // layer 1: pair of unit tiles; layer 2: the unit tile
+    const int J = layer ? pair : 2 * pair + ws;
+    const bool tile_ok = J < GRU_J; // layer 1's 13th workgroup: its second half has no tile, it only loads and joins barriers
+    const int Jc = tile_ok ? J : 0;
+    const int tslot = layer ? 0 : ws; // where this wavefront's tile sits in xch / xci / hpv
+    const int my_rt = (n_rt - g * RT < RT) ? n_rt - g * RT : RT;
+    // who does the gate math, fetches gi and publishes: layer 1: each half's helper for its tile; layer 2: wavefront 7
+    const bool helper = layer ? wave == 7 : (wg == 3 && tile_ok);
+
+    if (tid == 0) *s_dead = (int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid; i < RT * 2 * 64; i += 512) hpv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    if (*s_dead) return;
+    __syncthreads();
+
+    // ---- stationary weights of a gate wavefront: gate wg of tile J, all 25 super-steps: R1 (layer 1), or layer 2's
+    // W_ih (first half) / R2 (second half)
+    f32x4 w[GRU_J];
+    {
+        const bool gate = wg < 3 && tile_ok;
+        const size_t blk = ((size_t)(Jc * 3 + (wg < 3 ? wg : 0)) * GRU_J) * 64 + lane;
+        const f32x4* src = reinterpret_cast<const f32x4*>(layer ? (ws ? R2frag : W2frag) : R1frag) + blk;
+#pragma unroll
+        for (int S = 0; S < GRU_J; ++S) w[S] = gate ? src[S * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // biases of this wavefront's tile, held in registers (a load per step would sit on the step's critical path):
+    // Rb, and for layer 2 the input projection's Wb
+    const float* bR = (layer ? bR2 : bR1) + 16 * Jc + 4 * q;
+    const float* bW = bW2 + 16 * Jc + 4 * q;
+    const f32x4 bz = *reinterpret_cast<const f32x4*>(bR), br = *reinterpret_cast<const f32x4*>(bR + GRU_H),
+                bn = *reinterpret_cast<const f32x4*>(bR + 2 * GRU_H);
+    f32x4 wbz = (f32x4){0.f, 0.f, 0.f, 0.f}, wbr = wbz, wbn = wbz;
+    if (layer) {
+        wbz = *reinterpret_cast<const f32x4*>(bW);
+        wbr = *reinterpret_cast<const f32x4*>(bW + GRU_H);
+        wbn = *reinterpret_cast<const f32x4*>(bW + 2 * GRU_H);
+    }
+    // layer 1's gi of the step for the helper's first two row tiles: requested BEFORE the wait, like gru_ws_kernel
+    // does (further row tiles are fetched inside the product phase, beside the MFMAs, through xci)
+    constexpr int GPRE = 2;
+    f32x4 gpre[GPRE][3];
+    auto request_gi = [&](int t) {
+        if (layer == 0 && helper) {
+#pragma unroll
+            for (int rt = 0; rt < GPRE; ++rt) {
+                if (rt < my_rt) {
+                    const size_t row = (size_t)(g * RT + rt) * 16 + (lane & 15);
+                    const float* gp = gi1 + (row * T + t) * (3 * GRU_H) + 48 * J + 4 * q; // tile-major rows: [25 J][3 gates][16]
+                    gpre[rt][0] = *reinterpret_cast<const f32x4*>(gp);
+                    gpre[rt][1] = *reinterpret_cast<const f32x4*>(gp + 16);
+                    gpre[rt][2] = *reinterpret_cast<const f32x4*>(gp + 32);
+                }
+            }
+        }
+    };
+
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(hx1, 0, 4 * n_rt * GRU_J * 1024, 0x00020000);
+    const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(hx2, 0, 2 * n_rt * GRU_J * 1024, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    __attribute__((address_space(1))) unsigned* my_flag =
+        (__attribute__((address_space(1))) unsigned*)((layer ? flags2 + g * 25 : flags1 + g * 13) + pair);
+    // the polling wavefront (wave 3): lanes 0..12 watch layer 1's 13 flags of this group, lanes 32..56 layer 2's 25
+    __attribute__((address_space(1))) unsigned* poll_flag =
+        (__attribute__((address_space(1))) unsigned*)(lane < 32 ? flags1 + g * 13 + (lane < 13 ? lane : 0)
+                                                                : flags2 + g * 25 + (lane - 32 < 25 ? lane - 32 : 0));
+
+    // wait until layer 1 has published `need1` steps and layer 2 `need2` (0 = no requirement); uniform false on a deadline
+    auto wait_for = [&](unsigned need1, unsigned need2) -> bool {
+        if (wave == 3) {
+            const unsigned need = lane < 32 ? need1 : need2;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            int dead = 0;
+            for (;;) {
+                const unsigned v = __hip_atomic_load(poll_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(v >= need)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) { dead = 1; break; }
+            }
+            if (lane == 0) {
+                if (dead) __hip_atomic_store((__attribute__((address_space(1))) unsigned*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_dead = dead;
+            }
+        }
+        __syncthreads();
+        return *s_dead == 0; // uniform: every wavefront reads the same word after the barrier
+    };
+
+    // Product of the gate wavefronts' stationary fragments with every row tile of the group's h in ring `rs` at byte
+    // offset slot_base (of row tile 0 of the batch): a row tile's h is fetched once per workgroup (25 KB: the eight
+    // wavefronts load 3-4 of its 25 blocks each, sc1) into LDS, double-buffered, one barrier per row tile.  While the
+    // gate wavefronts run their 100 MFMAs the helper wavefronts of layer 1 fetch the step's gi (gi_t >= 0) into xci.
+    // Layer 1: both halves multiply their own tile of R1 with h1_{t-1} (source A).  Layer 2: the first half multiplies
+    // W_ih with h1 (source A), the second half R2 with h2 (source B) -- at the same time when both are asked for.
+    // useA / useB: which sources are fetched and which halves compute (layer 1: A only, both halves).
+    auto product = [&](bool useA, unsigned slotA, bool useB, unsigned slotB, int gi_t) {
+        constexpr int PER = (GRU_J + 7) / 8;
+        f32x4 ldA[PER], ldB[PER];
+        auto issue = [&](int rt) {
+            const unsigned row0 = (unsigned)((g * RT + rt) * GRU_J) * 1024u;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int S = wave + 8 * i;
+                if (S < GRU_J) {
+                    if (useA) ldA[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, lane16, slotA + row0 + S * 1024, WS_AUX_SC1));
+                    if (useB) ldB[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs2, lane16, slotB + row0 + S * 1024, WS_AUX_SC1));
+                }
+            }
+        };
+        issue(0);
+        for (int rt = 0; rt < my_rt; ++rt) {
+            f32x4* hbA = hbuf + (rt & 1) * (2 * GRU_J * 64);
+            f32x4* hbB = hbA + GRU_J * 64;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int S = wave + 8 * i;
+                if (S < GRU_J) {
+                    if (useA) hbA[S * 64 + lane] = ldA[i];
+                    if (useB) hbB[S * 64 + lane] = ldB[i];
+                }
+            }
+            __syncthreads();
+            if (rt + 1 < my_rt) issue(rt + 1);
+            if (wg < 3) {
+                const bool mine = layer ? (ws ? useB : useA) : true; // layer 2: this half's matrix was asked for
+                if (tile_ok && mine) {
+                    const f32x4* hb = (layer && ws) ? hbB : hbA;
+                    f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+                    for (int S = 0; S < GRU_J; ++S) {
+                        const f32x4 hv = hb[S * 64 + lane];
+                        if (S & 1) {
+                            a1 = MFMA16(w[S].x, hv.x, a1);
+                            a1 = MFMA16(w[S].y, hv.y, a1);
+                            a1 = MFMA16(w[S].z, hv.z, a1);
+                            a1 = MFMA16(w[S].w, hv.w, a1);
+                        } else {
+                            a0 = MFMA16(w[S].x, hv.x, a0);
+                            a0 = MFMA16(w[S].y, hv.y, a0);
+                            a0 = MFMA16(w[S].z, hv.z, a0);
+                            a0 = MFMA16(w[S].w, hv.w, a0);
+                        }
+                    }
+                    // layer 1: R1 h1 -> xch; layer 2: W_ih h1 -> xci (first half), R2 h2 -> xch (second half)
+                    f32x4* xdst = (layer && !ws) ? xci : xch;
+                    xdst[((rt * 2 + tslot) * 3 + wg) * 64 + lane] = a0 + a1;
+                }
+            } else if (gi_t >= 0 && helper && rt >= GPRE) {
+                const size_t row = (size_t)(g * RT + rt) * 16 + (lane & 15);
+                const float* gp = gi1 + (row * T + gi_t) * (3 * GRU_H) + 48 * J + 4 * q; // tile-major rows: [25 J][3 gates][16]
+                const f32x4 z4 = *reinterpret_cast<const f32x4*>(gp);
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(gp + 16);
+                const f32x4 n4 = *reinterpret_cast<const f32x4*>(gp + 32);
+                xci[((rt * 2 + tslot) * 3 + 0) * 64 + lane] = z4;
+                xci[((rt * 2 + tslot) * 3 + 1) * 64 + lane] = r4;
+                xci[((rt * 2 + tslot) * 3 + 2) * 64 + lane] = n4;
+            }
+        }
+        __syncthreads();
+    };
+
+    // gate math + publish of step t: the helper wavefront of each tile, for every row tile of the group.
+    // `first`: h_{t-1} = 0, so R h + Rb = Rb.  xci holds gi (layer 1) or W_ih h1_t (layer 2: Wb is added here).
+    auto gates_and_publish = [&](int t, bool first) {
+        if (helper) {
+            for (int rt = 0; rt < my_rt; ++rt) {
+                const int x0 = (rt * 2 + tslot) * 3 * 64 + lane;
+                f32x4 giz, gir, gin;
+                if (layer == 0 && rt < GPRE) {
+                    giz = rt == 0 ? gpre[0][0] : gpre[1][0];
+                    gir = rt == 0 ? gpre[0][1] : gpre[1][1];
+                    gin = rt == 0 ? gpre[0][2] : gpre[1][2];
+                } else {
+                    giz = xci[x0] + wbz; gir = xci[x0 + 64] + wbr; gin = xci[x0 + 128] + wbn;
+                }
+                f32x4 az = (f32x4){0.f, 0.f, 0.f, 0.f}, ar = az, an = az;
+                if (!first) { az = xch[x0]; ar = xch[x0 + 64]; an = xch[x0 + 128]; }
+                const f32x4 hp = hpv[(rt * 2 + tslot) * 64 + lane];
+                f32x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z = fast_sigmoid(giz[r] + (az[r] + bz[r]));
+                    const float rr = fast_sigmoid(gir[r] + (ar[r] + br[r]));
+                    const float n = fast_tanh(gin[r] + rr * (an[r] + bn[r]));
+                    h[r] = (1.0f - z) * n + z * hp[r];
+                }
+                hpv[(rt * 2 + tslot) * 64 + lane] = h;
+                const int rtg = g * RT + rt;
+                if (layer == 0) {
+                    const unsigned off = (unsigned)((((t & 3) * n_rt + rtg) * GRU_J + J) * 1024);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs1, lane16, off, WS_AUX_SC1);
+                } else {
+                    const unsigned off = (unsigned)((((t & 1) * n_rt + rtg) * GRU_J + J) * 1024);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs2, lane16, off, WS_AUX_SC1);
+                    const size_t row = (size_t)rtg * 16 + (lane & 15);
+                    *reinterpret_cast<f32x4*>(hout2 + (row * T + t) * GRU_H + 16 * J + 4 * q) = h;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the flag is raised
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(my_flag, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+
+    if (layer == 0) {
+        // t = 0: gi only (fetched by the helpers; no product: h_{-1} = 0)
+        request_gi(0);
+        if (helper)
+            for (int rt = GPRE; rt < my_rt; ++rt) {
+                const size_t row = (size_t)(g * RT + rt) * 16 + (lane & 15);
+                const float* gp = gi1 + (row * T) * (3 * GRU_H) + 48 * J + 4 * q;
+                xci[((rt * 2 + tslot) * 3 + 0) * 64 + lane] = *reinterpret_cast<const f32x4*>(gp);
+                xci[((rt * 2 + tslot) * 3 + 1) * 64 + lane] = *reinterpret_cast<const f32x4*>(gp + 16);
+                xci[((rt * 2 + tslot) * 3 + 2) * 64 + lane] = *reinterpret_cast<const f32x4*>(gp + 32);
+            }
+        gates_and_publish(0, true);
+        for (int t = 1; t < T; ++t) {
+            // h1_{t-1} of every peer, and -- before slot t % 4 is overwritten -- h1_{t-4} consumed by every layer-2 peer
+            // (layer 2 reads h1_s in its step s: it has published h2_{t-4}, flag t - 3, only after that)
+            request_gi(t);
+            if (!wait_for((unsigned)t, t >= 4 ? (unsigned)(t - 3) : 0u)) return;
+            product(true, (unsigned)(((t - 1) & 3) * n_rt * GRU_J) * 1024u, false, 0u, t);
+            gates_and_publish(t, false);
+        }
+    } else {
+        // step t: gi2_t = W_ih h1_t (first half) beside R2 h2_{t-1} (second half), both from one fetch phase
+        for (int t = 0; t < T; ++t) {
+            if (!wait_for((unsigned)(t + 1), (unsigned)t)) return;
+            product(true, (unsigned)((t & 3) * n_rt * GRU_J) * 1024u, t >= 1, (unsigned)(((t - 1) & 1) * n_rt * GRU_J) * 1024u, -1);
+            gates_and_publish(t, t == 0);
+        }
+    }
+}
+
+// geometry of the pipelined launch: G groups of 38 workgroups, RT row tiles per group
+bool fvad_gru_ws2_shape(long n_seq_pad, int n_cu, int* RT, int* G)
+{
+    if (n_seq_pad <= 0 || n_seq_pad % 16) return false;
+    const int n_rt = (int)(n_seq_pad / 16);
+    const int g_max = n_cu / 38;
+    if (g_max < 1) return false;
+    const int rt = (n_rt + g_max - 1) / g_max;
+    if (rt > 4) return false; // LDS: 50 KB + 14 KB per row tile; beyond a few row tiles the throughput kernels win anyway
+    *RT = rt;
+    *G = (n_rt + rt - 1) / rt;
+    return true;
+}
+
+size_t fvad_gru_ws2_exchange_floats(long n_seq_pad) { return (size_t)6 * (size_t)(n_seq_pad / 16) * GRU_J * 256; }
+
+int fvad_launch_gru_ws2(const float* gi1, const float* R1frag, const float* bR1, const float* W2frag, const float* bW2,
+                        const float* R2frag, const float* bR2, float* hout2, float* hx, unsigned* flags, unsigned* err,
+                        long n_seq_pad, int T, int n_cu, unsigned long long spin_ticks, hipStream_t stream)
+{
+    int RT = 0, G = 0;
+    if (!fvad_gru_ws2_shape(n_seq_pad, n_cu, &RT, &G)) return -1;
+    const int n_rt = (int)(n_seq_pad / 16);
+    float* hx1 = hx;                                    // four slots
+    float* hx2 = hx + (size_t)4 * n_rt * GRU_J * 256;   // two slots
+    // more than half of a CU's 160 KB of LDS: one workgroup per CU (all workgroups of the launch spin on each other)
+    const size_t need = (size_t)(4 * GRU_J + RT * 14) * 1024 + 16;
+    const size_t lds = need > 84 * 1024 ? need : 84 * 1024;
+    if (lds > 160 * 1024) return -1;
+    if (hipFuncSetAttribute((const void*)gru_ws2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+    hipLaunchKernelGGL(gru_ws2_kernel, dim3((unsigned)(G * 38)), dim3(512), lds, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
+                       hout2, hx1, hx2, flags, flags + 256, err, T, RT, n_rt, spin_ticks);
+    return 0;
+}
+
 __global__ void zero_words_kernel(unsigned* p, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1307,7 +1307,7 @@ def test_nsnet2_saturated_gates_match_oracle(fv, weights7):
     ref = np.stack([orc.nsnet2_forward(w, f[i]) for i in pick])
     g64 = np.stack([_nsnet2_float64(w, f[i]) for i in pick])
     e_orc = np.abs(ref - g64).max()
-    for env in ({}, {"gru_kernel": "v4w8"}, {"gru_kernel": "v5w0"}, {"nn_math": "f16x3"}, {"reproducible": "1"}):
+    for env in ({}, {"gru_kernel": "v4w8"}, {"gru_kernel": "v5w0"}, {"gru_kernel": "v6w0"}, {"nn_math": "f16x3"}, {"reproducible": "1"}):
         with ctx.options(**env):
             g_small = ctx.nsnet2_forward(f[:2])
             g_big = ctx.nsnet2_forward(f)
@@ -1399,6 +1399,8 @@ import orc
 ctx = fv.Context(0); ctx.load_synth(7)
 W = ctx.weights()
 f = np.random.default_rng(3).uniform(-11, 2, (100, 54, 161)).astype(np.float32)
+ref = np.stack([orc.nsnet2_forward(W, s) for s in f[:3]])
+ctx.set_option("gru_kernel", "v5w0")
 good = ctx.nsnet2_forward(f)                    # gru_ws at its normal deadline
 assert "gru_ws" in ctx.last_nn_path() and ctx.ws_fallbacks() == 0
 ctx.set_option("ws_spin_ticks", "0")            # every wait that is not already satisfied gives up: gru_lat redoes both layers
@@ -1410,7 +1412,18 @@ lat = ctx.nsnet2_forward(f)                     # the low-latency kernel directl
 assert "gru_lat" in ctx.last_nn_path()
 assert np.array_equal(g, lat), np.abs(g - lat).max()
 assert np.array_equal(g, good), np.abs(g - good).max()   # both recurrences accumulate in the same order: same bits
-ref = np.stack([orc.nsnet2_forward(W, s) for s in f[:3]])
+# the pipelined two-layer kernel (the default at this size): same fallback chain behind it, same result as gru_lat
+ctx.set_option("gru_kernel", None)
+p2 = ctx.nsnet2_forward(f)
+assert "gru_ws2" in ctx.last_nn_path(), ctx.last_nn_path()
+assert ctx.ws_fallbacks() == 1
+assert (np.abs(p2[:3] - ref) / np.maximum(np.abs(ref), 1e-2)).max() <= 1e-4
+ctx.set_option("ws_spin_ticks", "0")
+g2 = ctx.nsnet2_forward(f)
+assert ctx.ws_fallbacks() == 2, ctx.ws_fallbacks()
+ctx.set_option("ws_spin_ticks", None)
+assert np.array_equal(g2, lat), np.abs(g2 - lat).max()
+assert np.abs(p2 - lat).max() <= 2e-6              # its own family: layer 2's input projection is computed in the kernel
 assert (np.abs(g[:3] - ref) / np.maximum(np.abs(ref), 1e-2)).max() <= 1e-4
 print("FALLBACK_OK")
 """

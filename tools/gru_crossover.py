@@ -14,7 +14,7 @@ sizes = [int(a) for a in sys.argv[1:]] or [1024, 2048, 4096, 8192, 12288, 16384,
 for n in sizes:
     f = rng.uniform(-11, 2, (n, 54, 161)).astype(np.float32)
     row = []
-    for k in ("v5w0", "v4w8", "v3w4", "v3w8", "v3w12", ""):
+    for k in ("v6w0", "v5w0", "v4w8", "v3w4", "v3w8", "v3w12", ""):
         ctx.set_option("gru_kernel", k or None)
         try:
             ctx.nsnet2_forward(f)
@@ -22,7 +22,7 @@ for n in sizes:
             ctx.nsnet2_forward(f)
             kt = ctx.kernel_times()
             ctx.enable_timing(False)
-            row.append(f"{k or 'auto'}={kt.get('gru1_rec', float('nan')):.2f}/{sum(v for a, v in kt.items()):.2f}")
+            row.append(f"{k or 'auto'}={kt.get('gru1_rec', kt.get('gru12_rec_pipelined', float('nan'))):.2f}/{sum(v for a, v in kt.items()):.2f}")
         except Exception as e:
             row.append(f"{k}=ERR")
     print(f"n={n}: gru1 ms / all kernels ms:", "  ".join(row), flush=True)
