@@ -468,9 +468,11 @@ def test_engine_batch_consistency_at_scale(fv, gpu_ctx, pkg):
     assert np.all(np.isfinite(ref_a["denoised"]))
 
 
-def test_engine_host_buffer_pipelining_is_invisible(fv, gpu_ctx, pkg, monkeypatch):
+def test_engine_host_buffer_pipelining_is_invisible(fv, gpu_ctx, pkg):
     # above 64 MB of input the host-buffer path runs in four lane groups with staged copies on their own
-    # streams; results must be bit-identical to the single-group path, ragged lanes included
+    # streams; results must be bit-identical to the single-group path, ragged lanes included -- within one kernel
+    # family: the groups are smaller launches than the whole, so the comparison runs in "reproducible" mode; by
+    # default the two may pick different small-batch kernels and then agree to round-off, counts and RMS exactly
     rng = np.random.default_rng(3)
     base, _ = pkg.synth.make_stream(50.0, seed=21)
     lanes = []
@@ -478,13 +480,19 @@ def test_engine_host_buffer_pipelining_is_invisible(fv, gpu_ctx, pkg, monkeypatc
         n = int(rng.integers(60, 100)) * 24000 + int(rng.integers(0, 24000))
         lanes.append(np.roll(base[0], 4801 * i)[:n].copy())
     assert sum(x.nbytes for x in lanes) > (64 << 20)
-    a = gpu_ctx.engine_run(lanes, want_denoised=True)
-    with gpu_ctx.options(no_pipeline="1"):
-        b = gpu_ctx.engine_run(lanes, want_denoised=True)
-    for x, y in zip(a, b):
-        assert x["n_chunks"] == y["n_chunks"] and x["n_fft_frames"] == y["n_fft_frames"]
-        assert np.array_equal(x["denoised"], y["denoised"])
-        assert np.array_equal(x["band_sum"], y["band_sum"]) and np.array_equal(x["chunk_rms"], y["chunk_rms"])
+    for opts in ({"reproducible": "1"}, {}):
+        with gpu_ctx.options(**opts):
+            a = gpu_ctx.engine_run(lanes, want_denoised=True)
+            with gpu_ctx.options(no_pipeline="1"):
+                b = gpu_ctx.engine_run(lanes, want_denoised=True)
+        for x, y in zip(a, b):
+            assert x["n_chunks"] == y["n_chunks"] and x["n_fft_frames"] == y["n_fft_frames"]
+            assert np.array_equal(x["chunk_rms"], y["chunk_rms"])
+            if opts:
+                assert np.array_equal(x["denoised"], y["denoised"]) and np.array_equal(x["band_sum"], y["band_sum"])
+            else:
+                assert np.abs(x["denoised"] - y["denoised"]).max() <= 2e-5 * np.abs(y["denoised"]).max()
+                assert_rel(x["band_sum"], y["band_sum"], 1e-5, what="band sums across kernel families")
     assert np.all(np.isfinite(a[0]["denoised"])) and np.abs(a[0]["denoised"]).max() > 0
 
 
