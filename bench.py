@@ -759,6 +759,7 @@ def side_measurements(pkg, fv, ctx, torch, dev):
         L.fvad_engine_enqueue_device(ctx.h, d.data_ptr(), 2, d.stride(0), 41 * CHUNK, None, band.data_ptr(), rms.data_ptr(), None)
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / 3
+    cfg3_path = ctx.last_nn_path()
     # host-buffer entry point (what AudioPipeline.pushSamples hands over): H2D of the 48 kHz input, the
     # kernels, D2H of band sums / RMS (and of the denoised audio in the second figure).  Pageable numpy
     # buffers, staged by the library; never `value`.
@@ -927,7 +928,8 @@ def side_measurements(pkg, fv, ctx, torch, dev):
     except Exception as e:
         extra["hipgraph_replay"] = {"error": repr(e)}
     extra["cfg3_82_chunks_4100_frames"] = {"ms": dt * 1e3, "frames_per_s": 4100 / dt,
-                                           "note": "latency-bound: 54 dependent GRU steps x 2 layers over only 82 sequences (gru_ws_kernel: recurrent weights stationary in registers across 150 workgroups, h exchanged per step)"}
+                                           "nn_path": cfg3_path,
+                                           "note": "latency-bound: 55 dependent, exchange-bound steps over only 82 sequences (gru_ws2_kernel: both GRU layers in one launch, layer 2 a step behind layer 1, recurrent weights stationary in registers across 228 workgroups, h exchanged per step)"}
     return extra
 
 
