@@ -706,7 +706,7 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
         time_begin(ctx, "gru12_rec_pipelined");
         rc |= ws_serialised(ctx, [&] {
             return fvad_launch_gru_ws2(ws.gi, m.r1v2.p, m.br1.p, m.s_w2frag.p, m.s_bw2.p, m.r2v2.p, m.br2.p, ws.h2, ws.hx, ws.ws_sync, err,
-                                       n_pad, T, ctx->n_cu, tn.ws_spin_ticks, st);
+                                       n_pad, T, ctx->n_cu, tn.ws_spin_ticks, tn.ws2_variant, st);
         });
         rc |= fvad_launch_gru_lat(ws.gi, m.r1v2.p, m.br1.p, ws.h1, n_pad, T, err, 1, st);
         rc |= fvad_launch_panel_gemm(ws.h1, 400, m.s_gi2_w.p, m.gi2_btm.p, ws.gi, 1200, rows, 5, 15, 25, FVAD_ACT_NONE, 0, 0, st, 0, err);
@@ -891,6 +891,10 @@ static int apply_option(fvad_ctx* ctx, const std::string& name, const char* valu
     } else if (name == "ws_spin_ticks") {
         if (unset) tn.ws_spin_ticks = def.ws_spin_ticks;
         else { char* end = nullptr; tn.ws_spin_ticks = strtoull(v.c_str(), &end, 10); if (!end || *end) return FVAD_ERR_INVALID_ARGUMENT; }
+    } else if (name == "ws2_variant") { // timing-only builds of gru_ws2_kernel's step (wrong results): tools/ws2_variants.py
+        long c = 0;
+        if (!unset && (!to_long(c) || c < 0 || c > 7)) return FVAD_ERR_INVALID_ARGUMENT;
+        tn.ws2_variant = (int)c;
     } else if (name == "no_pipeline") { if (!to_bool(tn.no_pipeline)) return FVAD_ERR_INVALID_ARGUMENT; }
     else if (name == "trace_kernels") { if (!to_bool(tn.trace_kernels)) return FVAD_ERR_INVALID_ARGUMENT; }
     else if (name == "reproducible") { if (!to_bool(tn.reproducible)) return FVAD_ERR_INVALID_ARGUMENT; }

@@ -148,6 +148,7 @@ struct Tuning {
     int copy_threads = 8;        // memcpy threads of the pinned staging rings
     bool trace_kernels = false;  // name every NSNet2 stage on stderr and wait for it
     bool reproducible = false;   // one kernel family (the large-batch one) at every batch size
+    int ws2_variant = 0;         // timing-only variants of gru_ws2_kernel (tools/ws2_variants.py); 0 in production
     unsigned long long ws_spin_ticks = 25000000ull; // spin deadline of gru_ws_kernel (100 MHz ticks: 0.25 s)
 };
 

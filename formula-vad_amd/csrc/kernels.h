@@ -113,7 +113,7 @@ bool fvad_gru_ws2_shape(long n_seq_pad, int n_cu, int* RT, int* G);
 size_t fvad_gru_ws2_exchange_floats(long n_seq_pad);
 int fvad_launch_gru_ws2(const float* gi1, const float* R1frag, const float* bR1, const float* W2frag, const float* bW2,
                         const float* R2frag, const float* bR2, float* hout2, float* hx, unsigned* flags, unsigned* err,
-                        long n_seq_pad, int T, int n_cu, unsigned long long spin_ticks, hipStream_t stream);
+                        long n_seq_pad, int T, int n_cu, unsigned long long spin_ticks, int variant, hipStream_t stream);
 int fvad_launch_gru_gen(const float* gi, int gi_ld, const float* R2frag, const float* bR, float* hout, int h_ld,
                         long n_seq_pad, int T, int J, hipStream_t stream);
 int fvad_launch_gru_rec3(const float* gi, const float* R2frag, const float* bR, float* hout,

@@ -266,8 +266,12 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
                                                       const float* __restrict__ bW2, const float* __restrict__ R2frag,
                                                       const float* __restrict__ bR2, float* __restrict__ hout2,
                                                       float* hx1, float* hx2, unsigned* flags1, unsigned* flags2,
-                                                      unsigned* err, int T, int RT, int n_rt, unsigned long long spin_ticks)
+                                                      unsigned* err, int T, int RT, int n_rt, unsigned long long spin_ticks,
+                                                      int variant)
 {
+    // variant != 0: TIMING-ONLY builds of the step (wrong results; tools/ws2_variants.py, context option ws2_variant):
+    // 1 layer 2 without its input projection (no h1 fetch, no W_ih product); 2 no row-major store of h2;
+    // 4 layer 1 alone (layer 2's workgroups exit, no back-pressure)
     // dynamic LDS, in float4s: hbuf[2][2][25][64] (one row tile of h1 and one of h2, double-buffered); per (row tile, tile of the pair):
     // xch[3 gates][64] recurrent products, xci[3][64] layer 2's input projection / layer 1's gi of this step,
     // hpv[64] the previous h of the tile; one int
@@ -298,8 +302,10 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
 
     if (tid == 0) *s_dead = (int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = tid; i < RT * 2 * 64; i += 512) hpv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < RT * 6 * 64; i += 512) xci[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     if (*s_dead) return;
+    if ((variant & 4) && layer) return;
     __syncthreads();
 
     // ---- stationary weights of a gate wavefront: gate wg of tile J, all 25 super-steps: R1 (layer 1), or layer 2's
@@ -381,21 +387,21 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
     // Layer 1: both halves multiply their own tile of R1 with h1_{t-1} (source A).  Layer 2: the first half multiplies
     // W_ih with h1 (source A), the second half R2 with h2 (source B) -- at the same time when both are asked for.
     // useA / useB: which sources are fetched and which halves compute (layer 1: A only, both halves).
-    auto product = [&](bool useA, unsigned slotA, bool useB, unsigned slotB, int gi_t) {
-        constexpr int PER = (GRU_J + 7) / 8;
-        f32x4 ldA[PER], ldB[PER];
-        auto issue = [&](int rt) {
-            const unsigned row0 = (unsigned)((g * RT + rt) * GRU_J) * 1024u;
+    constexpr int PER = (GRU_J + 7) / 8;
+    f32x4 ldA[PER], ldB[PER];
+    auto issue = [&](int rt, bool doA, unsigned slotA, bool doB, unsigned slotB) {
+        const unsigned row0 = (unsigned)((g * RT + rt) * GRU_J) * 1024u;
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int S = wave + 8 * i;
-                if (S < GRU_J) {
-                    if (useA) ldA[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, lane16, slotA + row0 + S * 1024, WS_AUX_SC1));
-                    if (useB) ldB[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs2, lane16, slotB + row0 + S * 1024, WS_AUX_SC1));
-                }
+        for (int i = 0; i < PER; ++i) {
+            const int S = wave + 8 * i;
+            if (S < GRU_J) {
+                if (doA) ldA[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, lane16, slotA + row0 + S * 1024, WS_AUX_SC1));
+                if (doB) ldB[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs2, lane16, slotB + row0 + S * 1024, WS_AUX_SC1));
             }
-        };
-        issue(0);
+        }
+    };
+    auto product = [&](bool useA, unsigned slotA, bool useB, unsigned slotB, int gi_t) {
+        issue(0, useA, slotA, useB, slotB);
         for (int rt = 0; rt < my_rt; ++rt) {
             f32x4* hbA = hbuf + (rt & 1) * (2 * GRU_J * 64);
             f32x4* hbB = hbA + GRU_J * 64;
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
                 }
             }
             __syncthreads();
-            if (rt + 1 < my_rt) issue(rt + 1);
+            if (rt + 1 < my_rt) issue(rt + 1, useA, slotA, useB, slotB);
             if (wg < 3) {
                 const bool mine = layer ? (ws ? useB : useA) : true; // layer 2: this half's matrix was asked for
                 if (tile_ok && mine) {
@@ -481,7 +487,7 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
                     const unsigned off = (unsigned)((((t & 1) * n_rt + rtg) * GRU_J + J) * 1024);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs2, lane16, off, WS_AUX_SC1);
                     const size_t row = (size_t)rtg * 16 + (lane & 15);
-                    *reinterpret_cast<f32x4*>(hout2 + (row * T + t) * GRU_H + 16 * J + 4 * q) = h;
+                    if (!(variant & 2)) *reinterpret_cast<f32x4*>(hout2 + (row * T + t) * GRU_H + 16 * J + 4 * q) = h;
                 }
             }
         }
@@ -506,15 +512,16 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
             // h1_{t-1} of every peer, and -- before slot t % 4 is overwritten -- h1_{t-4} consumed by every layer-2 peer
             // (layer 2 reads h1_s in its step s: it has published h2_{t-4}, flag t - 3, only after that)
             request_gi(t);
-            if (!wait_for((unsigned)t, t >= 4 ? (unsigned)(t - 3) : 0u)) return;
+            if (!wait_for((unsigned)t, (t >= 4 && !(variant & 4)) ? (unsigned)(t - 3) : 0u)) return;
             product(true, (unsigned)(((t - 1) & 3) * n_rt * GRU_J) * 1024u, false, 0u, t);
             gates_and_publish(t, false);
         }
     } else {
         // step t: gi2_t = W_ih h1_t (first half) beside R2 h2_{t-1} (second half), both from one fetch phase
         for (int t = 0; t < T; ++t) {
-            if (!wait_for((unsigned)(t + 1), (unsigned)t)) return;
-            product(true, (unsigned)((t & 3) * n_rt * GRU_J) * 1024u, t >= 1, (unsigned)(((t - 1) & 1) * n_rt * GRU_J) * 1024u, -1);
+            const bool useA = !(variant & 1);
+            if (!wait_for(useA ? (unsigned)(t + 1) : 0u, (unsigned)t)) return;
+            product(useA, (unsigned)((t & 3) * n_rt * GRU_J) * 1024u, t >= 1, (unsigned)(((t - 1) & 1) * n_rt * GRU_J) * 1024u, -1);
             gates_and_publish(t, t == 0);
         }
     }
@@ -538,7 +545,7 @@ size_t fvad_gru_ws2_exchange_floats(long n_seq_pad) { return (size_t)6 * (size_t
 
 int fvad_launch_gru_ws2(const float* gi1, const float* R1frag, const float* bR1, const float* W2frag, const float* bW2,
                         const float* R2frag, const float* bR2, float* hout2, float* hx, unsigned* flags, unsigned* err,
-                        long n_seq_pad, int T, int n_cu, unsigned long long spin_ticks, hipStream_t stream)
+                        long n_seq_pad, int T, int n_cu, unsigned long long spin_ticks, int variant, hipStream_t stream)
 {
     int RT = 0, G = 0;
     if (!fvad_gru_ws2_shape(n_seq_pad, n_cu, &RT, &G)) return -1;
@@ -546,12 +553,12 @@ int fvad_launch_gru_ws2(const float* gi1, const float* R1frag, const float* bR1,
     float* hx1 = hx;                                    // four slots
     float* hx2 = hx + (size_t)4 * n_rt * GRU_J * 256;   // two slots
     // more than half of a CU's 160 KB of LDS: one workgroup per CU (all workgroups of the launch spin on each other)
-    const size_t need = (size_t)(4 * GRU_J + RT * 14) * 1024 + 16;
+    const size_t need = (size_t)(4 * GRU_J + RT * 14) * 1024 + 32;
     const size_t lds = need > 84 * 1024 ? need : 84 * 1024;
     if (lds > 160 * 1024) return -1;
     if (hipFuncSetAttribute((const void*)gru_ws2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
     hipLaunchKernelGGL(gru_ws2_kernel, dim3((unsigned)(G * 38)), dim3(512), lds, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
-                       hout2, hx1, hx2, flags, flags + 256, err, T, RT, n_rt, spin_ticks);
+                       hout2, hx1, hx2, flags, flags + 256, err, T, RT, n_rt, spin_ticks, variant);
     return 0;
 }
 
