@@ -297,9 +297,10 @@ const char *fvad_ctx_last_nn_path(const fvad_ctx *ctx);
  * over any number of launches or time-split over ranks gives the same bits.  FVAD_NN_MATH_F16X3 has one family.
  *
  * Testing / tuning aids, none needed in production: name = "reproducible" | "nn_math" ("f32" | "f16x3": overrides
- * fvad_ctx_set_nn_math) | "gru_kernel" ("v3w12" | "v3w8" | "v3w4" | "v4w8" | "v5w0") | "gemm_kernel" ("v1" | "v3" |
- * "v3nofold") | "h3_waves" ("8" | "12") | "max_chunks" | "copy_threads" | "no_pipeline" | "trace_kernels" |
- * "ws_spin_ticks"; value NULL or "" restores the default.  The environment variables FVAD_<NAME> are read ONCE, by
+ * fvad_ctx_set_nn_math) | "gru_kernel" ("v3w12" | "v3w8" | "v3w4" | "v4w8" | "v5w0" | "v6w0") | "gemm_kernel" ("v1" |
+ * "v3" | "v3nofold") | "h3_waves" ("8" | "12") | "max_chunks" | "copy_threads" | "no_pipeline" | "trace_kernels" |
+ * "ws_spin_ticks" | "ws2_variant" (timing-only variants of a kernel: wrong results); value NULL or "" restores the
+ * default.  The environment variables FVAD_<NAME> are read ONCE, by
  * fvad_ctx_create, as initial values (a bad value fails the creation); the data path never reads the environment. */
 int fvad_ctx_set_option(fvad_ctx *ctx, const char *name, const char *value);
 /* Network passes in which the weight-stationary small-batch recurrence (gru_ws_kernel) gave up waiting for a peer
