@@ -286,7 +286,7 @@ static void free_workspace_nn(Workspace& ws)
 int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
 {
     Workspace& ws = ctx->ws;
-    const long need = ((n_chunks + 383) / 384) * 384; // 384 = lcm of the 128- and 192-sequence workgroups
+    const long need = ((n_chunks + 767) / 768) * 768; // 768 = lcm of every batch padding (32, 128, 192 -> 384, 256)
     const DeviceModel& dm = ctx->dm;
     const bool same_widths = ws.w_a1 == dm.w_a1 && ws.w_gi == dm.w_gi && ws.w_h == dm.w_h && ws.w_f == dm.w_f;
     if (need <= ws.cap_chunks && T <= ws.T && same_widths) return FVAD_OK;
@@ -410,7 +410,7 @@ int nn_math_effective(const fvad_ctx* ctx)
     return FVAD_NN_MATH_F16X3;
 }
 
-static long padded_batch(const fvad_ctx* ctx, long n)
+static long padded_batch(const fvad_ctx* ctx, long n, int T, int skip)
 {
     const long a = (n + 383) / 384 * 384, b = (n + 127) / 128 * 128;
     const Tuning& tn = ctx->tune;
@@ -420,10 +420,13 @@ static long padded_batch(const fvad_ctx* ctx, long n)
     if (nn_math_effective(ctx) == FVAD_NN_MATH_F16X3) {
         // kernels_h3.hip at every batch size: 192- or 128-sequence workgroups (a round of the latter costs 0.76 of a
         // round of the former)
-        if (a == b || tn.h3_waves == 12) return a;
-        if (tn.h3_waves == 8) return b;
+        // the tiled layouts group 16 sequences per time step, and the GEMM panels take 16 such row tiles: both
+        // (n_pad / 16) T and (n_pad / 16) (T - skip) must be multiples of 16 (T = 54, skip = 4: any multiple of 128)
+        auto fits = [&](long np) { return ((np / 16) * T) % 16 == 0 && ((np / 16) * (T - skip)) % 16 == 0; };
         const double ca = (double)((a / 192 + cu - 1) / cu), cb = 0.76 * (double)((b / 128 + cu - 1) / cu);
-        return cb <= ca ? b : a;
+        long pick = (a == b || tn.h3_waves == 12) ? a : (tn.h3_waves == 8) ? b : (cb <= ca ? b : a);
+        if (!fits(pick)) pick = fits(a) ? a : (pick + 255) / 256 * 256; // 16 row-tile groups: fits for every T
+        return pick;
     }
     // the weight-stationary recurrence and the small-batch GEMMs (64-row workgroups over 54 n and 50 n rows)
     // only need a multiple of 32 sequences
@@ -817,7 +820,7 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
                                                ws.feat + (size_t)t.batch0 * (kRowsPerChunk * kFeatStride), kFeatStride * sizeof(float),
                                                kNBins * sizeof(float), t.count * (size_t)kRowsPerChunk, hipMemcpyDeviceToHost, ctx->stream));
         }
-        const long n_pad = padded_batch(ctx, n);
+        const long n_pad = padded_batch(ctx, n, kRowsPerChunk, kWarmupRows);
         rc = run_nn(ctx, n_pad, kRowsPerChunk, kWarmupRows);
         if (rc) return rc;
         time_begin(ctx, "istft320_ola_up3");
@@ -1213,7 +1216,7 @@ int fvad_nsnet2_forward(fvad_ctx* ctx, const float* features, size_t n_seq, size
     int rc = ensure_workspace(ctx, (long)n_seq, (int)T);
     if (rc) return rc;
     Workspace& ws = ctx->ws;
-    const long n_pad = padded_batch(ctx, (long)n_seq);
+    const long n_pad = padded_batch(ctx, (long)n_seq, (int)T, 0);
     // rows are [n_seq*T][161] on the host, [.][176] on the device
     FVAD_HIP(ctx, hipMemsetAsync(ws.feat, 0, (size_t)n_pad * T * kFeatStride * sizeof(float), ctx->stream));
     FVAD_HIP(ctx, hipMemcpy2DAsync(ws.feat, kFeatStride * sizeof(float), features, kNBins * sizeof(float),

@@ -80,7 +80,7 @@ struct DeviceModel {
 };
 
 struct Workspace {
-    long cap_chunks = 0; // padded chunk capacity (multiple of 384)
+    long cap_chunks = 0; // padded chunk capacity (multiple of 768: covers every batch padding)
     int T = 0;
     int w_a1 = 0, w_gi = 0, w_h = 0, w_f = 0; // row widths the buffers were allocated for (DeviceModel::w_*)
     ChunkDesc* descs = nullptr;

@@ -188,6 +188,13 @@ orc_pipeline *orc_pipeline_create(const orc_pipeline_config *cfg, const orc_nsne
         if (err) *err = ORC_ERR_INVALID_FFT_SIZE;
         return NULL;
     }
+    /* Not in the reference: AudioPipeline.pushSamples writes buffer_length / 2 samples per step
+     * (AudioPipeline.zig:121-140), so a buffer_length of 1 never ends its loop there, and a ring shorter than one
+     * chunk fails in MultiRingBuffer.readSlice.  The checker refuses such a configuration instead of hanging a test. */
+    if (cfg->buffer_length != 0 && (size_t)cfg->buffer_length < orc_nsnet2_chunk_size(cfg->sample_rate)) {
+        if (err) *err = ORC_ERR_OUT_OF_RANGE;
+        return NULL;
+    }
     orc_pipeline *p = (orc_pipeline *)calloc(1, sizeof(*p));
     p->cfg = *cfg;
     const int C = cfg->n_channels;

@@ -268,7 +268,7 @@ def test_f16x3_products_are_as_close_to_float64_as_f32(fv, weights7):
     c.close()
 
 
-@pytest.mark.parametrize("n_seq,T", [(2304, 7), (2176, 20), (4000, 54), (3, 54), (130, 54)])
+@pytest.mark.parametrize("n_seq,T", [(2304, 7), (2176, 20), (4000, 54), (3, 54), (130, 54), (5, 7), (200, 3)])
 def test_f16x3_other_sequence_lengths_and_paddings(fv, gpu_ctx, weights7, n_seq, T):
     # the tiled layouts of the f16x3 path group 16 sequences per time step: other sequence lengths than the
     # pipeline's 54 rows, a batch that pads to 128- rather than 192-sequence workgroups (2176), and one that is not
@@ -811,6 +811,36 @@ def test_pipeline_errors_and_skip_processing(fv, gpu_ctx):
     q.push_samples(np.zeros((1, 24000 * 4), np.float32))
     band, _ = q.trace()
     assert band.shape[0] == 93 and np.all(band == 0.0) and q.segments() == []
+
+
+def test_context_options_validate_their_values(fv, gpu_ctx):
+    # fvad_ctx_set_option: unknown names and bad values are errors, not ignored settings; NULL / "" restores the default
+    L = fv.lib()
+    for name, value in (("gru_kernel", "v9w9"), ("gemm_kernel", "fast"), ("h3_waves", "10"), ("max_chunks", "0"), ("nn_math", "bf16"),
+                        ("reproducible", "yes"), ("copy_threads", "-1"), ("no_such_option", "1"), ("ws2_variant", "9")):
+        assert L.fvad_ctx_set_option(gpu_ctx.h, name.encode(), value.encode()) == fv.FVAD_ERR_INVALID_ARGUMENT, (name, value)
+        assert name.encode() in L.fvad_last_error(gpu_ctx.h)
+    assert L.fvad_ctx_set_option(None, b"reproducible", b"1") == fv.FVAD_ERR_INVALID_ARGUMENT
+    assert L.fvad_ctx_set_option(gpu_ctx.h, None, b"1") == fv.FVAD_ERR_INVALID_ARGUMENT
+    gpu_ctx.set_option("nn_math", "f16x3")
+    assert gpu_ctx.nn_math_effective() == "f16x3"
+    gpu_ctx.set_option("nn_math", "")                     # "" like NULL: back to fvad_ctx_set_nn_math's setting
+    assert gpu_ctx.nn_math_effective() == "f32"
+    assert L.fvad_ctx_nn_math_effective(None) == fv.FVAD_ERR_INVALID_ARGUMENT
+    n = C.c_uint64(7)
+    assert L.fvad_ctx_ws_fallbacks(None, C.byref(n)) == fv.FVAD_ERR_INVALID_ARGUMENT
+    # AudioPipeline.Config.buffer_length: 0 = 10 s; a ring shorter than one chunk cannot serve VADPipeline (and a
+    # length of 1 would never end pushSamples' loop): rejected at creation
+    cfg = fv.PipelineConfig()
+    L.fvad_pipeline_config_default(C.byref(cfg))
+    cfg.sample_rate, cfg.n_channels = 48000, 1
+    h = C.c_void_p()
+    for bad in (1, 2, 23999):
+        cfg.buffer_length = bad
+        assert L.fvad_pipeline_create(gpu_ctx.h, C.byref(cfg), None, C.byref(h)) == -6      # OutOfRange
+    cfg.buffer_length = 24000
+    assert L.fvad_pipeline_create(gpu_ctx.h, C.byref(cfg), None, C.byref(h)) == 0
+    L.fvad_pipeline_destroy(h)
 
 
 def test_no_model_is_an_error(fv):

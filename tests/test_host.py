@@ -39,6 +39,21 @@ def test_gpu_entry_points_fail_loudly_without_device(fv):
         fv.Context(0)
 
 
+def test_bench_gpus_n_without_enough_gpus_is_refused_before_any_rank_starts():
+    # `python bench.py --gpus 2` starts its ranks itself; on a box that does not show 2 GPUs (this container shows none)
+    # the launcher refuses with exit code 2 instead of running one rank and printing n_gpus: 1
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs are present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 2 and "needs 2 GPUs" in r.stderr and r.stdout.strip() == ""
+    # under a launcher that started another number of ranks than --gpus says: refused too
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=120,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode == 2 and "rank" in r.stderr
+
+
 def test_windows_bit_equal_oracle(fv):
     L = fv.lib()
     w = np.zeros(320, np.float32)
