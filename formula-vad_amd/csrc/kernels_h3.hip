@@ -427,6 +427,10 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __r
                                                                 float sx, float bias_scale, float out_scale)
 {
     __shared__ __attribute__((aligned(16))) float slab[2][H3_SLAB];
+    // the n gate's recurrent bias: read from LDS in the gate math, after the tile's last MFMA (a global load at the top of
+    // every unit tile costs an address register in the hot loop: 4 VGPR spills at the 168-register cap of three
+    // wavefronts per SIMD; and an LDS read up there would sit in front of the counted waits of the fragment ring)
+    __shared__ __attribute__((aligned(16))) float sbn[GRU_H];
     typedef __attribute__((address_space(3))) float lds_float;
 
     const int tid = threadIdx.x;
@@ -434,6 +438,8 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __r
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15;
     const int q = lane >> 4;
+    for (int i = tid; i < GRU_H; i += WAVES * 64) sbn[i] = bR[2 * GRU_H + i];
+    (void)bias_scale;
     // gi and hout are in the tiled layout (see panel_gemm_h3_kernel): this wavefront's 16 sequences are group
     // `grp`; row tile grp * T + t holds their time step t as [unit tile][64 lanes][4 floats] blocks, so a gate's
     // operand tile, h_{t-1}'s operand halves and the h_t store are 1 KB of contiguous memory each.  gi's unit
@@ -542,10 +548,8 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __r
             };
             SFor<0, D>::run([&](auto sc) { read_step(sc, std::integral_constant<int, decltype(sc)::value % D>{}); });
 
-            // the n gate's accumulator starts from its recurrent bias (scaled like the products)
             f32x4 az = (f32x4){0.f, 0.f, 0.f, 0.f};
-            f32x4 ar = az;
-            f32x4 an = ld4(bR_b + 64 * J + 8 * GRU_H, b_off) * bias_scale;
+            f32x4 ar = az, an = az;
             auto k_step = [&](auto sc) {
                 constexpr int S = decltype(sc)::value;
                 constexpr int k = S % D;
@@ -585,12 +589,13 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec_h3_kernel(const float* __r
                 hp_lo = *(const __attribute__((address_space(1))) h16x4*)(src + 1024);
             }
             SFor<LOAD_AT, H3_S>::run(k_step);
+            const f32x4 bn = *reinterpret_cast<const f32x4*>(sbn + 16 * J + 4 * q);
             f32x4 h;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float z = fast_sigmoid(giz[r] + az[r] * out_scale);
                 const float rr = fast_sigmoid(gir[r] + ar[r] * out_scale);
-                const float n = fast_tanh(gin[r] + rr * (an[r] * out_scale));
+                const float n = fast_tanh(gin[r] + rr * (an[r] * out_scale + bn[r]));
                 const float hp = ((float)hp_hi[r] + (float)hp_lo[r]) * inv_sx;
                 h[r] = (1.0f - z) * n + z * hp;
             }
