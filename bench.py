@@ -58,11 +58,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-2 / config-3 side measurements")
     ap.add_argument("--vad-threads", type=int, default=0)
-    ap.add_argument("--nn-math", default="f32", choices=("f32", "f16x3"),
+    ap.add_argument("--nn-math", default="f32", choices=("f32", "f16x3", "bf16x3"),
                     help="arithmetic of the NSNet2 matrix products of the HEADLINE (fvad_ctx_set_nn_math): f32 = "
                          "v_mfma_f32_16x16x4_f32, the reference's arithmetic (default); f16x3 = the emulation (three f16 "
-                         "MFMAs on split f32 operands, 22-bit operands).  With f32 the emulation is timed too, over the "
-                         "same number of steps, and reported in the `emulated` block")
+                         "MFMAs on split f32 operands, 22-bit operands); bf16x3 = the dense layers as six bf16 MFMAs on "
+                         "exact three-piece splits (24-bit operands), recurrences on f32 MFMA.  With f32 both emulations "
+                         "are timed too, over the same number of steps, and reported in the `emulated` / `emulated24` blocks")
     ap.add_argument("--no-emulated", action="store_true", help="skip the `emulated` block (the f16x3 path)")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL; one rank per GPU) or gloo (rehearsal: every rank on cuda:0)")
@@ -329,6 +330,7 @@ def pmc_traffic(chunks_per_launch, nn_math="f32"):
     come from: file, the commit and kernel-source digest recorded when the passes were summarised, and whether
     that digest is the current build's.  None when no profile holds this kernel at this launch size."""
     want = "gru_rec_h3_kernel" if nn_math == "f16x3" else "gru_rec3_kernel"
+    ts3 = nn_math == "bf16x3"            # its recurrence is the instance that also writes three-piece fragments
     try:
         pdir = os.path.join(ROOT, "profiles")
         files = sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_summary.json")),
@@ -339,7 +341,7 @@ def pmc_traffic(chunks_per_launch, nn_math="f32"):
             if d["chunks_per_launch"] != min(chunks_per_launch, 49152):
                 continue
             for k, v in d["kernels"].items():
-                if k.startswith(want):
+                if k.startswith(want) and (nn_math == "f16x3" or k.rstrip(">").endswith("true") == ts3):
                     cands.append((d.get("recorded_at", ""), name, k, v, d))
         if not cands:
             return None
@@ -571,7 +573,8 @@ def main():
         pmc = pmc_traffic(lanes * n_chunks, m["nn_math"])
         r = {"bound": "mfma",
              "kernel": ("gru_rec_h3_kernel<12, 1> (v_mfma_f32_16x16x32_f16, three per f32 product)" if h3 else
-                        "gru_rec3_kernel<12, 2> (fp32 v_mfma_f32_16x16x4_f32)"),
+                        "gru_rec3_kernel<12, 2, true> (fp32 v_mfma_f32_16x16x4_f32; also writes h as three bf16 pieces)"
+                        if m["nn_math"] == "bf16x3" else "gru_rec3_kernel<12, 2, false> (fp32 v_mfma_f32_16x16x4_f32)"),
              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
              # HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction)
              "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
@@ -604,7 +607,7 @@ def main():
         raise RuntimeError(f"asked for {nn_math}, the context runs {head['nn_math']}")
     # ---- the emulated arithmetic on the same batch, first-class: the same W + K steps end to end, its own roofline
     # and self-check.  It is NOT the headline: f16x3 carries 22 significand bits per operand, the reference's f32 24.
-    emulated = None
+    emulated = emulated24 = None
     if nn_math == "f32" and not args.no_emulated:
         em = measure("f16x3", "emulated")
         if em["nn_math"] == "f16x3":
@@ -617,6 +620,20 @@ def main():
                         "roofline": roofline_of(em), "roofline_pipeline": pipeline_of(em),
                         "kernel_ms_per_step": {k: v / args.steps for k, v in em["ktimes"].items()},
                         "self_check": em["self_check"], "host_stage_ms": em["host_ms"]}
+        # ... and the emulation that is NOT narrower than f32: the five dense layers as six bf16 MFMAs per product on exact
+        # three-piece splits of both operands (24 significand bits, f32's exponent range), the recurrences on f32 MFMA
+        em24 = measure("bf16x3", "emulated24")
+        if em24["nn_math"] == "bf16x3":
+            emulated24 = {"nn_math": "bf16x3", "note": "dense layers: six v_mfma_f32_16x16x32_bf16 per product on exact three-piece bf16 splits of "
+                          "both f32 operands (x = h + m + l: all 24 significand bits, no scales; the three dropped cross terms are <= 2^-23 "
+                          "of a product, one f32 rounding), f32 accumulation; GRU recurrences on v_mfma_f32_16x16x4_f32.  Opt-in through "
+                          "fvad_ctx_set_nn_math; reported beside the headline, which stays on plain f32",
+                          "value": frames_per_step * args.steps * world / em24["elapsed"], "unit": "frames/s",
+                          "ms_per_step": em24["elapsed"] / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
+                          "device_only_frames_per_s": frames_per_step * args.steps * world / em24["dev_elapsed"],
+                          "roofline": roofline_of(em24), "roofline_pipeline": pipeline_of(em24),
+                          "kernel_ms_per_step": {k: v / args.steps for k, v in em24["ktimes"].items()},
+                          "self_check": em24["self_check"], "host_stage_ms": em24["host_ms"]}
         ctx.set_nn_math(nn_math)
     elapsed, dev_elapsed, ktimes, self_check = head["elapsed"], head["dev_elapsed"], head["ktimes"], head["self_check"]
 
@@ -672,7 +689,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16x3 EMULATION of f32 (22-bit operands: narrower than the reference's f32)" if h3 else "f32",
+            "dtype": ("f16x3 EMULATION of f32 (22-bit operands: narrower than the reference's f32)" if h3 else
+                      "bf16x3 emulation of the f32 GEMMs (24-bit operands, six cross terms) + f32 recurrences" if nn_math == "bf16x3" else "f32"),
             "nn_math_effective": head["nn_math"], "nn_path": head["nn_path"],
             "data": "synthetic 48 kHz mono (seeded noise floor + 500-2000 Hz harmonic bursts; every lane a different stream), random-init NSNet2 weights seed 7",
             "config": {"workload": f"full pipeline (window->STFT->NSNet2->iSTFT->FFT1024 band->VAD decision), "
@@ -695,6 +713,7 @@ def main():
             "parity_note": "parity unpinned: the checker is oracle/, a CPU restatement of the reference; the reference holds no "
                            "golden vector for FFT / NSNet2 / band sums / segments and cannot be built here (DESIGN.md section 4)",
             "emulated": emulated,
+            "emulated24": emulated24,
             "headline_as_stereo": stereo,
             "host_vad_threads": vad_threads,
             "gpu_stage_wall_ms": head["gpu_wall_ms"],
@@ -708,7 +727,8 @@ def main():
         if not args.no_extra and world == 1:
             out["extra"] = side_measurements(pkg, fv, ctx, torch, dev)
         print(json.dumps(out))
-        if not self_check or not self_check["ok"] or (emulated and not emulated["self_check"]["ok"]):
+        if not self_check or not self_check["ok"] or (emulated and not emulated["self_check"]["ok"]) or \
+                (emulated24 and not emulated24["self_check"]["ok"]):
             print("bench.py: SELF-CHECK FAILED: the timed configuration does not match the oracle", file=sys.stderr)
             sys.exit(1)
     if world > 1:

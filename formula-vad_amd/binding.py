@@ -378,11 +378,11 @@ class Context:
     def set_nn_math(self, mode):
         """'f32' (default: the reference's arithmetic) or 'f16x3' (emulation on the f16 matrix cores): arithmetic of the
         NSNet2 matrix products at every batch size; returns the previous mode"""
-        m = {"f32": 0, "f16x3": 1}[mode]
+        m = {"f32": 0, "f16x3": 1, "bf16x3": 2}[mode]
         prev = lib().fvad_ctx_set_nn_math(self.h, m)
         if prev < 0:
             self._ck(prev, "fvad_ctx_set_nn_math")
-        return ("f32", "f16x3")[prev]
+        return ("f32", "f16x3", "bf16x3")[prev]
 
     def set_nn_math_raw(self, mode):
         return self._ck(lib().fvad_ctx_set_nn_math(self.h, int(mode)), "fvad_ctx_set_nn_math")
@@ -392,7 +392,7 @@ class Context:
         m = lib().fvad_ctx_nn_math_effective(self.h)
         if m < 0:
             self._ck(m, "fvad_ctx_nn_math_effective")
-        return ("f32", "f16x3")[m]
+        return ("f32", "f16x3", "bf16x3")[m]
 
     def last_nn_path(self):
         return lib().fvad_ctx_last_nn_path(self.h).decode()

@@ -122,7 +122,7 @@ int upload_model(fvad_ctx* ctx)
     m.generic = false;
     m.w_a1 = 400; m.w_gi = 1200; m.w_h = 400; m.w_f = 640;
     const int H = 400;
-    std::vector<float> f;
+    std::vector<float> f, gi1f_folded; // gi1f_folded: fc1 folded into GRU1's input projection, [1200][161]
     int rc;
     // fc1: 161 -> 400, K padded to 176 (11 super-steps), one block of 25 tiles
     pack_panel(w.fc1_w.data(), 400, 161, 1, 25, 11, f);
@@ -157,7 +157,9 @@ int upload_model(fvad_ctx* ctx)
         // projection is one linear map 161 -> 1200: W' = W_ih W_fc1, b' = W_ih b_fc1 + Wb.  Folded
         // once on the host in double and rounded to f32: algebraically exact, differs from the
         // two-GEMM form only by round-off (~1e-7 rel), and removes 12 % of the network's FLOPs.
-        std::vector<float> wf((size_t)1200 * 161), bf(1200);
+        std::vector<float>& wf = gi1f_folded;
+        wf.assign((size_t)1200 * 161, 0.0f);
+        std::vector<float> bf(1200);
         std::vector<double> row(161);
         for (int o = 0; o < 1200; ++o) {
             std::fill(row.begin(), row.end(), 0.0);
@@ -264,6 +266,17 @@ int upload_model(fvad_ctx* ctx)
         // the scales are finite powers of two whenever the weights and the bounds are finite
         // ... and the split keeps its 22 bits only for values within ~18 binades below the bound: a model whose l1
         // bounds are absurdly loose (activations expected around 1 against a bound above 2^17) keeps the f32 kernels
+        // bf16x3 layouts of the same five layers (kernels_b3.hip): three exact pieces per weight, no scales, no bounds
+        pack_panel_b3(tile_major_rows(gi1f_folded.data(), 161).data(), 1200, 161, 5, 15, f);
+        if ((rc = upload(ctx, m.gi1f_b3, f))) return rc;
+        pack_panel_b3(g2.data(), 1200, 400, 5, 15, f);
+        if ((rc = upload(ctx, m.gi2_b3, f))) return rc;
+        pack_panel_b3(w.fc2_w.data(), 600, 400, 4, 10, f);
+        if ((rc = upload(ctx, m.fc2_b3, f))) return rc;
+        pack_panel_b3(w.fc3_w.data(), 600, 600, 4, 10, f);
+        if ((rc = upload(ctx, m.fc3_b3, f))) return rc;
+        pack_panel_b3(w.fc4_w.data(), 161, 600, 1, 12, f);
+        if ((rc = upload(ctx, m.fc4_b3, f))) return rc;
         m.h3_ok = std::isfinite(b_fc3) && b_fc3 <= 131072.0 && b_fc2 <= 131072.0;
         for (const DeviceModel::H3Scale* sc : {&m.h3_gi1f, &m.h3_gi2, &m.h3_fc2, &m.h3_fc3, &m.h3_fc4, &m.h3_r1, &m.h3_r2})
             m.h3_ok = m.h3_ok && std::isfinite(sc->sw) && std::isfinite(sc->sx) && sc->sw > 0.0f && sc->sx > 0.0f &&
@@ -289,6 +302,24 @@ int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
     const long need = ((n_chunks + 767) / 768) * 768; // 768 = lcm of every batch padding (32, 128, 192 -> 384, 256)
     const DeviceModel& dm = ctx->dm;
     const bool same_widths = ws.w_a1 == dm.w_a1 && ws.w_gi == dm.w_gi && ws.w_h == dm.w_h && ws.w_f == dm.w_f;
+    // bf16x3 mode: h1 / h2 and the fc2 / fc3 outputs as three-piece fragments (13 / 19 K-steps of 3 KB per 16 rows),
+    // allocated only for contexts that run in that mode
+    if (nn_math_effective(ctx) == FVAD_NN_MATH_BF16X3 && (need > ws.b3_cap_chunks || T > ws.b3_T)) {
+        hipStreamSynchronize(ctx->stream);
+        float** b3bufs[] = {&ws.b3_hs1, &ws.b3_hs2, &ws.b3_f2, &ws.b3_f3};
+        for (float** b : b3bufs) { if (*b) hipFree(*b); *b = nullptr; }
+        const long G3 = std::max(need, ws.b3_cap_chunks);
+        const int T3 = std::max(T, ws.b3_T);
+        const size_t rows3 = (size_t)G3 * T3;
+        int rc3;
+        if ((rc3 = dev_alloc(ctx, &ws.b3_hs1, rows3 * 624, true))) return rc3;
+        if ((rc3 = dev_alloc(ctx, &ws.b3_hs2, rows3 * 624, true))) return rc3;
+        if ((rc3 = dev_alloc(ctx, &ws.b3_f2, rows3 * 912, true))) return rc3;
+        if ((rc3 = dev_alloc(ctx, &ws.b3_f3, rows3 * 912, true))) return rc3;
+        ws.b3_cap_chunks = G3;
+        ws.b3_T = T3;
+        ws.generation++;
+    }
     if (need <= ws.cap_chunks && T <= ws.T && same_widths) return FVAD_OK;
     hipStreamSynchronize(ctx->stream);
     free_workspace_nn(ws);
@@ -404,8 +435,10 @@ int nn_math_effective(const fvad_ctx* ctx)
 {
     const Tuning& tn = ctx->tune;
     const int want = tn.nn_math_force >= 0 ? tn.nn_math_force : ctx->nn_math;
-    if (want != FVAD_NN_MATH_F16X3) return FVAD_NN_MATH_F32;
+    if (want == FVAD_NN_MATH_F32) return FVAD_NN_MATH_F32;
     if (!tn.gru_kernel.empty() || !tn.gemm_kernel.empty()) return FVAD_NN_MATH_F32;
+    if (want == FVAD_NN_MATH_BF16X3) // exact three-piece splits: no bounds to satisfy, only the baseline dimensions
+        return (ctx->dm.loaded && ctx->dm.generic) ? FVAD_NN_MATH_F32 : FVAD_NN_MATH_BF16X3;
     if (ctx->dm.loaded && !ctx->dm.h3_ok) return FVAD_NN_MATH_F32;
     return FVAD_NN_MATH_F16X3;
 }
@@ -426,6 +459,16 @@ static long padded_batch(const fvad_ctx* ctx, long n, int T, int skip)
         const double ca = (double)((a / 192 + cu - 1) / cu), cb = 0.76 * (double)((b / 128 + cu - 1) / cu);
         long pick = (a == b || tn.h3_waves == 12) ? a : (tn.h3_waves == 8) ? b : (cb <= ca ? b : a);
         if (!fits(pick)) pick = fits(a) ? a : (pick + 255) / 256 * 256; // 16 row-tile groups: fits for every T
+        return pick;
+    }
+    if (nn_math_effective(ctx) == FVAD_NN_MATH_BF16X3) {
+        // kernels_b3.hip GEMMs (16 row tiles per panel) + gru_rec3: a multiple of 128 sequences, 384 when its 12-wave
+        // recurrence is cheaper; every launch, small ones too
+        auto fits = [&](long np) { return ((np / 16) * T) % 16 == 0 && ((np / 16) * (T - skip)) % 16 == 0; };
+        const double cost_a = std::min(std::min(gru_cost(a, 12, cu), gru_cost(a, 8, cu)), gru_cost(a, 4, cu));
+        const double cost_b = std::min(gru_cost(b, 8, cu), gru_cost(b, 4, cu));
+        long pick = (a == b || cost_a < cost_b) ? a : b;
+        if (!fits(pick)) pick = fits(a) ? a : (pick + 255) / 256 * 256;
         return pick;
     }
     // the weight-stationary recurrence and the small-batch GEMMs (64-row workgroups over 54 n and 50 n rows)
@@ -604,8 +647,45 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     int rc = 0;
     const Tuning& tn = ctx->tune;
     const char* force = tn.gemm_kernel.empty() ? nullptr : tn.gemm_kernel.c_str(); // "v1" (small-batch GEMM) / "v3" / "v3nofold"
-    const bool h3 = nn_math_effective(ctx) == FVAD_NN_MATH_F16X3;
-    if (h3 && n_pad % 128) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "f16x3 kernels need a batch padded to 128 sequences");
+    const int math = nn_math_effective(ctx);
+    const bool h3 = math == FVAD_NN_MATH_F16X3, b3 = math == FVAD_NN_MATH_BF16X3;
+    if ((h3 || b3) && n_pad % 128) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "the emulated kernels need a batch padded to 128 sequences");
+    if (b3) {
+        // bf16x3: the five dense layers as six bf16 MFMAs per product on exact three-piece splits (kernels_b3.hip), the
+        // two recurrences on the f32 matrix cores (gru_rec3, which writes h a second time as three-piece fragments)
+        if (!ws.b3_hs1 || n_pad > ws.b3_cap_chunks || T > ws.b3_T) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "bf16x3 workspace not allocated");
+        auto gemm_b3 = [&](const float* A, int in_ts, int a_ld, const DevBuf& W, const float* b, float* Cc, int out, int c_ld, int seq_T,
+                           long row_tiles, int nt, int nblk, int K, int act, int valid, int mT, int mskip) {
+            return fvad_launch_panel_gemm_b3(A, in_ts, a_ld, W.p, b, Cc, out, c_ld, seq_T, row_tiles, nt, nblk, K, act, valid, mT, mskip, ctx->n_cu, st);
+        };
+        const int waves = n_pad % 192 == 0 ? 12 : 8;
+        const long G = n_pad / 16;
+        ctx->last_nn_path = std::string("bf16x3: panel_gemm_b3 (fc1 folded) + gru_rec3<") + std::to_string(waves) + "> (f32 recurrences)";
+        time_begin(ctx, "gru1_in_gemm_fc1folded");
+        rc |= gemm_b3(ws.feat, 0, kFeatStride, m.gi1f_b3, m.gi1f_bzr.p, ws.gi, 0, 1200, T, G * T, 15, 5, 161, FVAD_ACT_NONE, 75, 0, 0);
+        time_end(ctx);
+        time_begin(ctx, "gru1_rec");
+        rc |= fvad_launch_gru_rec3(ws.gi, m.r1v2.p, m.br1.p, ws.h1, n_pad, T, waves, st, ws.b3_hs1);
+        time_end(ctx);
+        time_begin(ctx, "gru2_in_gemm");
+        rc |= gemm_b3(ws.b3_hs1, 1, 13, m.gi2_b3, m.gi2_bzr.p, ws.gi, 0, 1200, T, G * T, 15, 5, 400, FVAD_ACT_NONE, 75, 0, 0);
+        time_end(ctx);
+        time_begin(ctx, "gru2_rec");
+        rc |= fvad_launch_gru_rec3(ws.gi, m.r2v2.p, m.br2.p, ws.h2, n_pad, T, waves, st, ws.b3_hs2);
+        time_end(ctx);
+        time_begin(ctx, "fc2_gemm");
+        rc |= gemm_b3(ws.b3_hs2, 1, 13, m.fc2_b3, m.fc2h3_b.p, ws.b3_f2, 2, 19, T - skip, G * (T - skip), 10, 4, 400, FVAD_ACT_RELU, 38, skip ? T : 0, skip);
+        time_end(ctx);
+        time_begin(ctx, "fc3_gemm");
+        rc |= gemm_b3(ws.b3_f2, 1, 19, m.fc3_b3, m.fc3h3_b.p, ws.b3_f3, 2, 19, T - skip, G * (T - skip), 10, 4, 600, FVAD_ACT_RELU, 38, 0, 0);
+        time_end(ctx);
+        time_begin(ctx, "fc4_gemm");
+        rc |= gemm_b3(ws.b3_f3, 1, 19, m.fc4_b3, m.fc4h3_b.p, ws.gains, 0, kFeatStride, T - skip, G * (T - skip), 12, 1, 600, FVAD_ACT_SIGMOID, 11, 0, 0);
+        time_end(ctx);
+        if (rc) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "no kernel instance for this layer shape");
+        FVAD_HIP(ctx, hipGetLastError());
+        return FVAD_OK;
+    }
     const bool big = h3 || (force ? force[1] != '1' : (tn.reproducible || n_pad >= 2048));
     if (big && rows % 256 == 0 && rows_out % 256 == 0) {
         // The persistent kernel: one workgroup per CU walking all (row panel, column block) items; 15-, 13- and
@@ -872,6 +952,7 @@ static int apply_option(fvad_ctx* ctx, const std::string& name, const char* valu
         if (unset) tn.nn_math_force = -1;
         else if (v == "f32") tn.nn_math_force = FVAD_NN_MATH_F32;
         else if (v == "f16x3") tn.nn_math_force = FVAD_NN_MATH_F16X3;
+        else if (v == "bf16x3") tn.nn_math_force = FVAD_NN_MATH_BF16X3;
         else return FVAD_ERR_INVALID_ARGUMENT;
     } else if (name == "gru_kernel") {
         if (!unset && v != "v3w12" && v != "v3w8" && v != "v3w4" && v != "v4w8" && v != "v5w0" && v != "v6w0") return FVAD_ERR_INVALID_ARGUMENT;
@@ -1013,6 +1094,7 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     if (ws.hx) hipFree(ws.hx);
     if (ws.ws_sync) hipFree(ws.ws_sync);
     if (ws.ws_fallbacks) hipFree(ws.ws_fallbacks);
+    for (float* b : {ws.b3_hs1, ws.b3_hs2, ws.b3_f2, ws.b3_f3}) if (b) hipFree(b);
     for (Workspace::PinRing* r : {&ws.ring_in, &ws.ring_out}) {
         if (r->base) hipHostFree(r->base);
         for (hipEvent_t& e : r->ev) if (e) hipEventDestroy(e);
@@ -1034,6 +1116,7 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
     DeviceModel& m = ctx->dm;
     DevBuf* gbufs[] = {&m.g_fc1_w, &m.g_fc1_b, &m.g_gi1_w, &m.g_gi1_b, &m.g_r1, &m.g_br1, &m.g_gi2_w, &m.g_gi2_b, &m.g_r2, &m.g_br2,
                        &m.g_fc2_w, &m.g_fc2_b, &m.g_fc3_w, &m.g_fc3_b, &m.g_fc4_w, &m.g_fc4_b,
+                       &m.gi1f_b3, &m.gi2_b3, &m.fc2_b3, &m.fc3_b3, &m.fc4_b3,
                        &m.gi1f_h3, &m.gi2_h3, &m.fc2_h3, &m.fc3_h3, &m.fc4_h3, &m.fc2h3_b, &m.fc3h3_b, &m.fc4h3_b, &m.r1_h3, &m.r2_h3};
     for (DevBuf* b : gbufs) if (b->p) hipFree(b->p);
     DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.s_gi1f_w, &m.s_gi2_w, &m.s_fc4_w, &m.s_fc4_b, &m.s_w2frag, &m.s_bw2, &m.br1, &m.br2,
@@ -1104,7 +1187,7 @@ int fvad_ctx_copy_to_host(fvad_ctx* ctx, void* dst_host, const void* src_device,
 
 int fvad_ctx_set_nn_math(fvad_ctx* ctx, int mode)
 {
-    if (!ctx || (mode != FVAD_NN_MATH_F32 && mode != FVAD_NN_MATH_F16X3)) return FVAD_ERR_INVALID_ARGUMENT;
+    if (!ctx || (mode != FVAD_NN_MATH_F32 && mode != FVAD_NN_MATH_F16X3 && mode != FVAD_NN_MATH_BF16X3)) return FVAD_ERR_INVALID_ARGUMENT;
     const int prev = ctx->nn_math;
     if (prev != mode) ctx->ws.generation++; // a captured launch sequence holds the other kernels
     ctx->nn_math = mode;

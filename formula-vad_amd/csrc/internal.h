@@ -44,6 +44,8 @@ float h3_weight_scale(const float* W, size_t n);      // power of two: max |W| *
 float h3_activation_scale(double bound);              // power of two: |x| <= bound -> |x * sx| <= 2^14
 void pack_panel_h3(const float* W, int N, int K, int n_blocks, int NT, float sw, std::vector<float>& out);
 void pack_gru_r_h3(const float* R, int H, float sw, std::vector<float>& out);
+// bf16x3 layout (kernels_b3.hip): three bf16 pieces per weight, no scale
+void pack_panel_b3(const float* W, int N, int K, int n_blocks, int NT, std::vector<float>& out);
 
 // ------------------------------------------------------------------ device model
 struct DevBuf {
@@ -63,6 +65,8 @@ struct DeviceModel {
     struct H3Scale { float sw = 1.0f, sx = 1.0f; };
     H3Scale h3_gi1f, h3_gi2, h3_fc2, h3_fc3, h3_fc4, h3_r1, h3_r2;
     bool h3_ok = false; // every weight and bound finite: the f16x3 kernels may be used
+    // bf16x3 layouts of the five dense layers (kernels_b3.hip); biases are shared with the other families
+    DevBuf gi1f_b3, gi2_b3, fc2_b3, fc3_b3, fc4_b3;
     bool loaded = false;
     // A model of other dimensions than NSNet2-baseline's 161/400/400/600/600 (NSNet2.init binds whatever file the
     // configuration names, NSNet2.zig:53-112): run by run_nn_generic on kernels that take their sizes at run time.
@@ -83,6 +87,10 @@ struct Workspace {
     long cap_chunks = 0; // padded chunk capacity (multiple of 768: covers every batch padding)
     int T = 0;
     int w_a1 = 0, w_gi = 0, w_h = 0, w_f = 0; // row widths the buffers were allocated for (DeviceModel::w_*)
+    // bf16x3 mode only (allocated when a context first runs in it): h1 / h2 and the fc2 / fc3 outputs as three-piece
+    // fragments, 13 and 19 K-steps of 3 KB per 16 rows
+    float *b3_hs1 = nullptr, *b3_hs2 = nullptr, *b3_f2 = nullptr, *b3_f3 = nullptr;
+    long b3_cap_chunks = 0; int b3_T = 0;
     ChunkDesc* descs = nullptr;
     ChunkDesc* h_descs = nullptr; // pinned, two slots of cap_chunks descriptors
     hipEvent_t desc_ev[2] = {nullptr, nullptr}; // slot's upload has left the host

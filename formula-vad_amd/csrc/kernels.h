@@ -117,7 +117,13 @@ int fvad_launch_gru_ws2(const float* gi1, const float* R1frag, const float* bR1,
 int fvad_launch_gru_gen(const float* gi, int gi_ld, const float* R2frag, const float* bR, float* hout, int h_ld,
                         long n_seq_pad, int T, int J, hipStream_t stream);
 int fvad_launch_gru_rec3(const float* gi, const float* R2frag, const float* bR, float* hout,
-                         long n_seq_pad, int T, int waves, hipStream_t stream);
+                         long n_seq_pad, int T, int waves, hipStream_t stream, float* hs3 = nullptr);
+// bf16x3 form of the dense layers (kernels_b3.hip): Wfrag from pack_panel_b3, K = true reduction length.
+// in_ts: A in the three-piece tiled layout TS3 (a_ld = K-steps per row tile) or row-major f32 [sequence][seq_T][a_ld];
+// out: 0 row-major f32 [sequence][seq_T][c_ld], 2 TS3 (c_ld K-steps per row tile); row_tiles = output row tiles of 16 rows
+int fvad_launch_panel_gemm_b3(const float* A, int in_ts, int a_ld, const float* Wfrag, const float* bias, float* C,
+                              int out, int c_ld, int seq_T, long row_tiles, int nt, int n_blocks, int K, int act,
+                              int n_valid_tiles, int map_T, int map_skip, int n_wg, hipStream_t stream);
 
 // K1: per chunk: RMS, decimate, STFT-320, log-power features (+ warm-up rows)
 void fvad_launch_stft(const ChunkDesc* descs, int n_chunks, FftTables tb, float* feat,

@@ -263,6 +263,12 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
                 }
                 rd += NT * 2048;
             }
+            // the last step's look-ahead reads are still in flight and the compiler does not know (it considers the
+            // ring registers dead from here on): wait for them while they are still allocated
+            SFor<0, D>::run([&](auto tc) {
+                constexpr int k = decltype(tc)::value;
+                lds_wait2<0>(wh[k], wl[k]);
+            });
             __syncthreads();
             buf ^= 1;
         }
@@ -358,24 +364,9 @@ int fvad_launch_panel_gemm_h3(const float* A, int in_ts, int a_ld, const float* 
     unsigned n_items = (unsigned)((row_tiles / 16) * n_blocks);
     unsigned grid = n_items < (unsigned)n_wg ? n_items : (unsigned)n_wg;
     const float bias_scale = sx * sw, out_scale = 1.0f / (sx * sw);
-    // fc2 / fc3 (10-tile column blocks; fc4's sigmoid epilogue spills in this form): three row tiles per wavefront when the row tiles divide by
-    // 24 -- the accumulator budget of a 15-tile block, 1.5 x the MFMAs per weight fragment read and per phase
-    // barrier (measured: -5 %); the per-row arithmetic is the same, so results do not depend on which form runs
-    if (row_tiles % 24 == 0 && in_ts && nt == 10) {
-        n_items = (unsigned)((row_tiles / 24) * n_blocks);
-        grid = n_items < (unsigned)n_wg ? n_items : (unsigned)n_wg;
-#define CASE3(NT_, ACT_, SP_, D_, OUT_)                                                                         \
-        if (nt == NT_ && act == ACT_ && out == OUT_) {                                                          \
-            hipLaunchKernelGGL((panel_gemm_h3_kernel<NT_, 3, ACT_, SP_, D_, 8, true, OUT_>), dim3(grid), dim3(512), 0, \
-                               stream, A, a_ld, Wfrag, bias, C, c_ld, seq_T, S_steps, k_tiles, n_blocks,        \
-                               n_valid_tiles, map_T, map_skip, n_items, sx, bias_scale, out_scale, out_sx);     \
-            return 0;                                                                                           \
-        }
-        CASE3(10, FVAD_ACT_RELU, 3, 5, 2)
-#undef CASE3
-        n_items = (unsigned)((row_tiles / 16) * n_blocks);
-        grid = n_items < (unsigned)n_wg ? n_items : (unsigned)n_wg;
-    }
+    // (A three-row-tile form of the fc2 / fc3 instance was 5 % faster, but it sits one register over the 256-register cap:
+    // one spilled VGPR.  A spill is not slow here, it is unsafe -- the inline ds_reads and the LDS-DMA land in registers
+    // the compiler believes it may reuse -- so the form is gone.)
 #define CASEH(NT_, ACT_, SP_, D_, IN_, OUT_)                                                                  \
     if (nt == NT_ && act == ACT_ && (in_ts != 0) == IN_ && out == OUT_) {                                     \
         hipLaunchKernelGGL((panel_gemm_h3_kernel<NT_, 2, ACT_, SP_, D_, 8, IN_, OUT_>), dim3(grid), dim3(512), 0, \

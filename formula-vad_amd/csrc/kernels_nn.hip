@@ -131,15 +131,16 @@ __global__ __launch_bounds__(WAVES * 64) void panel_gemm_kernel(
     const int valid_t = n_valid_tiles - nblk * NT; // tiles past the output's width are computed but not stored
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        if (t >= valid_t) break;
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(b_ptr + 16 * t);
-        f32x4 v = acc[t] + b4;
-        if (ACT == FVAD_ACT_RELU) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        } else if (ACT == FVAD_ACT_SIGMOID) {
-            v.x = act_sigmoid(v.x); v.y = act_sigmoid(v.y); v.z = act_sigmoid(v.z); v.w = act_sigmoid(v.w);
+        if (t < valid_t) { // (no `break`: the loop must unroll completely, or the accumulators end up in scratch)
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(b_ptr + 16 * t);
+            f32x4 v = acc[t] + b4;
+            if (ACT == FVAD_ACT_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            } else if (ACT == FVAD_ACT_SIGMOID) {
+                v.x = act_sigmoid(v.x); v.y = act_sigmoid(v.y); v.z = act_sigmoid(v.z); v.w = act_sigmoid(v.w);
+            }
+            *reinterpret_cast<f32x4*>(c_ptr + 16 * t) = v;
         }
-        *reinterpret_cast<f32x4*>(c_ptr + 16 * t) = v;
     }
 }
 
@@ -324,7 +325,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
                 constexpr int t = decltype(tc)::value;
                 lds_read_b128<t * 1024>(w[t], rd);
             });
-            for (int s = 0; s < cnt; ++s) {
+            // one super-step; LAST: the last one of the phase
+            auto super_step = [&](int s, auto last_c) {
+                constexpr bool LAST = decltype(last_c)::value;
                 const int sg = s0 + s;
                 f32x4 a1[RT];
                 if (sg == 0) {
@@ -355,21 +358,29 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
                         for (int rt = 0; rt < RT; ++rt) acc[rt][t] = MFMA16(w[t].w, a0[rt].w, acc[rt][t]);
                     }
                 };
-                // The read of tile t for the next super-step follows tile t's MFMAs, so every wait below
-                // sees exactly NT-1 younger reads in flight.  In the last step of a phase the next data
-                // is not in LDS yet (other buffer, after the barrier): read this step's tile again so the
-                // count stays uniform; the post-barrier reads overwrite w[].
-                const unsigned rdn = (s + 1 < cnt) ? rd : rd - NT * 1024;
+                // The read of tile t for the next super-step follows tile t's MFMAs, so every wait below sees exactly
+                // NT-1 younger reads in flight.  In the last step of a phase the next data is not in LDS yet (other
+                // buffer, after the barrier): nothing is read ahead and the waits count down -- no read may still be in
+                // flight when the phase ends, because the compiler does not know about these reads and reuses their
+                // registers at once (round 3: a late read landing in an epilogue address register faulted the bf16x3
+                // form of this loop; here it had never shown, by timing only).
                 StaticFor<0, NT>::run([&](auto tc) {
                     constexpr int t = decltype(tc)::value;
-                    lds_wait<WAITN>(w[t]);
-                    mfmas(tc);
-                    lds_read_b128<(NT + t) * 1024>(w[t], rdn);
+                    if constexpr (LAST) {
+                        lds_wait<((NT - 1 - t) < 15 ? (NT - 1 - t) : 15)>(w[t]);
+                        mfmas(tc);
+                    } else {
+                        lds_wait<WAITN>(w[t]);
+                        mfmas(tc);
+                        lds_read_b128<(NT + t) * 1024>(w[t], rd);
+                    }
                 });
                 rd += NT * 1024;
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) a0[rt] = a1[rt];
-            }
+            };
+            for (int s = 0; s + 1 < cnt; ++s) super_step(s, std::false_type{});
+            super_step(cnt - 1, std::true_type{});
             __syncthreads(); // next phase's weights (and bias block) landed; this buffer is free again
             buf ^= 1;
         }
@@ -492,11 +503,14 @@ __device__ __forceinline__ void gru3_issue_slab(const float* __restrict__ src, f
     }
 }
 
-template <int WAVES, int D>
+// TS3: h is written a second time as three bf16 pieces per value in the tiled fragment layout of kernels_b3.hip
+// (hs3: [16-sequence group * T + t][13 K-steps][h, m, l][64 lanes][8 bf16]) for the bf16x3 GEMM that reads it; the
+// recurrence itself keeps reading its own f32 rows
+template <int WAVES, int D, bool TS3>
 __global__ __launch_bounds__(WAVES * 64) void gru_rec3_kernel(const float* __restrict__ gi,
                                                               const float* __restrict__ R2frag,
                                                               const float* __restrict__ bR,
-                                                              float* hout, int T)
+                                                              float* hout, int T, float* hs3)
 {
     __shared__ __attribute__((aligned(16))) float slab[2][GRU2_SLAB];
     typedef __attribute__((address_space(3))) float lds_float;
@@ -524,6 +538,36 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec3_kernel(const float* __res
     };
     const unsigned slab_addr[2] = {(unsigned)(uintptr_t)(lds_float*)slab[0] + (unsigned)lane * 16u,
                                    (unsigned)(uintptr_t)(lds_float*)slab[1] + (unsigned)lane * 16u};
+    // unit tile J of h_t as three bf16 pieces (x = h + m + l exactly): half (J & 1) of K-step J / 2's fragments, 8
+    // bytes per piece and lane; the last tile also writes the zero upper half of K-step 12
+    __attribute__((address_space(1))) char* hs_w = nullptr;
+    if (TS3) hs_w = (__attribute__((address_space(1))) char*)(hs3 + (size_t)(blockIdx.x * WAVES + wave) * T * (13 * 768));
+    auto store_split3 = [&](__attribute__((address_space(1))) char* hs_t, int J, const f32x4& h) {
+        typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+        typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+        b16x4 ph, pm, pl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = h[r];
+            const __bf16 a = (__bf16)v;
+            const float ra = v - (float)a;
+            const __bf16 b = (__bf16)ra;
+            ph[r] = a; pm[r] = b; pl[r] = (__bf16)(ra - (float)b);
+        }
+        unsigned o = (unsigned)lane * 16u;
+        asm volatile("" : "+v"(o));
+        __attribute__((address_space(1))) char* dst = hs_t + (J >> 1) * 3072 + (J & 1) * 8 + o;
+        if (J == GRU_J - 1) {
+            const b16x4 z4 = (b16x4){0, 0, 0, 0};
+            *(__attribute__((address_space(1))) b16x8*)dst = __builtin_shufflevector(ph, z4, 0, 1, 2, 3, 4, 5, 6, 7);
+            *(__attribute__((address_space(1))) b16x8*)(dst + 1024) = __builtin_shufflevector(pm, z4, 0, 1, 2, 3, 4, 5, 6, 7);
+            *(__attribute__((address_space(1))) b16x8*)(dst + 2048) = __builtin_shufflevector(pl, z4, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+            *(__attribute__((address_space(1))) b16x4*)dst = ph;
+            *(__attribute__((address_space(1))) b16x4*)(dst + 1024) = pm;
+            *(__attribute__((address_space(1))) b16x4*)(dst + 2048) = pl;
+        }
+    };
 
     gru3_issue_slab<WAVES>(R2frag, slab[0], wave, (unsigned)lane * 16u);
 
@@ -542,6 +586,7 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec3_kernel(const float* __res
             h[r] = (1.0f - z) * n + z * 0.0f;
         }
         *(__attribute__((address_space(1))) f32x4*)(h_w + 64 * J + h_off) = h;
+        if (TS3) store_split3(hs_w, J, h);
     }
     __syncthreads(); // drains the LDS-DMA (vmcnt) and publishes slab 0
     int buf = 0;
@@ -627,9 +672,14 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec3_kernel(const float* __res
                 asm volatile("" : "+v"(o));
                 *(__attribute__((address_space(1))) f32x4*)(h_out + 64 * J + o) = h;
             }
-            // next slab landed (everything older than the h store has retired) and everyone is done
+            // next slab landed (everything older than the h store(s) has retired) and everyone is done
             // reading this one (all ds_reads were waited for above)
-            asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+            if (TS3) {
+                store_split3(hs_w + (size_t)t * (13 * 3072), J, h);
+                asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+            }
             buf ^= 1;
         }
     }
@@ -903,18 +953,20 @@ int fvad_launch_gru_gen(const float* gi, int gi_ld, const float* R2frag, const f
     return 0;
 }
 
+// hs3 != nullptr: h is also written as three-piece bf16 fragments (TS3, kernels_b3.hip)
 int fvad_launch_gru_rec3(const float* gi, const float* R2frag, const float* bR, float* hout,
-                         long n_seq_pad, int T, int waves, hipStream_t stream)
+                         long n_seq_pad, int T, int waves, hipStream_t stream, float* hs3)
 {
-    if (waves == 12) {
-        hipLaunchKernelGGL((gru_rec3_kernel<12, 2>), dim3((unsigned)(n_seq_pad / 192)), dim3(768), 0, stream, gi, R2frag, bR, hout, T);
-    } else if (waves == 8) {
-        hipLaunchKernelGGL((gru_rec3_kernel<8, 2>), dim3((unsigned)(n_seq_pad / 128)), dim3(512), 0, stream, gi, R2frag, bR, hout, T);
-    } else if (waves == 4) {
-        hipLaunchKernelGGL((gru_rec3_kernel<4, 2>), dim3((unsigned)(n_seq_pad / 64)), dim3(256), 0, stream, gi, R2frag, bR, hout, T);
-    } else {
-        return -1;
+#define REC3(W_)                                                                                                          \
+    if (waves == W_) {                                                                                                    \
+        if (hs3) hipLaunchKernelGGL((gru_rec3_kernel<W_, 2, true>), dim3((unsigned)(n_seq_pad / (16 * W_))), dim3(64 * W_), 0, stream, gi, R2frag, bR, hout, T, hs3); \
+        else hipLaunchKernelGGL((gru_rec3_kernel<W_, 2, false>), dim3((unsigned)(n_seq_pad / (16 * W_))), dim3(64 * W_), 0, stream, gi, R2frag, bR, hout, T, hs3); \
+        return 0;                                                                                                         \
     }
-    return 0;
+    REC3(12)
+    REC3(8)
+    REC3(4)
+#undef REC3
+    return -1;
 }
 

@@ -323,6 +323,49 @@ void pack_gru_r_h3(const float* R, int H, float sw, std::vector<float>& out)
                     }
 }
 
+// ---- bf16x3 layout (kernels_b3.hip): every weight as three bf16 pieces, W = h + m + l exactly
+// f32 -> bf16 bits, round to nearest even (what v_cvt_pk_bf16_f32 does on the device; NaN stays NaN)
+static uint16_t f32_to_bf16_bits(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x0040u); // quiet NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf16_bits_to_f32(uint16_t h)
+{
+    const uint32_t u = (uint32_t)h << 16;
+    float v;
+    memcpy(&v, &u, 4);
+    return v;
+}
+
+// [n_blocks][S32][NT][h, m, l][64 lanes][8 bf16], S32 = ceil(ceil(K / 16) / 2) K-steps of 32 slots, kernels_h3's slot order
+void pack_panel_b3(const float* W, int N, int K, int n_blocks, int NT, std::vector<float>& out)
+{
+    const int S = ((K + 15) / 16 + 1) / 2;
+    out.assign((size_t)n_blocks * S * NT * 768, 0.0f);
+    for (int b = 0; b < n_blocks; ++b)
+        for (int s = 0; s < S; ++s)
+            for (int t = 0; t < NT; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int n = (b * NT + t) * 16 + (lane & 15);
+                        const int k = h3_slot_k(s, lane >> 4, j);
+                        if (n >= N || k >= K) continue;
+                        const float w = W[(size_t)n * K + k];
+                        const uint16_t h = f32_to_bf16_bits(w);
+                        const float r1 = w - bf16_bits_to_f32(h);
+                        const uint16_t m = f32_to_bf16_bits(r1);
+                        const uint16_t l = f32_to_bf16_bits(r1 - bf16_bits_to_f32(m));
+                        const size_t d = (((size_t)b * S + s) * NT + t) * 768 + (size_t)lane * 4 + (size_t)(j >> 1);
+                        put_half(out, d, j & 1, h);
+                        put_half(out, d + 256, j & 1, m);
+                        put_half(out, d + 512, j & 1, l);
+                    }
+}
+
 // ------------------------------------------------------------------ ONNX (protobuf) reader
 // Wire format only: varint, 64-bit, length-delimited, 32-bit.  Message/field numbers from
 // onnx.proto3: ModelProto.graph = 7; GraphProto.node = 1, .initializer = 5; NodeProto.input = 1,

@@ -280,11 +280,16 @@ int fvad_nsnet2_forward(fvad_ctx *ctx, const float *features, size_t n_seq, size
  *     (kernels_h3.hip), batches padded to 128 sequences.  Measured against float64 as close as the f32 kernels on the
  *     models tried (tests), 2.1 x their speed at saturating batches; differs from them by ~1e-6 in the gains.  A
  *     model whose weights are not finite or whose l1 activation bounds exceed 2^17 is not eligible and keeps f32.
+ *   FVAD_NN_MATH_BF16X3 (opt-in, an emulation that is NOT narrower than f32): the five dense layers with every f32
+ *     operand as three bf16 pieces (x = h + m + l exactly: all 24 significand bits, f32's exponent range, no scales
+ *     or bounds) and the six significant cross terms as six bf16 MFMAs with f32 accumulation per product
+ *     (kernels_b3.hip); the two GRU recurrences stay on the f32 matrix cores.  Batches padded to 128 sequences.
+ *     NSNet2-baseline dimensions only (other models keep f32).
  * fvad_ctx_set_nn_math returns the previous setting or a negative status.  fvad_ctx_nn_math_effective returns what
  * the context actually uses with the model it has loaded (the request, demoted to F32 for an ineligible model or
  * while an f32 kernel variant is forced through fvad_ctx_set_option); fvad_ctx_last_nn_path names the kernels the
  * last NSNet2 pass ran, e.g. "f32: panel_gemm3 (fc1 folded) + gru_rec3<12>". */
-enum { FVAD_NN_MATH_F32 = 0, FVAD_NN_MATH_F16X3 = 1 };
+enum { FVAD_NN_MATH_F32 = 0, FVAD_NN_MATH_F16X3 = 1, FVAD_NN_MATH_BF16X3 = 2 };
 int fvad_ctx_set_nn_math(fvad_ctx *ctx, int mode);
 int fvad_ctx_nn_math_effective(const fvad_ctx *ctx);
 const char *fvad_ctx_last_nn_path(const fvad_ctx *ctx);
@@ -296,7 +301,7 @@ const char *fvad_ctx_last_nn_path(const fvad_ctx *ctx);
  * are padded to 128 sequences and lose their low-latency kernels), so that a stream pushed in any pieces, split
  * over any number of launches or time-split over ranks gives the same bits.  FVAD_NN_MATH_F16X3 has one family.
  *
- * Testing / tuning aids, none needed in production: name = "reproducible" | "nn_math" ("f32" | "f16x3": overrides
+ * Testing / tuning aids, none needed in production: name = "reproducible" | "nn_math" ("f32" | "f16x3" | "bf16x3": overrides
  * fvad_ctx_set_nn_math) | "gru_kernel" ("v3w12" | "v3w8" | "v3w4" | "v4w8" | "v5w0" | "v6w0") | "gemm_kernel" ("v1" |
  * "v3" | "v3nofold") | "h3_waves" ("8" | "12") | "max_chunks" | "copy_threads" | "no_pipeline" | "trace_kernels" |
  * "ws_spin_ticks" | "ws2_variant" (timing-only variants of a kernel: wrong results); value NULL or "" restores the

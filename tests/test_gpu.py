@@ -199,6 +199,7 @@ def test_nsnet2_forward_matches_oracle(fv, gpu_ctx, weights7):
     {"gemm_kernel": "v3nofold"}, {"gemm_kernel": "v1"}, {"gru_kernel": "v4w8"},
     {"gru_kernel": "v5w0"}, {"nn_math": "f32"}, {"nn_math": "f16x3", "h3_waves": "8"},
     {"nn_math": "f16x3", "h3_waves": "12"}, {"nn_math": "f16x3", "gru_kernel": "v3w12"}, {"reproducible": "1"},
+    {"nn_math": "bf16x3"},
 ], ids=lambda e: "-".join(e.values()) or "default")
 def test_nsnet2_large_batch_kernels_match_oracle(fv, gpu_ctx, weights7, opts):
     # 2100 sequences take the large-batch path (LDS-DMA GEMMs, persistent GEMM, multi-wave recurrence);
@@ -210,7 +211,7 @@ def test_nsnet2_large_batch_kernels_match_oracle(fv, gpu_ctx, weights7, opts):
     f[::7, :2] = 0.0
     with gpu_ctx.options(**opts):
         # the arithmetic is a property of the context: f16x3 only when asked for and no f32 variant is forced
-        want = "f16x3" if opts.get("nn_math") == "f16x3" and "gru_kernel" not in opts else "f32"
+        want = opts.get("nn_math", "f32") if "gru_kernel" not in opts else "f32"
         assert gpu_ctx.nn_math_effective() == want
         g = gpu_ctx.nsnet2_forward(f)
         path = gpu_ctx.last_nn_path()
@@ -266,6 +267,76 @@ def test_f16x3_products_are_as_close_to_float64_as_f32(fv, weights7):
     with pytest.raises(fv.FvadError):
         c.set_nn_math_raw(7)
     c.close()
+
+
+def test_bf16x3_is_not_narrower_than_f32(fv, weights7):
+    # FVAD_NN_MATH_BF16X3: the dense layers as six bf16 MFMAs on exact three-piece splits of both operands (all 24
+    # significand bits, f32's exponent range, no scales or eligibility bounds), recurrences on f32 MFMA.  Against
+    # float64 numpy it must be at least as close as the f32 kernels -- on the synthetic model, on heavy-tailed weights
+    # (a few entries per row hundreds of times the rest) and on rows whose entries span 40 binades -- and, unlike
+    # f16x3, it must never be demoted: a model whose l1 bounds leave the f16 range stays on it.
+    rng = np.random.default_rng(77)
+    f = rng.uniform(-11, 2, (5, 54, 161)).astype(np.float32)
+    f[1] = rng.uniform(20, 60, (54, 161))          # absurdly loud input
+    f[2, :, ::3] = -12.0                           # digital silence in a third of the bins
+    fb = np.tile(f, (26, 1, 1))                    # 130 sequences: padded to 256, the 8-wave recurrence
+
+    def heavy(w, gen):
+        out = {}
+        for k, v in w.items():
+            if v.ndim == 2:
+                t = np.exp(1.8 * gen.standard_normal(v.shape)) * np.sign(gen.standard_normal(v.shape))
+                u = v * np.abs(t)
+                u *= np.linalg.norm(v, axis=1, keepdims=True) / np.maximum(np.linalg.norm(u, axis=1, keepdims=True), 1e-30)
+                out[k] = u.astype(np.float32)
+            else:
+                out[k] = v.copy()
+        return out
+
+    def binades(w, gen):
+        out = {}
+        for k, v in w.items():
+            if v.ndim == 2 and k in ("fc1_w", "gru2_w", "fc2_w", "fc3_w", "fc4_w"):
+                e = gen.uniform(-40, 0, v.shape)
+                e[np.arange(v.shape[0]), gen.integers(0, v.shape[1], v.shape[0])] = 0.0   # one entry per row keeps its size
+                u = v * np.exp2(e) * np.sqrt(v.shape[1] / 8.0)
+                out[k] = u.astype(np.float32)
+            else:
+                out[k] = v.copy()
+        return out
+
+    def run(w, mode):
+        ctx = fv.Context(0)
+        ctx.load_weights(w)
+        ctx.set_nn_math(mode)
+        eff = ctx.nn_math_effective()
+        g = ctx.nsnet2_forward(fb)
+        path = ctx.last_nn_path()
+        ctx.close()
+        return g, eff, path
+
+    big = {k: v.copy() for k, v in weights7.items()}
+    big["fc2_w"] *= np.float32(1.0e5); big["fc2_b"] *= np.float32(1.0e5); big["fc3_w"] /= np.float32(1.0e5)   # f16x3 would be demoted here
+    for name, w in (("synthetic", weights7), ("heavy-tailed", heavy(weights7, rng)), ("40 binades", binades(weights7, rng)), ("l1 bound 1e7", big)):
+        g64 = np.stack([_nsnet2_float64(w, s) for s in f])
+        assert 0.02 < g64.std() and np.all(np.isfinite(g64)), name          # the model still responds
+        (g_b3, eff, path), (g_f32, _, _) = run(w, "bf16x3"), run(w, "f32")
+        assert eff == "bf16x3" and path.startswith("bf16x3:"), (name, eff, path)
+        e_b3 = max(np.abs(g_b3[:5] - g64).max(), np.abs(g_b3[-5:] - g64).max())
+        e_f32 = max(np.abs(g_f32[:5] - g64).max(), np.abs(g_f32[-5:] - g64).max())
+        assert e_b3 <= max(1.25 * e_f32, 4e-7), (name, e_b3, e_f32)
+        assert e_f32 <= 1e-5, (name, e_f32)
+        assert np.array_equal(g_b3[:5], g_b3[-5:])      # same sequences, different workgroups: same bits
+    # one family at every launch size: the same sequences alone in a 128-sequence launch
+    ctx = fv.Context(0)
+    ctx.load_weights(weights7)
+    ctx.set_nn_math("bf16x3")
+    a = ctx.nsnet2_forward(fb)
+    b = ctx.nsnet2_forward(fb[:3].copy())
+    assert np.array_equal(a[:3], b)
+    ctx.set_nn_math("f16x3")
+    assert ctx.nn_math_effective() == "f16x3"
+    ctx.close()
 
 
 @pytest.mark.parametrize("n_seq,T", [(2304, 7), (2176, 20), (4000, 54), (3, 54), (130, 54), (5, 7), (200, 3)])
@@ -1223,7 +1294,7 @@ def test_launch_size_does_not_change_the_arithmetic(fv, gpu_ctx, pkg):
         return worst
 
     res = {}
-    for math in ("f32", "f16x3"):
+    for math in ("f32", "f16x3", "bf16x3"):
         # no_pipeline: the host-buffer call would otherwise run these 221 MB as four lane groups of 576 chunks
         with gpu_ctx.options(nn_math=math, no_pipeline="1"):
             assert gpu_ctx.nn_math_effective() == math
@@ -1231,9 +1302,9 @@ def test_launch_size_does_not_change_the_arithmetic(fv, gpu_ctx, pkg):
             p2, split = one(max_chunks_per_launch=1024)
             two = pushes()
             assert p1.startswith(math + ":") and p2.startswith(math + ":")
-            if math == "f16x3":
-                same_bits(whole, split, "f16x3 launch split")
-                same_bits(whole, two, "f16x3 two pushes")
+            if math != "f32":
+                same_bits(whole, split, math + " launch split")
+                same_bits(whole, two, math + " two pushes")
             else:
                 assert "panel_gemm3" in p1 and "panel_gemm3" not in p2, (p1, p2)   # two kernel families
                 close_and_same_segments(split, whole, "f32 launch split")
@@ -1247,6 +1318,7 @@ def test_launch_size_does_not_change_the_arithmetic(fv, gpu_ctx, pkg):
                     same_bits(whole_r, two_r, "reproducible two pushes")
             res[math] = whole
     close_and_same_segments(res["f16x3"], res["f32"], "f16x3 against f32")
+    close_and_same_segments(res["bf16x3"], res["f32"], "bf16x3 against f32")
 
 
 def test_time_split_across_the_family_line_needs_reproducible_mode(fv, gpu_ctx, pkg):

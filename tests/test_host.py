@@ -54,6 +54,27 @@ def test_bench_gpus_n_without_enough_gpus_is_refused_before_any_rank_starts():
     assert r.returncode == 2 and "rank" in r.stderr
 
 
+@pytest.mark.parametrize("unit", ["kernels_b3.hip", "kernels_h3.hip", "kernels_nn.hip"])
+def test_kernels_with_inline_lds_reads_compile_without_spills(unit):
+    # The persistent GEMMs and the LDS-DMA recurrences read weight fragments with inline ds_read_b128 / global_load_lds
+    # that the compiler knows nothing about: a spilled register there is not slow but unsafe (its in-flight read lands
+    # in whatever the compiler has meanwhile put into it: DESIGN.md section 3.0b).  Every kernel of these translation units
+    # must compile for gfx950 with zero spilled registers and no scratch.
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "formula-vad_amd", "csrc", unit)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                        "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.devnull], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", r.stderr)
+    spills = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", r.stderr)]
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    assert names and len(names) == len(spills) == len(scratch)
+    bad = [(n, sp, sc) for n, sp, sc in zip(names, spills, scratch) if sp or sc]
+    assert not bad, bad
+
+
 def test_windows_bit_equal_oracle(fv):
     L = fv.lib()
     w = np.zeros(320, np.float32)

@@ -20,7 +20,7 @@ def main():
     g_orc = np.stack([orc.nsnet2_forward(w, s) for s in base])
     f = np.tile(base, (n_seq // 6, 1, 1))
     out = {}
-    for math in ("f32", "f16x3"):
+    for math in ("f32", "f16x3", "bf16x3"):
         ctx = fv.Context(0); ctx.load_synth(7); ctx.set_nn_math(math)
         g = ctx.nsnet2_forward(f)
         ctx.enable_timing(True)
@@ -33,6 +33,7 @@ def main():
         print(f"{math:6s} max|g - f64| last6 {e.max():.3e} first6 {first.max():.3e}  rms {np.sqrt((e**2).mean()):.3e}   vs oracle {np.abs(g[-6:] - g_orc).max():.3e}")
         print("       ", "  ".join(f"{k}={v:.3f}" for k, v in times.items()))
         ctx.close()
-    print(f"oracle max|g - f64| {np.abs(g_orc - g64).max():.3e};  f16x3 vs f32 path {np.abs(out['f16x3'] - out['f32']).max():.3e}")
+    print(f"oracle max|g - f64| {np.abs(g_orc - g64).max():.3e};  f16x3 vs f32 path {np.abs(out['f16x3'] - out['f32']).max():.3e};  "
+          f"bf16x3 vs f32 path {np.abs(out['bf16x3'] - out['f32']).max():.3e}")
 
 main()
