@@ -61,7 +61,7 @@ pub extern "c" fn fvad_last_error(ctx: ?*const Ctx) [*:0]const u8;
 pub extern "c" fn fvad_load_nsnet2_onnx(ctx: *Ctx, path: [*:0]const u8) c_int;
 pub extern "c" fn fvad_load_nsnet2_synth(ctx: *Ctx, seed: u64) c_int;
 /// 0 = f32 MFMA throughout, 1 = f16x3 (default): arithmetic of the large-batch NSNet2 matrix products; returns the previous mode
-pub extern "c" fn fvad_ctx_set_nn_math(ctx: *Ctx, mode: c_int) c_int; // 0 = f32 (default, the ORT CPU arithmetic), 1 = f16x3 emulation
+pub extern "c" fn fvad_ctx_set_nn_math(ctx: *Ctx, mode: c_int) c_int; // 0 = f32 (default, the ORT CPU arithmetic), 1 = f16x3 emulation (22-bit operands), 2 = bf16x3 (24-bit operands, dense layers)
 pub extern "c" fn fvad_ctx_nn_math_effective(ctx: *const Ctx) c_int;
 pub extern "c" fn fvad_ctx_last_nn_path(ctx: *const Ctx) [*:0]const u8;
 pub extern "c" fn fvad_ctx_set_option(ctx: *Ctx, name: [*:0]const u8, value: ?[*:0]const u8) c_int; // e.g. "reproducible", "1"
