@@ -176,11 +176,15 @@ int upload_model(fvad_ctx* ctx)
         }
         pack_panel(tile_major_rows(wf.data(), 161).data(), 1200, 161, 5, 15, 11, f);
         if ((rc = upload(ctx, m.gi1f_w, f))) return rc;
-        // small batches: the same matrices cut into 15 column blocks of 5 tiles (more, lighter workgroups)
-        pack_panel(tile_major_rows(wf.data(), 161).data(), 1200, 161, 15, 5, 11, f);
-        if ((rc = upload(ctx, m.s_gi1f_w, f))) return rc;
-        pack_panel(tile_major_rows(w.gru2_w.data(), 400).data(), 1200, 400, 15, 5, 25, f);
-        if ((rc = upload(ctx, m.s_gi2_w, f))) return rc;
+        // small batches (panel_gemm_s_kernel): the same matrices cut into column blocks of 2 tiles (launches of up to
+        // ~2000 rows) and of 4 tiles (larger ones): 75 unit tiles -> 38 / 19 blocks, the 76th tile never stored
+        for (int fam = 0; fam < 2; ++fam) {
+            const int nt = fam ? 4 : 2, nb = (75 + nt - 1) / nt;
+            pack_panel(tile_major_rows(wf.data(), 161).data(), 1200, 161, nb, nt, 11, f);
+            if ((rc = upload(ctx, m.s_gi1f_w[fam], f))) return rc;
+            pack_panel(tile_major_rows(w.gru2_w.data(), 400).data(), 1200, 400, nb, nt, 25, f);
+            if ((rc = upload(ctx, m.s_gi2_w[fam], f))) return rc;
+        }
         // gru_ws2_kernel computes layer 2's input projection itself: W_ih2 as stationary fragments like R, Wb gate-major
         pack_gru_r2(w.gru2_w.data(), H, f);
         if ((rc = upload(ctx, m.s_w2frag, f))) return rc;
@@ -203,16 +207,19 @@ int upload_model(fvad_ctx* ctx)
         for (int o = 0; o < 2 * H; ++o) b2[o] += w.gru2_b[3 * H + o];
         if ((rc = upload(ctx, m.gi2_bzr, tile_major_rows(b2.data(), 1)))) return rc;
     }
-    // small batches: fc2 400 -> 600 and fc3 600 -> 600 as 8 column blocks of 5 tiles (rows of 640 floats, K of fc3
-    // padded to 608 = 38 super-steps), fc4 600 -> 161 as 2 blocks of 6 tiles of which 11 are stored
-    pack_panel(w.fc2_w.data(), 600, 400, 8, 5, 25, f);
-    if ((rc = upload(ctx, m.fc2_w, f))) return rc;
+    // small batches: fc2 400 -> 600 and fc3 600 -> 600 as 19 column blocks of 2 tiles or 10 of 4 (rows of 640 floats,
+    // K of fc3 padded to 608 = 38 super-steps), fc4 600 -> 161 as 6 blocks of 2 or 3 of 4, of which 11 tiles are stored
+    for (int fam = 0; fam < 2; ++fam) {
+        const int nt = fam ? 4 : 2;
+        pack_panel(w.fc2_w.data(), 600, 400, (38 + nt - 1) / nt, nt, 25, f);
+        if ((rc = upload(ctx, m.s_fc2_w[fam], f))) return rc;
+        pack_panel(w.fc3_w.data(), 600, 600, (38 + nt - 1) / nt, nt, 38, f);
+        if ((rc = upload(ctx, m.s_fc3_w[fam], f))) return rc;
+        pack_panel(w.fc4_w.data(), 161, 600, (11 + nt - 1) / nt, nt, 38, f);
+        if ((rc = upload(ctx, m.s_fc4_w[fam], f))) return rc;
+    }
     if ((rc = upload(ctx, m.fc2_b, padded(w.fc2_b.data(), 600, 640)))) return rc;
-    pack_panel(w.fc3_w.data(), 600, 600, 8, 5, 38, f);
-    if ((rc = upload(ctx, m.fc3_w, f))) return rc;
     if ((rc = upload(ctx, m.fc3_b, padded(w.fc3_b.data(), 600, 640)))) return rc;
-    pack_panel(w.fc4_w.data(), 161, 600, 2, 6, 38, f);
-    if ((rc = upload(ctx, m.s_fc4_w, f))) return rc;
     if ((rc = upload(ctx, m.s_fc4_b, padded(w.fc4_b.data(), 161, 192)))) return rc;
     // the same two layers as 3 blocks of 13 tiles (39 tiles, the 39th is padding and never stored):
     // 104 accumulator + 52 fragment registers fit the persistent kernel, 19-tile blocks do not
@@ -447,7 +454,10 @@ static long padded_batch(const fvad_ctx* ctx, long n, int T, int skip)
 {
     const long a = (n + 383) / 384 * 384, b = (n + 127) / 128 * 128;
     const Tuning& tn = ctx->tune;
-    if (ctx->dm.generic) return (n + 31) / 32 * 32; // run-time-sized kernels: 64-row GEMM workgroups over 54 n and 50 n rows
+    if (ctx->dm.generic) { // run-time-sized kernels: 64-row GEMM workgroups over T n and (T - skip) n rows
+        const long g = (n + 31) / 32 * 32;
+        return ((g * T) % 64 != 0 || (g * (T - skip)) % 64 != 0) ? (n + 63) / 64 * 64 : g;
+    }
     const char* force = tn.gru_kernel.empty() ? nullptr : tn.gru_kernel.c_str();
     const int cu = ctx->n_cu;
     if (nn_math_effective(ctx) == FVAD_NN_MATH_F16X3) {
@@ -471,9 +481,11 @@ static long padded_batch(const fvad_ctx* ctx, long n, int T, int skip)
         if (!fits(pick)) pick = fits(a) ? a : (pick + 255) / 256 * 256;
         return pick;
     }
-    // the weight-stationary recurrence and the small-batch GEMMs (64-row workgroups over 54 n and 50 n rows)
-    // only need a multiple of 32 sequences
-    const long c = (n + 31) / 32 * 32;
+    // the weight-stationary recurrence and the small-batch GEMMs (64-row workgroups over T n and (T - skip) n rows:
+    // 54 n and 50 n) only need a multiple of 32 sequences; an odd sequence length (fvad_nsnet2_forward takes any)
+    // one of 64
+    long c = (n + 31) / 32 * 32;
+    if ((c * T) % 64 != 0 || (c * (T - skip)) % 64 != 0) c = (n + 63) / 64 * 64;
     if (!tn.reproducible && (!force || force[1] == '5' || force[1] == '6') && tn.gemm_kernel.empty() && c < 2048 &&
         std::min(gru_ws_cost(c, cu), gru_ws2_cost_both_layers(c, cu) / 108.0) < std::min(gru_cost(b, 0, cu), gru_cost(b, 4, cu)))
         return c;
@@ -774,10 +786,13 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
         return FVAD_OK;
     }
     // ---- small batches: a handful of 64-row panels per launch, so every layer is cut into narrow column blocks
-    // (5 or 6 tiles) that put several wavefronts on every SIMD; fc1 is folded into the first GRU's input projection
-    // like in the large-batch family; gi rows are tile-major
+    // (2 tiles up to 2048 rows, 4 above: the same arithmetic, more and lighter workgroups) with loads several phases
+    // ahead (panel_gemm_s_kernel); fc1 is folded into the first GRU's input projection like in the large-batch
+    // family; gi rows are tile-major
+    const int fam = rows > 2048 ? 1 : 0, snt = fam ? 4 : 2;
+    const int nb_gi = (75 + snt - 1) / snt, nb_fc = (38 + snt - 1) / snt, nb_fc4 = (11 + snt - 1) / snt;
     time_begin(ctx, "gru1_in_gemm_fc1folded");
-    rc |= fvad_launch_panel_gemm(ws.feat, kFeatStride, m.s_gi1f_w.p, m.gi1f_b.p, ws.gi, 1200, rows, 5, 15, 11, FVAD_ACT_NONE, 0, 0, st);
+    rc |= fvad_launch_panel_gemm_s(ws.feat, kFeatStride, m.s_gi1f_w[fam].p, m.gi1f_b.p, ws.gi, 1200, rows, snt, nb_gi, 11, FVAD_ACT_NONE, 0, 0, st, 75);
     time_end(ctx);
     const GruChoice gcs = pick_gru(ctx, n_pad, false);
     if (gcs.version >= 5 && (rc = prepare_gru_ws(ctx, n_pad))) return rc;
@@ -792,7 +807,7 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
                                        n_pad, T, ctx->n_cu, tn.ws_spin_ticks, tn.ws2_variant, st);
         });
         rc |= fvad_launch_gru_lat(ws.gi, m.r1v2.p, m.br1.p, ws.h1, n_pad, T, err, 1, st);
-        rc |= fvad_launch_panel_gemm(ws.h1, 400, m.s_gi2_w.p, m.gi2_btm.p, ws.gi, 1200, rows, 5, 15, 25, FVAD_ACT_NONE, 0, 0, st, 0, err);
+        rc |= fvad_launch_panel_gemm_s(ws.h1, 400, m.s_gi2_w[fam].p, m.gi2_btm.p, ws.gi, 1200, rows, snt, nb_gi, 25, FVAD_ACT_NONE, 0, 0, st, 75, err);
         rc |= fvad_launch_gru_lat(ws.gi, m.r2v2.p, m.br2.p, ws.h2, n_pad, T, err, 1, st);
         fvad_launch_count_word(ws.ws_fallbacks, err, st);
         time_end(ctx);
@@ -801,20 +816,20 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
         rc |= launch_gru(ctx, gcs, ws.gi, m.r1v2, m.br1.p, ws.h1, n_pad, T, 0, 1);
         time_end(ctx);
         time_begin(ctx, "gru2_in_gemm");
-        rc |= fvad_launch_panel_gemm(ws.h1, 400, m.s_gi2_w.p, m.gi2_btm.p, ws.gi, 1200, rows, 5, 15, 25, FVAD_ACT_NONE, 0, 0, st);
+        rc |= fvad_launch_panel_gemm_s(ws.h1, 400, m.s_gi2_w[fam].p, m.gi2_btm.p, ws.gi, 1200, rows, snt, nb_gi, 25, FVAD_ACT_NONE, 0, 0, st, 75);
         time_end(ctx);
         time_begin(ctx, "gru2_rec");
         rc |= launch_gru(ctx, gcs, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T, 1, 1);
         time_end(ctx);
     }
     time_begin(ctx, "fc2_gemm");
-    rc |= fvad_launch_panel_gemm(ws.h2, 400, m.fc2_w.p, m.fc2_b.p, ws.f2, 640, rows_out, 5, 8, 25, FVAD_ACT_RELU, skip ? T : 0, skip, st);
+    rc |= fvad_launch_panel_gemm_s(ws.h2, 400, m.s_fc2_w[fam].p, m.fc2_b.p, ws.f2, 640, rows_out, snt, nb_fc, 25, FVAD_ACT_RELU, skip ? T : 0, skip, st);
     time_end(ctx);
     time_begin(ctx, "fc3_gemm");
-    rc |= fvad_launch_panel_gemm(ws.f2, 640, m.fc3_w.p, m.fc3_b.p, ws.f3, 640, rows_out, 5, 8, 38, FVAD_ACT_RELU, 0, 0, st);
+    rc |= fvad_launch_panel_gemm_s(ws.f2, 640, m.s_fc3_w[fam].p, m.fc3_b.p, ws.f3, 640, rows_out, snt, nb_fc, 38, FVAD_ACT_RELU, 0, 0, st);
     time_end(ctx);
     time_begin(ctx, "fc4_gemm");
-    rc |= fvad_launch_panel_gemm(ws.f3, 640, m.s_fc4_w.p, m.s_fc4_b.p, ws.gains, kFeatStride, rows_out, 6, 2, 38, FVAD_ACT_SIGMOID, 0, 0, st, 11);
+    rc |= fvad_launch_panel_gemm_s(ws.f3, 640, m.s_fc4_w[fam].p, m.s_fc4_b.p, ws.gains, kFeatStride, rows_out, snt, nb_fc4, 38, FVAD_ACT_SIGMOID, 0, 0, st, 11);
     time_end(ctx);
     if (rc) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "no kernel instance for this layer shape");
     FVAD_HIP(ctx, hipGetLastError());
@@ -1119,8 +1134,9 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
                        &m.gi1f_b3, &m.gi2_b3, &m.fc2_b3, &m.fc3_b3, &m.fc4_b3,
                        &m.gi1f_h3, &m.gi2_h3, &m.fc2_h3, &m.fc3_h3, &m.fc4_h3, &m.fc2h3_b, &m.fc3h3_b, &m.fc4h3_b, &m.r1_h3, &m.r2_h3};
     for (DevBuf* b : gbufs) if (b->p) hipFree(b->p);
-    DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.s_gi1f_w, &m.s_gi2_w, &m.s_fc4_w, &m.s_fc4_b, &m.s_w2frag, &m.s_bw2, &m.br1, &m.br2,
-                      &m.fc2_w, &m.fc2_b, &m.fc3_w, &m.fc3_b, &m.fc4_w, &m.fc4_b, &m.r1v2, &m.r2v2, &m.gi1f_w, &m.gi1f_b, &m.gi1v2_w, &m.gi2v2_w, &m.gi1f_bzr, &m.gi2_bzr, &m.gi1_btm, &m.gi2_btm, &m.fc2v3_w, &m.fc3v3_w, &m.fc2v3_b, &m.fc3v3_b};
+    DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.s_gi1f_w[0], &m.s_gi1f_w[1], &m.s_gi2_w[0], &m.s_gi2_w[1], &m.s_fc2_w[0], &m.s_fc2_w[1],
+                      &m.s_fc3_w[0], &m.s_fc3_w[1], &m.s_fc4_w[0], &m.s_fc4_w[1], &m.s_fc4_b, &m.s_w2frag, &m.s_bw2, &m.br1, &m.br2,
+                      &m.fc2_b, &m.fc3_b, &m.fc4_w, &m.fc4_b, &m.r1v2, &m.r2v2, &m.gi1f_w, &m.gi1f_b, &m.gi1v2_w, &m.gi2v2_w, &m.gi1f_bzr, &m.gi2_bzr, &m.gi1_btm, &m.gi2_btm, &m.fc2v3_w, &m.fc3v3_w, &m.fc2v3_b, &m.fc3v3_b};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (ctx->d_tables) hipFree(ctx->d_tables);
     for (auto& kt : ctx->times) { hipEventDestroy(kt.e0); hipEventDestroy(kt.e1); }

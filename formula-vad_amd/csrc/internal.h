@@ -54,8 +54,9 @@ struct DevBuf {
 };
 
 struct DeviceModel {
-    DevBuf fc1_w, fc1_b, br1, br2, fc2_w, fc2_b, fc3_w, fc3_b, // fc2 / fc3: the small-batch layout (8 blocks of 5 tiles)
-        s_gi1f_w, s_gi2_w, s_fc4_w, s_fc4_b, s_w2frag, s_bw2,                   // small-batch layouts of the input projections and fc4
+    DevBuf fc1_w, fc1_b, br1, br2, fc2_b, fc3_b, // fc2 / fc3 biases padded to 640
+        s_gi1f_w[2], s_gi2_w[2], s_fc2_w[2], s_fc3_w[2], s_fc4_w[2], // small-batch layouts: column blocks of 2 / of 4 tiles
+        s_fc4_b, s_w2frag, s_bw2,
         fc4_w, fc4_b, r1v2, r2v2, gi1f_w, gi1f_b, gi1v2_w, gi2v2_w,
         fc2v3_w, fc3v3_w, fc2v3_b, fc3v3_b, // fc2/fc3 as 3 column blocks of 13 tiles for panel_gemm3
         gi1f_bzr, gi2_bzr, // input-projection biases with the recurrent z/r biases folded in (gru_rec3)

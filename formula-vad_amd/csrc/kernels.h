@@ -74,6 +74,10 @@ int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const fl
                            int ldc, long rows, int nt, int n_blocks, int S_steps, int act,
                            int map_T, int map_skip, hipStream_t stream, int n_valid_tiles = 0,
                            const unsigned* guard = nullptr);
+// small batches (kernels_nn.hip: panel_gemm_s_kernel): nt = 2 or 4 tiles per column block, S_steps in {11, 25, 38}
+int fvad_launch_panel_gemm_s(const float* A, int lda, const float* Wfrag, const float* bias, float* C, int ldc,
+                             long rows, int nt, int n_blocks, int S_steps, int act, int map_T, int map_skip,
+                             hipStream_t stream, int n_valid_tiles = 0, const unsigned* guard = nullptr);
 int fvad_launch_panel_gemm3(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
                             int ldc, long rows, int nt, int n_blocks, int S_steps, int K, int act,
                             int n_valid_tiles, int map_T, int map_skip, int n_wg, hipStream_t stream);

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(WAVES * 64) void panel_gemm_kernel(
         const f32x4* wl = reinterpret_cast<const f32x4*>(slab[cur]) + lane;
         // consecutive MFMAs go to different accumulators: a dependent v_mfma_f32_16x16x4_f32 issues every 40 cycles,
         // an independent one every 32 (each accumulator still sees its k in order)
-        constexpr int TG = NT <= 12 ? NT : 5; // tiles per interleaved group (register budget); instances: 5, 6, 8, 11, 25
+        constexpr int TG = NT <= 12 ? NT : 5; // tiles per interleaved group (register budget); instances: 8, 11, 25
         static_assert(NT % TG == 0, "tile groups");
 #pragma unroll
         for (int t0 = 0; t0 < NT; t0 += TG) {
@@ -162,6 +162,7 @@ int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const fl
                            int map_T, int map_skip, hipStream_t stream, int n_valid_tiles, const unsigned* guard)
 {
     if (n_valid_tiles <= 0) n_valid_tiles = nt * n_blocks;
+    if (rows <= 0 || rows % 64 != 0) return -1; // whole 64-row workgroups only (the engine pads the batch)
 #define CASE(NT_, ACT_)                                                                          \
     if (nt == NT_ && act == ACT_) {                                                              \
         launch_panel<NT_, ACT_>(A, lda, Wfrag, bias, C, ldc, rows, n_blocks, S_steps, map_T,     \
@@ -173,13 +174,157 @@ int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const fl
     // models of other dimensions than NSNet2-baseline's (run_nn_generic): any width as blocks of 8 tiles
     CASE(8, FVAD_ACT_NONE)
     CASE(8, FVAD_ACT_RELU)
-    // small batches (a push of a few chunks, BASELINE config 3's 82): a launch is a handful of 64-row panels, so the
-    // columns are cut into narrow blocks -- 5 or 6 tiles -- to put several wavefronts on every SIMD of the chip:
-    // 1200 = 15 x 5 tiles, 600 -> 8 x 5 tiles (rows of 640 floats), 161 -> 2 x 6 tiles of which 11 are stored
-    CASE(5, FVAD_ACT_NONE)
-    CASE(5, FVAD_ACT_RELU)
-    CASE(6, FVAD_ACT_SIGMOID)
 #undef CASE
+    return -1;
+}
+
+// ------------------------------------------------------------------ panel GEMM, small batches
+// The same 64-row x (16 NT)-column workgroup for launches of a few to a few thousand rows (a push of one chunk,
+// BASELINE config 3's 82), where a layer is a handful of row panels and what is exposed is the latency chain of one
+// workgroup, not the MFMA rate.  Against panel_gemm_kernel:
+//   * the reduction length S (super-steps of 16) is a template parameter and the phase loop is unrolled completely,
+//     so no load sits under a run-time predicate: with `if (more)` around the next slab's loads the compiler put
+//     s_waitcnt vmcnt(0) in the middle of the MFMA section and serialised the prologue's loads one by one;
+//   * slab and activation loads run PF phases (of KS super-steps) ahead through registers -- a first-touch
+//     activation load takes longer than one phase's MFMAs -- and LDS holds PF + 1 slabs, one barrier per phase;
+//   * narrow column blocks (2 or 4 tiles): 4800 rows x 600 columns are 750 (NT = 4) workgroups instead of 600, and
+//     each wavefront's chain is shorter.
+// tools/small_gemm.hip measures the variants: fc2 / fc3 / fc4 of the 82-chunk batch 41.7 / 59.3 / 33.9 us ->
+// 24.3 / 34.2 / 14.2 us, of a one-chunk push 25 -> 8 us.  Every output is still the k-ordered chain of f32 fmas with
+// the bias added after it: bit-identical to panel_gemm_kernel (asserted by the tool and by the parity tests).
+template <int NT, int KS, int S, int PF, int ACT>
+__global__ __launch_bounds__(256) void panel_gemm_s_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ Wfrag, const float* __restrict__ bias,
+    float* __restrict__ C, int ldc, int row_map_T, int row_map_skip, int n_valid_tiles, const unsigned* guard)
+{
+    constexpr int NB = PF + 1;
+    __shared__ __attribute__((aligned(16))) float slab[NB][KS * NT * 256];
+    // launched behind gru_ws2_kernel as part of its fallback chain: runs only if that kernel raised *guard
+    if (guard && *guard == 0) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int m = lane & 15;
+    const int q = lane >> 4;
+    const int nblk = blockIdx.y;
+    const unsigned row = (blockIdx.x * 4 + wave) * 16 + m;
+    unsigned a_row = row;
+    if (row_map_T > 0) { // compact row index -> rows skip..T-1 of every T-row sequence of A (panel_gemm_kernel)
+        const unsigned per = (unsigned)(row_map_T - row_map_skip);
+        const unsigned qd = row / per;
+        a_row = qd * (unsigned)row_map_T + (unsigned)row_map_skip + (row - qd * per);
+    }
+    const float* a_ptr = A + (size_t)a_row * (size_t)lda + 4 * q;
+    const f32x4* w_src = reinterpret_cast<const f32x4*>(Wfrag + (size_t)nblk * S * (NT * 256));
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NP = (S + KS - 1) / KS;              // phases; the last one may be short
+    constexpr int PER_T = (KS * NT * 64 + 255) / 256;  // float4s of a slab per thread
+    f32x4 stage[NB][PER_T];
+    f32x4 a_q[NB][KS];
+    auto ks_of = [](int p) { return (S - p * KS) < KS ? (S - p * KS) : KS; };
+    auto load = [&](int p) { // phase p: slab -> stage registers, activations -> a_q (p is a constant after unrolling)
+        const int ks = ks_of(p);
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int idx = tid + i * 256;
+            if ((i + 1) * 256 <= ks * NT * 64 || idx < ks * NT * 64) stage[p % NB][i] = w_src[(size_t)p * KS * NT * 64 + idx];
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            if (s < ks) a_q[p % NB][s] = *reinterpret_cast<const f32x4*>(a_ptr + 16 * (p * KS + s));
+    };
+    auto to_lds = [&](int p) {
+        const int ks = ks_of(p);
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int idx = tid + i * 256;
+            if ((i + 1) * 256 <= ks * NT * 64 || idx < ks * NT * 64) reinterpret_cast<f32x4*>(slab[p % NB])[idx] = stage[p % NB][i];
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < PF && p < NP; ++p) load(p);
+    to_lds(0);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (p + PF < NP) load(p + PF);
+        const int ks = ks_of(p);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s < ks) {
+                const f32x4* wl = reinterpret_cast<const f32x4*>(slab[p % NB]) + s * NT * 64 + lane;
+                f32x4 w4[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) w4[t] = wl[t * 64];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = MFMA16(w4[t].x, a_q[p % NB][s].x, acc[t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = MFMA16(w4[t].y, a_q[p % NB][s].y, acc[t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = MFMA16(w4[t].z, a_q[p % NB][s].z, acc[t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = MFMA16(w4[t].w, a_q[p % NB][s].w, acc[t]);
+            }
+        }
+        if (p + 1 < NP) {
+            // slab p + 1 goes into the buffer last read in phase p + 1 - NB <= p - 1: every wavefront has passed the
+            // barrier that ended that phase
+            to_lds(p + 1);
+            __syncthreads();
+        }
+    }
+
+    float* c_ptr = C + (size_t)row * (size_t)ldc + nblk * (NT * 16) + 4 * q;
+    const float* b_ptr = bias + nblk * (NT * 16) + 4 * q;
+    const int valid_t = n_valid_tiles - nblk * NT; // tiles past the output's width are computed but not stored
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t < valid_t) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(b_ptr + 16 * t);
+            f32x4 v = acc[t] + b4;
+            if (ACT == FVAD_ACT_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            } else if (ACT == FVAD_ACT_SIGMOID) {
+                v.x = act_sigmoid(v.x); v.y = act_sigmoid(v.y); v.z = act_sigmoid(v.z); v.w = act_sigmoid(v.w);
+            }
+            *reinterpret_cast<f32x4*>(c_ptr + 16 * t) = v;
+        }
+    }
+}
+
+// rows must be a multiple of 64; Wfrag from pack_panel with blocks of nt tiles (nt = 2: launches of up to ~2000 rows,
+// nt = 4: larger ones); the (S_steps, act) pairs of NSNet2-baseline's five layers; n_valid_tiles <= 0: every tile of
+// every block is stored; guard != nullptr: the kernel returns at once unless *guard != 0.
+int fvad_launch_panel_gemm_s(const float* A, int lda, const float* Wfrag, const float* bias, float* C, int ldc,
+                             long rows, int nt, int n_blocks, int S_steps, int act, int map_T, int map_skip,
+                             hipStream_t stream, int n_valid_tiles, const unsigned* guard)
+{
+    if (n_valid_tiles <= 0) n_valid_tiles = nt * n_blocks;
+    if (rows <= 0 || rows % 64 != 0) return -1;
+    const dim3 grid((unsigned)(rows / 64), (unsigned)n_blocks);
+#define CASES(S_, ACT_)                                                                                              \
+    if (S_steps == S_ && act == ACT_) {                                                                              \
+        if (nt == 2)                                                                                                 \
+            hipLaunchKernelGGL((panel_gemm_s_kernel<2, 2, S_, 3, ACT_>), grid, dim3(256), 0, stream, A, lda, Wfrag,  \
+                               bias, C, ldc, map_T, map_skip, n_valid_tiles, guard);                                 \
+        else if (nt == 4)                                                                                            \
+            hipLaunchKernelGGL((panel_gemm_s_kernel<4, 1, S_, 4, ACT_>), grid, dim3(256), 0, stream, A, lda, Wfrag,  \
+                               bias, C, ldc, map_T, map_skip, n_valid_tiles, guard);                                 \
+        else                                                                                                         \
+            return -1;                                                                                               \
+        return 0;                                                                                                    \
+    }
+    CASES(11, FVAD_ACT_NONE)    // features -> gi (fc1 folded): K = 161 -> 176
+    CASES(25, FVAD_ACT_NONE)    // h1 -> gi
+    CASES(25, FVAD_ACT_RELU)    // fc2
+    CASES(38, FVAD_ACT_RELU)    // fc3: K = 600 -> 608
+    CASES(38, FVAD_ACT_SIGMOID) // fc4
+#undef CASES
     return -1;
 }
 

@@ -180,7 +180,8 @@ def test_fft_linearity_at_scale(fv, gpu_ctx):
 # ------------------------------------------------------------------ NSNet2 graph (NSNet2.zig:220)
 def test_nsnet2_forward_matches_oracle(fv, gpu_ctx, weights7):
     rng = np.random.default_rng(4)
-    for n_seq, T in ((1, 54), (3, 54), (130, 54), (5, 7)):
+    # (32, 7), (31, 5): odd sequence lengths whose rows fill the padded batch's last 64-row panel
+    for n_seq, T in ((1, 54), (3, 54), (130, 54), (5, 7), (32, 7), (31, 5)):
         f = rng.uniform(-11, 2, (n_seq, T, 161)).astype(np.float32)
         f[0, :2] = 0.0  # literal-zero warm-up rows of a first chunk
         g = gpu_ctx.nsnet2_forward(f)
