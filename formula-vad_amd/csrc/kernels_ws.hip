@@ -527,6 +527,266 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------ the same, K split over 16 wavefronts
+// gru_ws2_kernel keeps a gate's whole row of fragments (25 blocks) in one wavefront: six gate wavefronts per
+// workgroup, two on each of three SIMDs, the fourth SIMD idle -- a step's MFMA phase is 200 MFMAs deep on a SIMD
+// (tools/ws2_variants.py: 6.2 us per step for layer 1 alone against gru_ws_kernel's 5.4 with 100).  Here a workgroup
+// has 16 wavefronts: twelve gate wavefronts (wave % 4 = SIMD: three on each), each holding ONE of the two
+// accumulation chains of a gate -- the even or the odd super-steps, 13 or 12 fragment blocks, 52 VGPRs -- and four
+// others (two tile helpers, the poller, one that only loads).  The two chains of a gate meet in the gate math,
+// a0 + a1 as before: the same bits as gru_ws2_kernel.  156 MFMAs per SIMD and step instead of 200.
+// Also: one flag per unit tile, raised by the tile's helper wavefront itself right after its own drain (no workgroup
+// barrier between publish and flag), and layer 2's row-major copy of h2 is stored after the flag.
+// One row tile per group (16 wavefronts x 128 VGPRs leave no room for a second one's operands): up to 6 groups = 96
+// sequences -- BASELINE config 3's 82 chunks, every live push; the 8-wavefront kernel above serves 2 to 4 row tiles
+// per group.
+__global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict__ gi1, const float* __restrict__ R1frag,
+                                                        const float* __restrict__ bR1, const float* __restrict__ W2frag,
+                                                        const float* __restrict__ bW2, const float* __restrict__ R2frag,
+                                                        const float* __restrict__ bR2, float* __restrict__ hout2,
+                                                        float* hx1, float* hx2, unsigned* flags1, unsigned* flags2,
+                                                        unsigned* err, int T, int n_rt, unsigned long long spin_ticks,
+                                                        int variant)
+{
+    // dynamic LDS, in float4s: hbuf[2][25][64] (the row tile's h1 and h2); per tile slot: xch[3 gates][2 chains][64]
+    // recurrent partial products, xci[3][2][64] layer 2's input projection, hpv[64] the previous h of the tile;
+    // btab[2 tile slots][6][4] the biases (Rb z, r, n; layer 2's Wb z, r, n) as the four float4s a lane quartet needs
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* hbA = reinterpret_cast<f32x4*>(smem);
+    f32x4* hbB = hbA + GRU_J * 64;
+    f32x4* xch = hbB + GRU_J * 64;
+    f32x4* xci = xch + 12 * 64;
+    f32x4* hpv = xci + 12 * 64;
+    f32x4* btab = hpv + 2 * 64;
+    volatile int* s_dead = reinterpret_cast<volatile int*>(btab + 48);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4;
+    const int g = blockIdx.x / 38;                // the group = the row tile
+    const int r38 = blockIdx.x - g * 38;
+    const int layer = r38 >= 13;
+    const int pair = layer ? r38 - 13 : r38;      // layer 1: pair of unit tiles; layer 2: the unit tile
+    const bool gate_wave = wave < 12;
+    const int ws = gate_wave ? wave / 6 : (wave == 13); // half: layer 1 the tile of the pair, layer 2 the matrix (W_ih / R2)
+    const int gk = wave % 6;
+    const int wg = gk % 3;                         // gate
+    const int kp = gk / 3;                         // accumulation chain: even (0) or odd (1) super-steps
+    const int J = layer ? pair : 2 * pair + ws;
+    const bool tile_ok = J < GRU_J; // layer 1's 13th workgroup: its second tile does not exist
+    const int Jc = tile_ok ? J : 0;
+    const int tslot = layer ? 0 : ws;
+    // who does the gate math, fetches gi and publishes: layer 1: wavefronts 12 / 13 for the two tiles; layer 2: 12
+    const bool helper = layer ? wave == 12 : ((wave == 12 || wave == 13) && tile_ok);
+
+    if (tid == 0) *s_dead = (int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 2 * 64) hpv[tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (tid >= 128 && tid < 128 + 48) { // biases of the workgroup's tile(s): read from LDS in the gate math
+        const int e = tid - 128, sl = e / 24, k = (e % 24) / 4, qq = e & 3;
+        const int Jb = layer ? pair : 2 * pair + sl;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (Jb < GRU_J && (layer ? sl == 0 : k < 3)) {
+            const float* src = (k < 3 ? (layer ? bR2 : bR1) : bW2) + (k % 3) * GRU_H + 16 * Jb + 4 * qq;
+            v = *reinterpret_cast<const f32x4*>(src);
+        }
+        btab[e] = v;
+    }
+    __syncthreads();
+    if (*s_dead) return;
+    if ((variant & 4) && layer) return;
+    __syncthreads();
+
+    // ---- stationary weights of a gate wavefront: chain kp of gate wg of tile J: R1 (layer 1), or layer 2's W_ih
+    // (first half) / R2 (second half)
+    constexpr int NW = (GRU_J + 1) / 2;
+    f32x4 w[NW];
+    {
+        const bool gate = gate_wave && tile_ok;
+        const size_t blk = ((size_t)(Jc * 3 + wg) * GRU_J) * 64 + lane;
+        const f32x4* src = reinterpret_cast<const f32x4*>(layer ? (ws ? R2frag : W2frag) : R1frag) + blk;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int S = 2 * i + kp;
+            w[i] = (gate && S < GRU_J) ? src[(S < GRU_J ? S : 0) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // layer 1's gi of the step: requested BEFORE the wait
+    // (32-bit lane offsets into buffer resources, the step as the scalar offset: the 128-VGPR budget has no room for
+    // 64-bit per-lane addresses)
+    const auto rs_gi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gi1), 0, n_rt * 16 * T * (3 * GRU_H) * 4, 0x00020000);
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(hout2, 0, n_rt * 16 * T * GRU_H * 4, 0x00020000);
+    const unsigned gi_lane = (unsigned)(((g * 16 + (lane & 15)) * T) * (3 * GRU_H) + 48 * Jc + 4 * q) * 4u; // tile-major rows: [25 J][3 gates][16]
+    const unsigned out_base = (unsigned)((g * 16 * T) * GRU_H + 16 * Jc) * 4u;
+    f32x4 gpre[3];
+    auto request_gi = [&](int t) {
+        if (layer == 0 && helper) {
+            const unsigned so = (unsigned)t * (3 * GRU_H * 4);
+            gpre[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gi, gi_lane, so, 0));
+            gpre[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gi, gi_lane + 64u, so, 0));
+            gpre[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gi, gi_lane + 128u, so, 0));
+        }
+    };
+
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(hx1, 0, 4 * n_rt * GRU_J * 1024, 0x00020000);
+    const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(hx2, 0, 2 * n_rt * GRU_J * 1024, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    // one flag per unit tile and layer (25 + 25 per group)
+    __attribute__((address_space(1))) unsigned* my_flag =
+        (__attribute__((address_space(1))) unsigned*)((layer ? flags2 : flags1) + g * GRU_J + Jc);
+    // the polling wavefront (14): lanes 0..24 watch layer 1's flags of this group, lanes 32..56 layer 2's
+    __attribute__((address_space(1))) unsigned* poll_flag =
+        (__attribute__((address_space(1))) unsigned*)(lane < 32 ? flags1 + g * GRU_J + (lane < GRU_J ? lane : 0)
+                                                                : flags2 + g * GRU_J + (lane - 32 < GRU_J ? lane - 32 : 0));
+
+    // The polling wavefront (14) does the whole acquisition of a step's operand: it waits until layer 1 has published
+    // `need1` steps and layer 2 `need2` (0 = no requirement), then fetches the row tile's h (25 KB, 25 blocks) straight
+    // into LDS -- sc1 LDS-DMA loads, no registers, no second barrier -- and drains them; the other wavefronts meet it
+    // at the workgroup barrier.  On a deadline it raises the error word instead.  Uniform false on a deadline.
+    const unsigned row0 = (unsigned)(g * GRU_J) * 1024u;
+    auto acquire = [&](unsigned need1, unsigned need2, bool from_h2, unsigned slot) {
+        if (wave == 14) {
+            const unsigned need = lane < 32 ? need1 : need2;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            int dead = 0;
+            for (;;) {
+                const unsigned v = __hip_atomic_load(poll_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(v >= need)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) { dead = 1; break; }
+            }
+            if (!dead) {
+                if (from_h2) {
+#pragma unroll
+                    for (int S = 0; S < GRU_J; ++S)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void*)(hbB + S * 64), 16, lane16,
+                                                                 slot + row0 + S * 1024, 0, WS_AUX_SC1);
+                } else {
+#pragma unroll
+                    for (int S = 0; S < GRU_J; ++S)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)(hbA + S * 64), 16, lane16,
+                                                                 slot + row0 + S * 1024, 0, WS_AUX_SC1);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (lane == 0 && dead) {
+                __hip_atomic_store((__attribute__((address_space(1))) unsigned*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_dead = 1;
+            }
+        }
+    };
+    auto barrier_alive = [&]() -> bool {
+        __syncthreads();
+        return *s_dead == 0; // uniform: every wavefront reads the same word after the barrier
+    };
+
+    // one chain of one gate of one matrix: this gate wavefront's fragments x the row tile's h in LDS -> its slot of
+    // xch (layer 1: R1 h1; layer 2: R2 h2, second half) or xci (layer 2: W_ih h1, first half; xci follows xch)
+    const unsigned xoff_s = (unsigned)__builtin_amdgcn_readfirstlane((((layer && !ws) ? 12 : 0) + (tslot * 3 + wg) * 2 + kp) * 1024);
+    auto chain = [&](const f32x4* hsrc) {
+        const f32x4* hb = hsrc + kp * 64 + lane; // chain kp: super-steps kp, kp + 2, ...
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            if (i < NW - 1 || kp == 0) { // the odd chain has 12 blocks, the even one 13
+                const f32x4 hv = hb[i * 128];
+                a = MFMA16(w[i].x, hv.x, a);
+                a = MFMA16(w[i].y, hv.y, a);
+                a = MFMA16(w[i].z, hv.z, a);
+                a = MFMA16(w[i].w, hv.w, a);
+            }
+        }
+        unsigned xoff = xoff_s;
+        asm volatile("" : "+s"(xoff)); // the per-lane address is formed here, per step: hoisted, it would be spilled
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(xch) + xoff + lane16) = a;
+    };
+
+    // gate math + publish of step t: the helper wavefront of each tile.  `first`: h_{t-1} = 0, so R h + Rb = Rb.
+    // Layer 1: gi from gpre; layer 2: W_ih h1_t from xci (+ Wb).
+    auto gates_and_publish = [&](int t, bool first) {
+        if (helper) {
+            const f32x4* bt = btab + tslot * 24 + q;
+            const int x0 = tslot * 6 * 64 + lane;
+            f32x4 z4, r4, h;
+            {
+                f32x4 gi = layer ? (xci[x0] + xci[x0 + 64]) + bt[12] : gpre[0];
+                f32x4 a = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : xch[x0] + xch[x0 + 64];
+                const f32x4 b = bt[0];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z4[r] = fast_sigmoid(gi[r] + (a[r] + b[r]));
+            }
+            {
+                f32x4 gi = layer ? (xci[x0 + 128] + xci[x0 + 192]) + bt[16] : gpre[1];
+                f32x4 a = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : xch[x0 + 128] + xch[x0 + 192];
+                const f32x4 b = bt[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) r4[r] = fast_sigmoid(gi[r] + (a[r] + b[r]));
+            }
+            {
+                f32x4 gi = layer ? (xci[x0 + 256] + xci[x0 + 320]) + bt[20] : gpre[2];
+                f32x4 a = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : xch[x0 + 256] + xch[x0 + 320];
+                const f32x4 b = bt[8];
+                const f32x4 hp = hpv[tslot * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float n = fast_tanh(gi[r] + r4[r] * (a[r] + b[r]));
+                    h[r] = (1.0f - z4[r]) * n + z4[r] * hp[r];
+                }
+            }
+            hpv[tslot * 64 + lane] = h;
+            if (layer == 0) {
+                const unsigned off = (unsigned)((((t & 3) * n_rt + g) * GRU_J + J) * 1024);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs1, lane16, off, WS_AUX_SC1);
+            } else {
+                const unsigned off = (unsigned)((((t & 1) * n_rt + g) * GRU_J + J) * 1024);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs2, lane16, off, WS_AUX_SC1);
+            }
+            // this wavefront stored the whole tile: it drains and raises the tile's flag itself
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(my_flag, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (layer && !(variant & 2)) { // the row-major copy the next layer (fc2) reads: not part of the hand-off
+                unsigned l16 = lane16;
+                asm volatile("" : "+v"(l16)); // the lane's offset is formed here, per step: hoisted, it would be spilled
+                const unsigned out_lane = ((l16 >> 4) & 15u) * (unsigned)(T * GRU_H * 4) + (l16 >> 8) * 16u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs_out, out_lane, out_base + (unsigned)t * (GRU_H * 4), 0);
+            }
+        }
+    };
+
+    if (layer == 0) {
+        request_gi(0);
+        gates_and_publish(0, true); // t = 0: gi only (no product: h_{-1} = 0)
+        for (int t = 1; t < T; ++t) {
+            // h1_{t-1} of every peer, and -- before slot t % 4 is overwritten -- h1_{t-4} consumed by every layer-2 peer
+            // (layer 2 reads h1_s in its step s: it has published h2_{t-4}, flag t - 3, only after that)
+            request_gi(t);
+            acquire((unsigned)t, (t >= 4 && !(variant & 4)) ? (unsigned)(t - 3) : 0u, false, (unsigned)(((t - 1) & 3) * n_rt * GRU_J) * 1024u);
+            if (!barrier_alive()) return;
+            if (gate_wave && tile_ok) chain(hbA);
+            __syncthreads();
+            gates_and_publish(t, false);
+        }
+    } else {
+        // step t: gi2_t = W_ih h1_t on the first half's chains WHILE the poller waits for the peers' h2_{t-1} and fetches
+        // it; then R2 h2_{t-1} on the second half's; then the gates -- and while the helper does those and publishes, the
+        // poller already fetches h1_{t+1} (layer 1 runs ahead through its ring of four slots).  On the chain from one
+        // publish to the next: flag, fetch of h2, ONE product phase of 104 MFMAs per SIMD, gates, drain.
+        const bool useA = !(variant & 1);
+        acquire(useA ? 1u : 0u, 0u, false, 0u);
+        if (!barrier_alive()) return;
+        for (int t = 0; t < T; ++t) {
+            if (t >= 1) acquire(0u, (unsigned)t, true, (unsigned)(((t - 1) & 1) * n_rt * GRU_J) * 1024u);
+            if (gate_wave && ws == 0 && useA && !(variant & 32)) chain(hbA);
+            if (!barrier_alive()) return;
+            if (gate_wave && ws == 1 && t >= 1) chain(hbB);
+            __syncthreads();
+            if (t + 1 < T) acquire(useA ? (unsigned)(t + 2) : 0u, 0u, false, (unsigned)(((t + 1) & 3) * n_rt * GRU_J) * 1024u);
+            gates_and_publish(t, t == 0);
+            if (!barrier_alive()) return;
+        }
+    }
+}
+
 // geometry of the pipelined launch: G groups of 38 workgroups, RT row tiles per group
 bool fvad_gru_ws2_shape(long n_seq_pad, int n_cu, int* RT, int* G)
 {
@@ -552,6 +812,13 @@ int fvad_launch_gru_ws2(const float* gi1, const float* R1frag, const float* bR1,
     const int n_rt = (int)(n_seq_pad / 16);
     float* hx1 = hx;                                    // four slots
     float* hx2 = hx + (size_t)4 * n_rt * GRU_J * 256;   // two slots
+    if (RT == 1 && !(variant & 8)) { // K split over 16 wavefronts (variant 8: the 8-wavefront kernel, for comparison)
+        const size_t lds_k = 84 * 1024; // 65 KB used; more than half of a CU's LDS: one workgroup per CU
+        if (hipFuncSetAttribute((const void*)gru_ws2k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return -2;
+        hipLaunchKernelGGL(gru_ws2k_kernel, dim3((unsigned)(G * 38)), dim3(1024), lds_k, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
+                           hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant);
+        return 0;
+    }
     // more than half of a CU's 160 KB of LDS: one workgroup per CU (all workgroups of the launch spin on each other)
     const size_t need = (size_t)(4 * GRU_J + RT * 14) * 1024 + 32;
     const size_t lds = need > 84 * 1024 ? need : 84 * 1024;

@@ -33,5 +33,5 @@ try:
 finally:
     stop = True
     th.join()
-print("mismatches:", bad)
+print("mismatches:", bad, " fallback passes:", ctx.ws_fallbacks())
 sys.exit(1 if bad else 0)
