@@ -394,7 +394,7 @@ struct GruChoice {
     int waves;
 };
 
-constexpr size_t kWsSyncWords = 520; // 2 x 256 flags + error word, padded to a multiple of 16 bytes
+constexpr size_t kWsSyncWords = 520 + 2000; // 2 x 256 flags + error word, padded to a multiple of 16 bytes; then gru_ws2k's step trace (ws2_variant 64)
 
 // gru_ws launches spin on each other's flags, so two of them must not share the chip half-resident.
 // Within a process every such launch waits (on the GPU) for the previous one on the same device; across
@@ -992,7 +992,7 @@ static int apply_option(fvad_ctx* ctx, const std::string& name, const char* valu
         else { char* end = nullptr; tn.ws_spin_ticks = strtoull(v.c_str(), &end, 10); if (!end || *end) return FVAD_ERR_INVALID_ARGUMENT; }
     } else if (name == "ws2_variant") { // timing-only builds of gru_ws2_kernel's step (wrong results): tools/ws2_variants.py
         long c = 0;
-        if (!unset && (!to_long(c) || c < 0 || c > 63)) return FVAD_ERR_INVALID_ARGUMENT;
+        if (!unset && (!to_long(c) || c < 0 || c > 127)) return FVAD_ERR_INVALID_ARGUMENT;
         tn.ws2_variant = (int)c;
     } else if (name == "no_pipeline") { if (!to_bool(tn.no_pipeline)) return FVAD_ERR_INVALID_ARGUMENT; }
     else if (name == "trace_kernels") { if (!to_bool(tn.trace_kernels)) return FVAD_ERR_INVALID_ARGUMENT; }
@@ -1217,6 +1217,18 @@ int fvad_ctx_nn_math_effective(const fvad_ctx* ctx)
 }
 
 const char* fvad_ctx_last_nn_path(const fvad_ctx* ctx) { return ctx ? ctx->last_nn_path.c_str() : ""; }
+
+// diagnostics for tools/ws2_trace.py, not part of the ABI in include/fvad.h: the step trace gru_ws2k_kernel leaves behind
+// the polled words when the context option ws2_variant has bit 64 set (2 x 1000 shader-clock stamps)
+int fvad_debug_ws_trace(fvad_ctx* ctx, uint32_t* out, int n_words)
+{
+    if (!ctx || !out || n_words < 0 || n_words > 2000) return FVAD_ERR_INVALID_ARGUMENT;
+    if (!ctx->ws.ws_sync) return FVAD_ERR_INVALID_ARGUMENT;
+    hipSetDevice(ctx->device);
+    FVAD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FVAD_HIP(ctx, hipMemcpy(out, ctx->ws.ws_sync + 520, (size_t)n_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return FVAD_OK;
+}
 
 int fvad_ctx_ws_fallbacks(fvad_ctx* ctx, uint64_t* n)
 {

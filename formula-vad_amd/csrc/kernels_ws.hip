@@ -540,6 +540,7 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
 // One row tile per group (16 wavefronts x 128 VGPRs leave no room for a second one's operands): up to 6 groups = 96
 // sequences -- BASELINE config 3's 82 chunks, every live push; the 8-wavefront kernel above serves 2 to 4 row tiles
 // per group.
+template <bool TRACE>
 __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict__ gi1, const float* __restrict__ R1frag,
                                                         const float* __restrict__ bR1, const float* __restrict__ W2frag,
                                                         const float* __restrict__ bW2, const float* __restrict__ R2frag,
@@ -559,6 +560,11 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     f32x4* hpv = xci + 12 * 64;
     f32x4* btab = hpv + 2 * 64;
     volatile int* s_dead = reinterpret_cast<volatile int*>(btab + 48);
+    // variant & 64 (tools/ws2_trace.py): the first layer-1 and the first layer-2 workgroup of group 0 keep shader-clock
+    // stamps of every step's events in LDS and copy them behind the polled words (flags1 + 520 ...) when they are done
+    __attribute__((address_space(3))) char* lds3 = (__attribute__((address_space(3))) char*)smem; // LDS-DMA targets, trace
+    __attribute__((address_space(3))) unsigned* trl = (__attribute__((address_space(3))) unsigned*)(lds3 + (2 * GRU_J * 64 + 24 * 64 + 2 * 64 + 49) * 16);
+#define WS_STAMP(t_, k_) do { if (TRACE && tr && lane == 0) trl[(t_) * 12 + (k_)] = (unsigned)clock64(); } while (0)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -568,6 +574,7 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     const int r38 = blockIdx.x - g * 38;
     const int layer = r38 >= 13;
     const int pair = layer ? r38 - 13 : r38;      // layer 1: pair of unit tiles; layer 2: the unit tile
+    const bool tr = TRACE && g == 0 && (r38 == 0 || r38 == 13);
     const bool gate_wave = wave < 12;
     const int ws = gate_wave ? wave / 6 : (wave == 13); // half: layer 1 the tile of the pair, layer 2 the matrix (W_ih / R2)
     const int gk = wave % 6;
@@ -644,31 +651,37 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     // into LDS -- sc1 LDS-DMA loads, no registers, no second barrier -- and drains them; the other wavefronts meet it
     // at the workgroup barrier.  On a deadline it raises the error word instead.  Uniform false on a deadline.
     const unsigned row0 = (unsigned)(g * GRU_J) * 1024u;
-    auto acquire = [&](unsigned need1, unsigned need2, bool from_h2, unsigned slot) {
+    auto acquire = [&](unsigned need1, unsigned need2, bool from_h2, unsigned slot, int st, int ev) {
         if (wave == 14) {
+            WS_STAMP(st, ev);
             const unsigned need = lane < 32 ? need1 : need2;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             int dead = 0;
+            // (one load at a time: a flag load takes ~1800 clocks to come back, but four of them in flight ~450 clocks apart
+            // made every step SLOWER -- 15.8k clocks against 14.8k: the extra sc1 traffic to the groups' flag lines delays
+            // the fetches and the drains more than the earlier notice saves; tools/ws2_trace.py)
             for (;;) {
                 const unsigned v = __hip_atomic_load(poll_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__all(v >= need)) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) { dead = 1; break; }
             }
+            WS_STAMP(st, ev + 1);
             if (!dead) {
                 if (from_h2) {
 #pragma unroll
                     for (int S = 0; S < GRU_J; ++S)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void*)(hbB + S * 64), 16, lane16,
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void*)(lds3 + (GRU_J + S) * 1024), 16, lane16,
                                                                  slot + row0 + S * 1024, 0, WS_AUX_SC1);
                 } else {
 #pragma unroll
                     for (int S = 0; S < GRU_J; ++S)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)(hbA + S * 64), 16, lane16,
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)(lds3 + S * 1024), 16, lane16,
                                                                  slot + row0 + S * 1024, 0, WS_AUX_SC1);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            WS_STAMP(st, ev + 2);
             if (lane == 0 && dead) {
                 __hip_atomic_store((__attribute__((address_space(1))) unsigned*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *s_dead = 1;
@@ -697,7 +710,7 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
             }
         }
         unsigned xoff = xoff_s;
-        asm volatile("" : "+s"(xoff)); // the per-lane address is formed here, per step: hoisted, it would be spilled
+        if (!TRACE) asm volatile("" : "+s"(xoff)); // the per-lane address is formed here, per step: hoisted, it would be spilled
         *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(xch) + xoff + lane16) = a;
     };
 
@@ -705,6 +718,7 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     // Layer 1: gi from gpre; layer 2: W_ih h1_t from xci (+ Wb).
     auto gates_and_publish = [&](int t, bool first) {
         if (helper) {
+            if (wave == 12) WS_STAMP(t, 6);
             const f32x4* bt = btab + tslot * 24 + q;
             const int x0 = tslot * 6 * 64 + lane;
             f32x4 z4, r4, h;
@@ -742,7 +756,9 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs2, lane16, off, WS_AUX_SC1);
             }
             // this wavefront stored the whole tile: it drains and raises the tile's flag itself
+            if (wave == 12) WS_STAMP(t, 7);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (wave == 12) WS_STAMP(t, 8);
             if (lane == 0) __hip_atomic_store(my_flag, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (layer && !(variant & 2)) { // the row-major copy the next layer (fc2) reads: not part of the hand-off
                 unsigned l16 = lane16;
@@ -760,9 +776,11 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
             // h1_{t-1} of every peer, and -- before slot t % 4 is overwritten -- h1_{t-4} consumed by every layer-2 peer
             // (layer 2 reads h1_s in its step s: it has published h2_{t-4}, flag t - 3, only after that)
             request_gi(t);
-            acquire((unsigned)t, (t >= 4 && !(variant & 4)) ? (unsigned)(t - 3) : 0u, false, (unsigned)(((t - 1) & 3) * n_rt * GRU_J) * 1024u);
+            acquire((unsigned)t, (t >= 4 && !(variant & 4)) ? (unsigned)(t - 3) : 0u, false, (unsigned)(((t - 1) & 3) * n_rt * GRU_J) * 1024u, t, 0);
             if (!barrier_alive()) return;
+            if (wave == 0) WS_STAMP(t, 4);
             if (gate_wave && tile_ok) chain(hbA);
+            if (wave == 0) WS_STAMP(t, 5);
             __syncthreads();
             gates_and_publish(t, false);
         }
@@ -772,19 +790,27 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
         // poller already fetches h1_{t+1} (layer 1 runs ahead through its ring of four slots).  On the chain from one
         // publish to the next: flag, fetch of h2, ONE product phase of 104 MFMAs per SIMD, gates, drain.
         const bool useA = !(variant & 1);
-        acquire(useA ? 1u : 0u, 0u, false, 0u);
+        acquire(useA ? 1u : 0u, 0u, false, 0u, 0, 0);
         if (!barrier_alive()) return;
         for (int t = 0; t < T; ++t) {
-            if (t >= 1) acquire(0u, (unsigned)t, true, (unsigned)(((t - 1) & 1) * n_rt * GRU_J) * 1024u);
+            if (t >= 1) acquire(0u, (unsigned)t, true, (unsigned)(((t - 1) & 1) * n_rt * GRU_J) * 1024u, t, 0);
             if (gate_wave && ws == 0 && useA && !(variant & 32)) chain(hbA);
+            if (wave == 0) WS_STAMP(t, 3);
             if (!barrier_alive()) return;
+            if (wave == 6) WS_STAMP(t, 4);
             if (gate_wave && ws == 1 && t >= 1) chain(hbB);
+            if (wave == 6) WS_STAMP(t, 5);
             __syncthreads();
-            if (t + 1 < T) acquire(useA ? (unsigned)(t + 2) : 0u, 0u, false, (unsigned)(((t + 1) & 3) * n_rt * GRU_J) * 1024u);
+            if (t + 1 < T) acquire(useA ? (unsigned)(t + 2) : 0u, 0u, false, (unsigned)(((t + 1) & 3) * n_rt * GRU_J) * 1024u, t, 9);
             gates_and_publish(t, t == 0);
             if (!barrier_alive()) return;
         }
     }
+    if (TRACE && tr) {
+        __syncthreads();
+        for (int i = tid; i < T * 12 && i < 1000; i += 1024) flags1[520 + layer * 1000 + i] = trl[i];
+    }
+#undef WS_STAMP
 }
 
 // geometry of the pipelined launch: G groups of 38 workgroups, RT row tiles per group
@@ -814,8 +840,14 @@ int fvad_launch_gru_ws2(const float* gi1, const float* R1frag, const float* bR1,
     float* hx2 = hx + (size_t)4 * n_rt * GRU_J * 256;   // two slots
     if (RT == 1 && !(variant & 8)) { // K split over 16 wavefronts (variant 8: the 8-wavefront kernel, for comparison)
         const size_t lds_k = 84 * 1024; // 65 KB used; more than half of a CU's LDS: one workgroup per CU
-        if (hipFuncSetAttribute((const void*)gru_ws2k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return -2;
-        hipLaunchKernelGGL(gru_ws2k_kernel, dim3((unsigned)(G * 38)), dim3(1024), lds_k, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
+        if (variant & 64) { // step trace (tools/ws2_trace.py)
+            if (hipFuncSetAttribute((const void*)gru_ws2k_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return -2;
+            hipLaunchKernelGGL(gru_ws2k_kernel<true>, dim3((unsigned)(G * 38)), dim3(1024), lds_k, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
+                               hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant);
+            return 0;
+        }
+        if (hipFuncSetAttribute((const void*)gru_ws2k_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return -2;
+        hipLaunchKernelGGL(gru_ws2k_kernel<false>, dim3((unsigned)(G * 38)), dim3(1024), lds_k, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
                            hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant);
         return 0;
     }
