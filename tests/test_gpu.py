@@ -1536,6 +1536,23 @@ ctx.set_option("ws_spin_ticks", None)
 assert np.array_equal(g2, lat), np.abs(g2 - lat).max()
 assert np.abs(p2 - lat).max() <= 2e-6              # its own family: layer 2's input projection is computed in the kernel
 assert (np.abs(g[:3] - ref) / np.maximum(np.abs(ref), 1e-2)).max() <= 1e-4
+# 82 sequences = one row tile per group: the 16-wavefront form of the pipelined kernel (gru_ws2k_kernel).  Same bits
+# as the 8-wavefront form (ws2_variant 8 forces it) and with the step trace on (64); same fallback chain behind it
+f82 = f[:82]
+k16 = ctx.nsnet2_forward(f82)
+assert "gru_ws2" in ctx.last_nn_path(), ctx.last_nn_path()
+assert np.array_equal(k16, p2[:82])                # a sequence's bits do not depend on the batch it sits in
+for variant in ("8", "64"):
+    ctx.set_option("ws2_variant", variant)
+    assert np.array_equal(ctx.nsnet2_forward(f82), k16), variant
+ctx.set_option("ws2_variant", None)
+assert ctx.ws_fallbacks() == 2
+ctx.set_option("ws_spin_ticks", "0")
+g3 = ctx.nsnet2_forward(f82)
+assert ctx.ws_fallbacks() == 3, ctx.ws_fallbacks()
+ctx.set_option("ws_spin_ticks", None)
+assert np.array_equal(g3, lat[:82]), np.abs(g3 - lat[:82]).max()
+assert np.array_equal(ctx.nsnet2_forward(f82), k16)   # and the next pass is the pipelined kernel's again
 print("FALLBACK_OK")
 """
 
