@@ -301,6 +301,7 @@ static void free_workspace_nn(Workspace& ws)
     if (ws.h_descs) hipHostFree(ws.h_descs);
     ws.descs = nullptr; ws.h_descs = nullptr;
     ws.cap_chunks = 0;
+    ws.cap_rows = 0;
 }
 
 int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
@@ -311,28 +312,26 @@ int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
     const bool same_widths = ws.w_a1 == dm.w_a1 && ws.w_gi == dm.w_gi && ws.w_h == dm.w_h && ws.w_f == dm.w_f;
     // bf16x3 mode: h1 / h2 and the fc2 / fc3 outputs as three-piece fragments (13 / 19 K-steps of 3 KB per 16 rows),
     // allocated only for contexts that run in that mode
-    if (nn_math_effective(ctx) == FVAD_NN_MATH_BF16X3 && (need > ws.b3_cap_chunks || T > ws.b3_T)) {
+    // (capacities are ROWS -- padded sequences x steps: a long sequence and a wide batch need not fit at once)
+    const size_t need_rows = (size_t)need * (size_t)T;
+    if (nn_math_effective(ctx) == FVAD_NN_MATH_BF16X3 && need_rows > ws.b3_cap_rows) {
         hipStreamSynchronize(ctx->stream);
         float** b3bufs[] = {&ws.b3_hs1, &ws.b3_hs2, &ws.b3_f2, &ws.b3_f3};
         for (float** b : b3bufs) { if (*b) hipFree(*b); *b = nullptr; }
-        const long G3 = std::max(need, ws.b3_cap_chunks);
-        const int T3 = std::max(T, ws.b3_T);
-        const size_t rows3 = (size_t)G3 * T3;
+        const size_t rows3 = need_rows;
         int rc3;
         if ((rc3 = dev_alloc(ctx, &ws.b3_hs1, rows3 * 624, true))) return rc3;
         if ((rc3 = dev_alloc(ctx, &ws.b3_hs2, rows3 * 624, true))) return rc3;
         if ((rc3 = dev_alloc(ctx, &ws.b3_f2, rows3 * 912, true))) return rc3;
         if ((rc3 = dev_alloc(ctx, &ws.b3_f3, rows3 * 912, true))) return rc3;
-        ws.b3_cap_chunks = G3;
-        ws.b3_T = T3;
+        ws.b3_cap_rows = rows3;
         ws.generation++;
     }
-    if (need <= ws.cap_chunks && T <= ws.T && same_widths) return FVAD_OK;
+    if (need <= ws.cap_chunks && need_rows <= ws.cap_rows && same_widths) return FVAD_OK;
     hipStreamSynchronize(ctx->stream);
-    free_workspace_nn(ws);
     const long G = std::max(need, ws.cap_chunks);
-    const int TT = std::max(T, ws.T);
-    const size_t rows = (size_t)G * TT;
+    const size_t rows = std::max(need_rows, ws.cap_rows);
+    free_workspace_nn(ws);
     int rc;
     FVAD_HIP(ctx, hipMalloc((void**)&ws.descs, (size_t)G * sizeof(ChunkDesc)));
     FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_descs, 2 * (size_t)G * sizeof(ChunkDesc), hipHostMallocDefault));
@@ -354,8 +353,8 @@ int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
     if ((rc = dev_alloc(ctx, &ws.gains, rows * kFeatStride, true))) return rc;
     ws.w_a1 = dm.w_a1; ws.w_gi = dm.w_gi; ws.w_h = dm.w_h; ws.w_f = dm.w_f;
     ws.cap_chunks = G;
+    ws.cap_rows = rows;
     ws.generation++;
-    ws.T = TT;
     return FVAD_OK;
 }
 
@@ -665,7 +664,7 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     if (b3) {
         // bf16x3: the five dense layers as six bf16 MFMAs per product on exact three-piece splits (kernels_b3.hip), the
         // two recurrences on the f32 matrix cores (gru_rec3, which writes h a second time as three-piece fragments)
-        if (!ws.b3_hs1 || n_pad > ws.b3_cap_chunks || T > ws.b3_T) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "bf16x3 workspace not allocated");
+        if (!ws.b3_hs1 || (size_t)n_pad * (size_t)T > ws.b3_cap_rows) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "bf16x3 workspace not allocated");
         auto gemm_b3 = [&](const float* A, int in_ts, int a_ld, const DevBuf& W, const float* b, float* Cc, int out, int c_ld, int seq_T,
                            long row_tiles, int nt, int nblk, int K, int act, int valid, int mT, int mskip) {
             return fvad_launch_panel_gemm_b3(A, in_ts, a_ld, W.p, b, Cc, out, c_ld, seq_T, row_tiles, nt, nblk, K, act, valid, mT, mskip, ctx->n_cu, st);

@@ -86,12 +86,12 @@ struct DeviceModel {
 
 struct Workspace {
     long cap_chunks = 0; // padded chunk capacity (multiple of 768: covers every batch padding)
-    int T = 0;
+    size_t cap_rows = 0; // rows (padded sequences x steps per sequence) the NSNet2 buffers hold
     int w_a1 = 0, w_gi = 0, w_h = 0, w_f = 0; // row widths the buffers were allocated for (DeviceModel::w_*)
     // bf16x3 mode only (allocated when a context first runs in it): h1 / h2 and the fc2 / fc3 outputs as three-piece
     // fragments, 13 and 19 K-steps of 3 KB per 16 rows
     float *b3_hs1 = nullptr, *b3_hs2 = nullptr, *b3_f2 = nullptr, *b3_f3 = nullptr;
-    long b3_cap_chunks = 0; int b3_T = 0;
+    size_t b3_cap_rows = 0; // rows (padded sequences x steps) the bf16x3 buffers hold
     ChunkDesc* descs = nullptr;
     ChunkDesc* h_descs = nullptr; // pinned, two slots of cap_chunks descriptors
     hipEvent_t desc_ev[2] = {nullptr, nullptr}; // slot's upload has left the host

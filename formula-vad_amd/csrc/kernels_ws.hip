@@ -838,7 +838,10 @@ int fvad_launch_gru_ws2(const float* gi1, const float* R1frag, const float* bR1,
     const int n_rt = (int)(n_seq_pad / 16);
     float* hx1 = hx;                                    // four slots
     float* hx2 = hx + (size_t)4 * n_rt * GRU_J * 256;   // two slots
-    if (RT == 1 && !(variant & 8)) { // K split over 16 wavefronts (variant 8: the 8-wavefront kernel, for comparison)
+    // K split over 16 wavefronts (variant 8: the 8-wavefront kernel, for comparison); it addresses gi and h2 through 32-bit
+    // buffer offsets, so a launch whose gi exceeds 2 GiB (a few sequences of tens of thousands of steps) keeps the other kernel
+    const bool fits32 = (long long)n_rt * 16 * T * (3 * GRU_H) * 4 < (1ll << 31);
+    if (RT == 1 && fits32 && !(variant & 8)) {
         const size_t lds_k = 84 * 1024; // 65 KB used; more than half of a CU's LDS: one workgroup per CU
         if (variant & 64) { // step trace (tools/ws2_trace.py)
             if (hipFuncSetAttribute((const void*)gru_ws2k_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return -2;

@@ -188,6 +188,12 @@ def test_nsnet2_forward_matches_oracle(fv, gpu_ctx, weights7):
         ref = np.stack([orc.nsnet2_forward(weights7, s) for s in f])
         assert_rel(g, ref, 1e-4, floor=1e-2, what=f"gains n_seq={n_seq} T={T}")
         assert g.min() >= 0 and g.max() <= 1
+    # one long sequence (its padded gi is 2.2 GB: past the 32-bit offsets of the 16-wavefront pipelined recurrence, which
+    # must hand the launch to the kernel with 64-bit addresses)
+    f = rng.uniform(-11, 2, (1, 14400, 161)).astype(np.float32)
+    g = gpu_ctx.nsnet2_forward(f)
+    ref = orc.nsnet2_forward(weights7, f[0])
+    assert_rel(g[0], ref, 1e-4, floor=1e-2, what="gains of one 14400-step sequence")
     # the GRU state is reset for every sequence: batch order cannot matter
     f = rng.uniform(-11, 2, (40, 54, 161)).astype(np.float32)
     g = gpu_ctx.nsnet2_forward(f)

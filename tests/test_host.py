@@ -54,7 +54,7 @@ def test_bench_gpus_n_without_enough_gpus_is_refused_before_any_rank_starts():
     assert r.returncode == 2 and "rank" in r.stderr
 
 
-@pytest.mark.parametrize("unit", ["kernels_b3.hip", "kernels_h3.hip", "kernels_nn.hip"])
+@pytest.mark.parametrize("unit", ["kernels_b3.hip", "kernels_h3.hip", "kernels_nn.hip", "kernels_ws.hip"])
 def test_kernels_with_inline_lds_reads_compile_without_spills(unit):
     # The persistent GEMMs and the LDS-DMA recurrences read weight fragments with inline ds_read_b128 / global_load_lds
     # that the compiler knows nothing about: a spilled register there is not slow but unsafe (its in-flight read lands
