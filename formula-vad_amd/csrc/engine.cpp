@@ -900,7 +900,10 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
             FVAD_HIP(ctx, hipEventRecord(ws.desc_ev[slot], ctx->stream));
         }
         time_begin(ctx, "stft320_logpow");
-        fvad_launch_stft(dd, (int)n, ctx->tb, ws.feat, ws.spec, ctx->stream);
+        // a launch of a few chunks leaves most CUs idle and a chunk's frames are a latency chain on one workgroup:
+        // cut them over 2 or 3 workgroups per chunk (the same instructions per frame: the same bits)
+        const int fft_parts = n <= 85 ? 3 : (n <= 128 ? 2 : 1);
+        fvad_launch_stft(dd, (int)n, ctx->tb, ws.feat, ws.spec, ctx->stream, fft_parts);
         time_end(ctx);
         // parity taps: K1's own outputs (the buffers the network and K3 read), straight to the caller
         for (const Tap& t : taps) {
@@ -918,7 +921,7 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
         rc = run_nn(ctx, n_pad, kRowsPerChunk, kWarmupRows);
         if (rc) return rc;
         time_begin(ctx, "istft320_ola_up3");
-        fvad_launch_istft(dd, (int)n, ctx->tb, ws.spec, ws.gains, kFramesPerChunk, 0, ctx->stream);
+        fvad_launch_istft(dd, (int)n, ctx->tb, ws.spec, ws.gains, kFramesPerChunk, 0, ctx->stream, fft_parts);
         time_end(ctx);
         for (size_t t : touched) jobs[t].cur ^= 1;
         job = j;

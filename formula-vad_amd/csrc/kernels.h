@@ -130,12 +130,13 @@ int fvad_launch_panel_gemm_b3(const float* A, int in_ts, int a_ld, const float* 
                               int n_valid_tiles, int map_T, int map_skip, int n_wg, hipStream_t stream);
 
 // K1: per chunk: RMS, decimate, STFT-320, log-power features (+ warm-up rows)
+// (parts: 1, or 2 / 3 to cut a chunk's frames over several workgroups in launches of a few chunks; same bits)
 void fvad_launch_stft(const ChunkDesc* descs, int n_chunks, FftTables tb, float* feat,
-                      float* spec, hipStream_t stream);
+                      float* spec, hipStream_t stream, int parts = 1);
 // K3: per chunk: gain, inverse STFT, overlap-add, x3 upsample
 void fvad_launch_istft(const ChunkDesc* descs, int n_chunks, FftTables tb, const float* spec,
                        const float* gains, int gains_rows_per_chunk, int gains_row0,
-                       hipStream_t stream);
+                       hipStream_t stream, int parts = 1);
 // K4: n-point periodic-Hann rFFT magnitude + band sum over [min_bin, max_bin], n = pl.n
 void fvad_launch_vadfft(const float* den, long n_frames, VadFftPlan pl, int min_bin, int max_bin,
                         float* band_sum, float* bins_or_null, hipStream_t stream);

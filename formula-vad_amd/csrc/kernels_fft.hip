@@ -315,9 +315,13 @@ __device__ __forceinline__ float wave_sum(float v)
 constexpr int K1_THREADS = 256;
 constexpr int K1_DEC = (kRowsPerChunk + 1) * kNHop; // 8800 decimated samples: frames -4..49
 
+// parts == 1: one workgroup per chunk does everything.  parts > 1 (launches of a few chunks, where a chunk's 27 frame
+// pairs on one workgroup are a latency chain): blockIdx.y < parts transforms its share of the frame pairs from its share
+// of the samples; blockIdx.y == parts streams the whole chunk for the RMS (the sample -> thread assignment and the order
+// of that sum do not change) and writes the carries.  Every value is computed by the same instructions either way.
 __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __restrict__ descs,
                                                           FftTables tb, float* __restrict__ feat,
-                                                          float* __restrict__ spec)
+                                                          float* __restrict__ spec, int parts)
 {
     __shared__ __attribute__((aligned(16))) float dec[K1_DEC];
     __shared__ __attribute__((aligned(16))) float zb[4][2][2 * 160];
@@ -330,6 +334,12 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    constexpr int N_PAIRS = kRowsPerChunk / 2; // 27
+    const int part = blockIdx.y;
+    const bool do_fft = parts == 1 || part < parts;
+    const bool do_rms = parts == 1 || part == parts;
+    const int pa = parts == 1 ? 0 : (do_fft ? (N_PAIRS * part) / parts : 0);          // this workgroup's frame pairs
+    const int pb = parts == 1 ? N_PAIRS : (do_fft ? (N_PAIRS * (part + 1)) / parts : 0);
 
     for (int i = tid; i < kNFft; i += K1_THREADS) s_win[i] = tb.win320[i];
     for (int i = tid; i < 160; i += K1_THREADS) s_st[i] = tb.st320[i];
@@ -343,7 +353,10 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
         // must not depend on where a launch or a push happens to start
         constexpr int hist = (kWarmupRows + 1) * kNHop * kDown; // 2400
         const int dec0 = (kWarmupRows + 1) * kNHop;             // 800: where the chunk's own decimated samples start
-        const int i4_begin = d.first ? hist / 4 : 0;
+        // float4s this workgroup needs: all of them for the RMS; for frame pairs [pa, pb) the decimated samples
+        // [320 pa, 320 pb + 160), i.e. raw samples [960 pa, 960 pb + 480)
+        const int i4_lo = do_rms ? 0 : 240 * pa, i4_hi = do_rms ? (hist + kChunk48) / 4 : 240 * pb + 120;
+        const int i4_begin = (d.first && hist / 4 > i4_lo) ? hist / 4 : i4_lo;
         auto take = [&](unsigned s, float x) { // sample s of [history | chunk]
             const unsigned s3 = s / 3u;
             if (s3 * 3u == s) dec[s3] = x;
@@ -358,9 +371,9 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
         const f32x4* src4 = reinterpret_cast<const f32x4*>(d.in - hist);
         const s16x4* src16 = reinterpret_cast<const s16x4*>(d.in16 - hist);
         const bool pcm16 = d.in16 != nullptr;
-        const int n4 = (hist + kChunk48) / 4;
+        const int n4 = i4_hi;
         constexpr int LD_BATCH = 9;
-        for (int base = 0; base < n4; base += LD_BATCH * K1_THREADS) {
+        for (int base = (i4_lo / (LD_BATCH * K1_THREADS)) * (LD_BATCH * K1_THREADS); base < n4; base += LD_BATCH * K1_THREADS) {
             f32x4 v[LD_BATCH];
             if (pcm16) {
                 s16x4 r[LD_BATCH];
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
                 }
             }
         }
-        if (d.last) {
+        if (d.last && do_rms) {
             for (int j = tid; j < kNHop * kDown; j += K1_THREADS) {
                 const int i = kChunk48 - kNHop * kDown + j;
                 d.carry_out->in_tail[j] = pcm16 ? (float)d.in16[i] * (1.0f / 32768.0f) : d.in[i];
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
     ss = wave_sum(ss);
     if (lane == 0) s_red[wave] = ss;
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && do_rms) {
         const float sum = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
         if (d.rms) *d.rms = sqrtf(sum / (float)kChunk48);
     }
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
     // ---- warm-up feature rows of the first chunk of a call come from the carry (zeros at t=0:
     // NSNet2.zig:77-79)
     float* feat_g = feat + (size_t)g * kRowsPerChunk * kFeatStride;
-    if (d.first) {
+    if (d.first && do_rms) {
         const float* ft = d.carry_in->feat_tail;
         for (int i = tid; i < kWarmupRows * kNBins; i += K1_THREADS) {
             const int r = i / kNBins, k = i - r * kNBins;
@@ -436,11 +449,10 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
     float* spec_g = spec + (size_t)g * kFramesPerChunk * kNBins * 2;
     const int fl_begin = d.first ? kWarmupRows : 0;
 
-    constexpr int N_PAIRS = kRowsPerChunk / 2; // 27
-    for (int it = 0; it < (N_PAIRS + 3) / 4; ++it) {
-        const int pi = it * 4 + wave;
+    for (int it = 0; it < (pb - pa + 3) / 4; ++it) {
+        const int pi = pa + it * 4 + wave;
         const int fl = 2 * pi + half;
-        const bool active = (pi < N_PAIRS) && (fl >= fl_begin);
+        const bool active = (pi < pb) && (fl >= fl_begin);
         if (active) {
             cpx v[5];
             const float* x = dec + kNHop * fl;
@@ -464,7 +476,7 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
             const int hh = item / 81;
             const int k = item - hh * 81;
             const int fl2 = 2 * pi + hh;
-            if (pi < N_PAIRS && fl2 >= fl_begin) {
+            if (pi < pb && fl2 >= fl_begin) {
                 const float* z = zb[wave][hh];
                 cpx xk, xnk;
                 int kn;
@@ -501,20 +513,25 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
     }
 }
 
+// parts: 1, or 2 / 3 for launches of a few chunks (parts + 1 workgroups per chunk)
 void fvad_launch_stft(const ChunkDesc* descs, int n_chunks, FftTables tb, float* feat, float* spec,
-                      hipStream_t stream)
+                      hipStream_t stream, int parts)
 {
-    hipLaunchKernelGGL(stft_kernel, dim3(n_chunks), dim3(K1_THREADS), 0, stream, descs, tb, feat,
-                       spec);
+    if (parts < 1 || parts > 3) parts = 1;
+    hipLaunchKernelGGL(stft_kernel, dim3(n_chunks, parts == 1 ? 1 : parts + 1), dim3(K1_THREADS), 0, stream, descs, tb, feat,
+                       spec, parts);
 }
 
 // ============================================================================ K3
 constexpr int K3_FR = kFramesPerChunk + 2; // frames -2..49
 
+// parts > 1 (launches of a few chunks): workgroup blockIdx.y produces the output hops [F0, F1) of the chunk's 50 from
+// the frames F0 - 2 .. F1 - 1 -- the same relation the whole chunk has to frames -2 .. 49, so a part is the same code
+// on a shorter range (two frames per seam are transformed twice, by the same instructions: the same bits).
 __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict__ descs, FftTables tb,
                                                     const float* __restrict__ spec,
                                                     const float* __restrict__ gains,
-                                                    int g_rows, int g_row0)
+                                                    int g_rows, int g_row0, int parts)
 {
     __shared__ __attribute__((aligned(16))) float oa[K3_FR][kNHop]; // first halves y_f[0..160)
     __shared__ __attribute__((aligned(16))) float ob[K3_FR][kNHop]; // second halves y_f[160..320)
@@ -539,9 +556,11 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
     lane_tw_load<5, 32, true>(tw, tb.tw160, p);
     const int k2 = bitrev_lane<32>(p);
 
-    // frames fr = -2..49; fr < 0 belong to the previous chunk of the same lane (g - 1)
-    const int fr_begin = d.first ? 0 : -2;
-    constexpr int N_PAIRS = K3_FR / 2; // 26
+    // frames fr = F0 - 2 .. F1 - 1 (the whole chunk: -2..49); fr < 0 belong to the previous chunk of the same lane (g - 1)
+    const int F0 = (kFramesPerChunk * (int)blockIdx.y) / parts, F1 = (kFramesPerChunk * ((int)blockIdx.y + 1)) / parts;
+    const int fr0 = F0 - 2; // frame in row 0 of oa / ob
+    const int fr_begin = (d.first && F0 == 0) ? 0 : fr0;
+    const int N_PAIRS = (F1 - fr0 + 1) / 2; // 26 for the whole chunk; an odd count leaves the last pair's second frame (F1) unused
     // The spectrogram / gain operands of a frame pair are fetched one iteration ahead (3 items per
     // lane: 12 spectrum floats + 6 gains), so each iteration's global-memory round trip overlaps the
     // previous pair's FFT instead of heading the critical path.
@@ -552,9 +571,9 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
             const int item = lane + 64 * u;
             const int hh = item / 81;
             const int k = item - hh * 81;
-            const int fr = 2 * pi + hh - 2;
+            const int fr = 2 * pi + hh + fr0;
             itm[u] = Item{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (item < 2 * 81 && pi < N_PAIRS && fr >= fr_begin) {
+            if (item < 2 * 81 && pi < N_PAIRS && fr >= fr_begin && fr < F1) {
                 const int gg = fr < 0 ? g - 1 : g;
                 const int f = fr < 0 ? fr + kFramesPerChunk : fr;
                 const float* srow = spec + ((size_t)gg * kFramesPerChunk + f) * kNBins * 2;
@@ -581,8 +600,8 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
             const int item = lane + 64 * u;
             const int hh = item / 81;
             const int k = item - hh * 81;
-            const int fr = 2 * pi + hh - 2;
-            if (item < 2 * 81 && pi < N_PAIRS && fr >= fr_begin) {
+            const int fr = 2 * pi + hh + fr0;
+            if (item < 2 * 81 && pi < N_PAIRS && fr >= fr_begin && fr < F1) {
                 const int kn = 160 - k;
                 float gk = cur[u].gk, gnk = cur[u].gnk;
                 gk = gk < -80.0f ? -80.0f : (gk > 1.0f ? 1.0f : gk);   // NSNet2.zig:295-305
@@ -606,8 +625,8 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
         for (int u = 0; u < 3; ++u) cur[u] = nxt[u];
         __syncthreads();
         {
-            const int fr = 2 * pi + half - 2;
-            if (pi < N_PAIRS && fr >= fr_begin) {
+            const int fr = 2 * pi + half + fr0;
+            if (pi < N_PAIRS && fr >= fr_begin && fr < F1) {
                 const float* z = zb[wave][half];
                 cpx v[5];
 #pragma unroll
@@ -622,8 +641,8 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
                     // inv_fft_buffer[i] *= window[i] * (1/320), NSNet2.zig:335
                     const float y0 = v[k1].r * s_wn[n];
                     const float y1 = v[k1].i * s_wn[n + 1];
-                    if (n < kNHop) { oa[fr + 2][n] = y0; oa[fr + 2][n + 1] = y1; }
-                    else { ob[fr + 2][n - kNHop] = y0; ob[fr + 2][n - kNHop + 1] = y1; }
+                    if (n < kNHop) { oa[fr - fr0][n] = y0; oa[fr - fr0][n + 1] = y1; }
+                    else { ob[fr - fr0][n - kNHop] = y0; ob[fr - fr0][n - kNHop + 1] = y1; }
                 }
             }
         }
@@ -631,22 +650,22 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
     }
 
     // previous-chunk state of the first chunk of a call comes from the carry
-    if (d.first) {
+    if (d.first && F0 == 0) {
         for (int j = tid; j < kNHop; j += 256) ob[1][j] = d.carry_in->ola_tail[j];
         if (tid == 0) s_dm1 = d.carry_in->last_sample;
     } else if (tid == 0) {
-        s_dm1 = ob[0][kNHop - 1] + oa[1][kNHop - 1]; // decimated output sample 8000c - 1
+        s_dm1 = ob[0][kNHop - 1] + oa[1][kNHop - 1]; // decimated output sample 8000c + 160 F0 - 1
     }
     __syncthreads();
 
     // overlap-add (NSNet2.zig:336), d[160 f + j] = y_{f-1}[160 + j] + y_f[j], is folded into the
     // upsampling loop below (each value is formed once, as ob + oa, where it is consumed)
-    auto ola = [&](int mdec) { // decimated output sample mdec of this chunk, 0 <= mdec < 8160
+    auto ola = [&](int mdec) { // decimated output sample mdec of this chunk, 160 F0 <= mdec < 160 F1
         const int f = mdec / kNHop, j = mdec - f * kNHop;
-        return ob[f + 1][j] + oa[f + 2][j];
+        return ob[f - F0 + 1][j] + oa[f - F0 + 2][j];
     };
-    if (d.last) {
-        for (int j = tid; j < kNHop; j += 256) d.carry_out->ola_tail[j] = ob[kFramesPerChunk + 1][j];
+    if (d.last && F1 == kFramesPerChunk) {
+        for (int j = tid; j < kNHop; j += 256) d.carry_out->ola_tail[j] = ob[kFramesPerChunk - F0 + 1][j];
         if (tid == 0) d.carry_out->last_sample = ola(kFramesPerChunk * kNHop - 1);
     }
 
@@ -656,11 +675,11 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
     const float frac1 = 1.0f / 3.0f, frac2 = 2.0f / 3.0f;
     f32x4* out4 = reinterpret_cast<f32x4*>(d.den);
     const float dm1 = s_dm1;
-    for (int w = tid; w < kFramesPerChunk * kNHop / 4; w += 256) {
+    for (int w = F0 * (kNHop / 4) + tid; w < F1 * (kNHop / 4); w += 256) {
         const int m0 = 4 * w;
         const int f = m0 / kNHop, j = m0 - f * kNHop; // 160 % 4 == 0: a float4 never straddles two frames
-        const f32x4 c = *reinterpret_cast<const f32x4*>(&ob[f + 1][j]) + *reinterpret_cast<const f32x4*>(&oa[f + 2][j]);
-        const float pv = m0 > 0 ? ola(m0 - 1) : dm1;
+        const f32x4 c = *reinterpret_cast<const f32x4*>(&ob[f - F0 + 1][j]) + *reinterpret_cast<const f32x4*>(&oa[f - F0 + 2][j]);
+        const float pv = m0 > F0 * kNHop ? ola(m0 - 1) : dm1;
         // std.math.lerp = mulAdd: (b - a) * t + a, fused
         const f32x4 o0 = {__builtin_fmaf(c.x - pv, frac1, pv), __builtin_fmaf(c.x - pv, frac2, pv), c.x,
                           __builtin_fmaf(c.y - c.x, frac1, c.x)};
@@ -681,12 +700,14 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
     }
 }
 
+// parts: 1, or 2 / 3 workgroups per chunk for launches of a few chunks
 void fvad_launch_istft(const ChunkDesc* descs, int n_chunks, FftTables tb, const float* spec,
                        const float* gains, int gains_rows_per_chunk, int gains_row0,
-                       hipStream_t stream)
+                       hipStream_t stream, int parts)
 {
-    hipLaunchKernelGGL(istft_kernel, dim3(n_chunks), dim3(256), 0, stream, descs, tb, spec, gains,
-                       gains_rows_per_chunk, gains_row0);
+    if (parts < 1 || parts > 3) parts = 1;
+    hipLaunchKernelGGL(istft_kernel, dim3(n_chunks, parts), dim3(256), 0, stream, descs, tb, spec, gains,
+                       gains_rows_per_chunk, gains_row0, parts);
 }
 
 // ============================================================================ K4 / rfft-N, N = 128 R
