@@ -547,7 +547,7 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
                                                         const float* __restrict__ bR2, float* __restrict__ hout2,
                                                         float* hx1, float* hx2, unsigned* flags1, unsigned* flags2,
                                                         unsigned* err, int T, int n_rt, unsigned long long spin_ticks,
-                                                        int variant)
+                                                        int variant, int nl1)
 {
     // dynamic LDS, in float4s: hbuf[2][25][64] (the row tile's h1 and h2); per tile slot: xch[3 gates][2 chains][64]
     // recurrent partial products, xci[3][2][64] layer 2's input projection, hpv[64] the previous h of the tile;
@@ -570,18 +570,23 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4;
-    const int g = blockIdx.x / 38;                // the group = the row tile
-    const int r38 = blockIdx.x - g * 38;
-    const int layer = r38 >= 13;
-    const int pair = layer ? r38 - 13 : r38;      // layer 1: pair of unit tiles; layer 2: the unit tile
-    const bool tr = TRACE && g == 0 && (r38 == 0 || r38 == 13);
+    // nl1 = layer-1 workgroups per group: 13 (two unit tiles each; 38 workgroups per group, six groups on 256 CUs) or,
+    // when the launch has few enough row tiles for 50 workgroups per group, 25 (one unit tile each: the layer-1 step's
+    // MFMA phase, which paces the whole pipeline, is 104 MFMAs deep on a SIMD instead of 156)
+    const int gsz = nl1 + GRU_J;
+    const bool one = nl1 == GRU_J;
+    const int g = blockIdx.x / gsz;               // the group = the row tile
+    const int r38 = blockIdx.x - g * gsz;
+    const int layer = r38 >= nl1;
+    const int pair = layer ? r38 - nl1 : r38;     // layer 1: pair of unit tiles (or the unit tile); layer 2: the unit tile
+    const bool tr = TRACE && g == 0 && (r38 == 0 || r38 == nl1);
     const bool gate_wave = wave < 12;
     const int ws = gate_wave ? wave / 6 : (wave == 13); // half: layer 1 the tile of the pair, layer 2 the matrix (W_ih / R2)
     const int gk = wave % 6;
     const int wg = gk % 3;                         // gate
     const int kp = gk / 3;                         // accumulation chain: even (0) or odd (1) super-steps
-    const int J = layer ? pair : 2 * pair + ws;
-    const bool tile_ok = J < GRU_J; // layer 1's 13th workgroup: its second tile does not exist
+    const int J = (layer || one) ? pair : 2 * pair + ws;
+    const bool tile_ok = (!layer && one) ? ws == 0 : J < GRU_J; // layer 1: the 13th workgroup's second tile does not exist; one tile per workgroup: the second half idles
     const int Jc = tile_ok ? J : 0;
     const int tslot = layer ? 0 : ws;
     // who does the gate math, fetches gi and publishes: layer 1: wavefronts 12 / 13 for the two tiles; layer 2: 12
@@ -591,9 +596,9 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     if (tid < 2 * 64) hpv[tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (tid >= 128 && tid < 128 + 48) { // biases of the workgroup's tile(s): read from LDS in the gate math
         const int e = tid - 128, sl = e / 24, k = (e % 24) / 4, qq = e & 3;
-        const int Jb = layer ? pair : 2 * pair + sl;
+        const int Jb = (layer || one) ? pair : 2 * pair + sl;
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (Jb < GRU_J && (layer ? sl == 0 : k < 3)) {
+        if (Jb < GRU_J && (layer ? sl == 0 : (k < 3 && (!one || sl == 0)))) {
             const float* src = (k < 3 ? (layer ? bR2 : bR1) : bW2) + (k % 3) * GRU_H + 16 * Jb + 4 * qq;
             v = *reinterpret_cast<const f32x4*>(src);
         }
@@ -843,15 +848,18 @@ int fvad_launch_gru_ws2(const float* gi1, const float* R1frag, const float* bR1,
     const bool fits32 = (long long)n_rt * 16 * T * (3 * GRU_H) * 4 < (1ll << 31);
     if (RT == 1 && fits32 && !(variant & 8)) {
         const size_t lds_k = 84 * 1024; // 65 KB used; more than half of a CU's LDS: one workgroup per CU
+        // up to five row tiles (80 sequences) on 256 CUs: 25 + 25 workgroups per group; six: 13 + 25 (variant 16: always)
+        const int nl1 = (G * 2 * GRU_J <= n_cu && !(variant & 16)) ? GRU_J : 13;
+        const dim3 grid((unsigned)(G * (nl1 + GRU_J)));
         if (variant & 64) { // step trace (tools/ws2_trace.py)
             if (hipFuncSetAttribute((const void*)gru_ws2k_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return -2;
-            hipLaunchKernelGGL(gru_ws2k_kernel<true>, dim3((unsigned)(G * 38)), dim3(1024), lds_k, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
-                               hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant);
+            hipLaunchKernelGGL(gru_ws2k_kernel<true>, grid, dim3(1024), lds_k, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
+                               hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant, nl1);
             return 0;
         }
         if (hipFuncSetAttribute((const void*)gru_ws2k_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return -2;
-        hipLaunchKernelGGL(gru_ws2k_kernel<false>, dim3((unsigned)(G * 38)), dim3(1024), lds_k, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
-                           hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant);
+        hipLaunchKernelGGL(gru_ws2k_kernel<false>, grid, dim3(1024), lds_k, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
+                           hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant, nl1);
         return 0;
     }
     // more than half of a CU's 160 KB of LDS: one workgroup per CU (all workgroups of the launch spin on each other)

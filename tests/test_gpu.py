@@ -1552,6 +1552,14 @@ for variant in ("8", "64"):
     ctx.set_option("ws2_variant", variant)
     assert np.array_equal(ctx.nsnet2_forward(f82), k16), variant
 ctx.set_option("ws2_variant", None)
+# up to five row tiles the groups have 25 + 25 workgroups (one layer-1 tile each) instead of 13 + 25 (16 forces those)
+f50 = f[:50]
+k50 = ctx.nsnet2_forward(f50)
+assert np.array_equal(k50, p2[:50])
+for variant in ("16", "8"):
+    ctx.set_option("ws2_variant", variant)
+    assert np.array_equal(ctx.nsnet2_forward(f50), k50), variant
+ctx.set_option("ws2_variant", None)
 assert ctx.ws_fallbacks() == 2
 ctx.set_option("ws_spin_ticks", "0")
 g3 = ctx.nsnet2_forward(f82)

@@ -10,11 +10,12 @@ from conftest import load_package
 pkg = load_package(); fv = pkg.binding
 ctx = fv.Context(0); ctx.load_synth(7)
 rng = np.random.default_rng(0)
-for n in (82, 1):
+for n in (82, 64, 1):
     f = rng.uniform(-11, 2, (n, 54, 161)).astype(np.float32)
     for name, opts in (("gru_ws2 (16 waves, K split)", {}), ("  no input projection in layer 2", {"ws2_variant": 1}), ("  no row-major h2 store", {"ws2_variant": 2}),
                        ("  layer 1 alone", {"ws2_variant": 4}),
                        ("  layer 2: h1 fetched, no W_ih product", {"ws2_variant": 32}),
+                       ("  13 + 25 workgroups per group (the shape of six row tiles)", {"ws2_variant": 16}),
                        ("gru_ws2 (8 waves)", {"ws2_variant": 8}), ("  no input projection in layer 2", {"ws2_variant": 9}),
                        ("  layer 1 alone", {"ws2_variant": 12}), ("gru_ws (2 launches + GEMM)", {"gru_kernel": "v5w0"})):
         with ctx.options(**opts):
@@ -25,4 +26,4 @@ for n in (82, 1):
             kt = ctx.kernel_times()
             ctx.enable_timing(False)
         rec = sum(v for k, v in kt.items() if "rec" in k or k == "gru2_in_gemm") / 5
-        print(f"n={n:3d} {name:50s} recurrences {rec * 1e3:7.1f} us  ({rec * 1e3 / 55:.2f} us per pipelined step)", flush=True)
+        print(f"n={n:3d} {name:62s} recurrences {rec * 1e3:7.1f} us  ({rec * 1e3 / 55:.2f} us per pipelined step)", flush=True)
