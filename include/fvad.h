@@ -197,7 +197,7 @@ void fvad_lane_state_destroy(fvad_lane_state *s);
  * 160-sample input hop, the 4 warm-up feature rows, the overlap-add tail and the upsampler's last sample
  * (NSNet2.zig:27-33,188-203), all functions of the previous chunk and of the 4 last frames of the one before.  A
  * lane that starts TWO chunks early from zero history (this call, sample_index = 24000 * (c0 - 2)) is therefore
- * bit-identical to the unsplit stream from chunk c0 on -- when both runs use the same kernel family (see
+ * bit-identical to the unsplit stream from chunk c0 on -- when both runs select the same kernels (see
  * fvad_ctx_set_option: "reproducible"; ~1e-6 apart otherwise) --; the VAD FFT's frame grid stays anchored at sample 0
  * (first_frame_index of the next fvad_engine_run says where the lane's first frame starts).  The caller drops
  * the two warm-up chunks and the frames that start before 24000 * c0.  sample_index: a multiple of 24000. */
@@ -293,13 +293,16 @@ enum { FVAD_NN_MATH_F32 = 0, FVAD_NN_MATH_F16X3 = 1, FVAD_NN_MATH_BF16X3 = 2 };
 int fvad_ctx_set_nn_math(fvad_ctx *ctx, int mode);
 int fvad_ctx_nn_math_effective(const fvad_ctx *ctx);
 const char *fvad_ctx_last_nn_path(const fvad_ctx *ctx);
-/* Bit-reproducibility.  Within one kernel family a chunk's results do not depend on where in a batch it sits, on how
- * lanes and chunks are split over launches, or on the launch size.  With FVAD_NN_MATH_F32 the engine picks the
- * family by batch size (weight-stationary / low-latency kernels and an unfolded fc1 below 2048 chunks per launch,
- * the persistent GEMM with fc1 folded into the first GRU's input projection above): the families agree to ~1e-6,
- * not bit for bit.  The option "reproducible" = "1" makes every launch use the large-batch family (small launches
- * are padded to 128 sequences and lose their low-latency kernels), so that a stream pushed in any pieces, split
- * over any number of launches or time-split over ranks gives the same bits.  FVAD_NN_MATH_F16X3 has one family.
+/* Bit-reproducibility.  Two launches that select the same NSNet2 kernels (fvad_ctx_last_nn_path names them) give a
+ * chunk the same bits wherever in the batch it sits and however lanes and chunks are split.  With FVAD_NN_MATH_F32
+ * the engine selects by launch size: up to 384 sequences the pipelined two-layer weight-stationary recurrence (it
+ * computes layer 2's input projection itself); up to 2047 the narrow-block GEMMs with a weight-stationary or the
+ * low-latency recurrence; from 2048 the persistent GEMM with the low-latency or the multi-wavefront recurrence (by
+ * a cost model over the CU count).  Every selection runs f32 operands and f32 accumulation; they differ in
+ * accumulation order and agree to ~1e-6 in the gains, not bit for bit.  The option "reproducible" = "1" makes every
+ * launch use one selection (persistent GEMM + multi-wavefront recurrence; small launches are padded to 128 sequences
+ * and lose their low-latency kernels), so that a stream pushed in any pieces, split over any number of launches or
+ * time-split over ranks gives the same bits.  FVAD_NN_MATH_F16X3 and FVAD_NN_MATH_BF16X3 have one selection each.
  *
  * Testing / tuning aids, none needed in production: name = "reproducible" | "nn_math" ("f32" | "f16x3" | "bf16x3": overrides
  * fvad_ctx_set_nn_math) | "gru_kernel" ("v3w12" | "v3w8" | "v3w4" | "v4w8" | "v5w0" | "v6w0") | "gemm_kernel" ("v1" |

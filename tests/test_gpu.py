@@ -1582,3 +1582,14 @@ def test_weight_stationary_timeout_falls_back_to_gru_lat():
     env = dict(os.environ)
     r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + _WS_FALLBACK_SCRIPT], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stderr[-3000:]
+
+
+def test_random_shapes_keep_their_bits_and_match_the_oracle():
+    # tools/fuzz_shapes.py, a short run: random (n_seq, T) through fvad_nsnet2_forward against the oracle (odd sequence
+    # lengths, batch sizes on both sides of every kernel-selection line), and random ragged lanes through fvad_engine_run
+    # one-shot against random launch splits and two pushes, bit for bit, in both kernel families (the spectral kernels
+    # cut a chunk over several workgroups in small launches: the cut must not show)
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_shapes.py"), "24", "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "mismatches: 0" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
