@@ -307,7 +307,7 @@ const char *fvad_ctx_last_nn_path(const fvad_ctx *ctx);
  * Testing / tuning aids, none needed in production: name = "reproducible" | "nn_math" ("f32" | "f16x3" | "bf16x3": overrides
  * fvad_ctx_set_nn_math) | "gru_kernel" ("v3w12" | "v3w8" | "v3w4" | "v4w8" | "v5w0" | "v6w0") | "gemm_kernel" ("v1" |
  * "v3" | "v3nofold") | "h3_waves" ("8" | "12") | "max_chunks" | "copy_threads" | "no_pipeline" | "trace_kernels" |
- * "ws_spin_ticks" | "ws2_variant" (timing-only variants of a kernel: wrong results); value NULL or "" restores the
+ * "ws_spin_ticks" | "ws2_variant" (diagnostic bit mask; bits 1, 2, 4, 32 are timing-only: WRONG results); value NULL or "" restores the
  * default.  The environment variables FVAD_<NAME> are read ONCE, by
  * fvad_ctx_create, as initial values (a bad value fails the creation); the data path never reads the environment. */
 int fvad_ctx_set_option(fvad_ctx *ctx, const char *name, const char *value);
