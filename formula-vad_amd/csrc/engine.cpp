@@ -557,7 +557,13 @@ static int prepare_gru_ws(fvad_ctx* ctx, long n_pad)
     if (rc) return rc;
     if (std::max(fvad_gru_ws_exchange_floats(n_pad), fvad_gru_ws2_exchange_floats(n_pad)) > ctx->ws.hx_cap)
         return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "batch too large for gru_ws");
-    fvad_launch_zero_words(ctx->ws.ws_sync, (int)kWsSyncWords, ctx->stream);
+    // the pipelined recurrence's fallback launch leaves the words zeroed (sync_clean); a pass of gru_ws_kernel, a failed
+    // pass, or a sequence under capture (a graph must not depend on what ran before it) starts from a reset
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(ctx->stream, &cap);
+    if (!ctx->ws.sync_clean || cap != hipStreamCaptureStatusNone)
+        fvad_launch_zero_words(ctx->ws.ws_sync, (int)kWsSyncWords, ctx->stream);
+    ctx->ws.sync_clean = false;
     return FVAD_OK;
 }
 
@@ -797,18 +803,22 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     if (gcs.version >= 5 && (rc = prepare_gru_ws(ctx, n_pad))) return rc;
     ctx->last_nn_path = std::string("f32: panel_gemm (fc1 folded) + ") + (gcs.version == 6 ? "gru_ws2 (layers pipelined)" : gcs.version == 5 ? "gru_ws" : "gru_lat");
     if (gcs.version == 6) {
-        // both GRU layers in one launch, layer 2 a step behind layer 1, its input projection computed inside; behind
-        // it the guarded fallback chain, every link of which returns at once unless the error word was raised
+        // both GRU layers in one launch, layer 2 a step behind layer 1, its input projection computed inside
         unsigned* err = ws.ws_sync + 512;
         time_begin(ctx, "gru12_rec_pipelined");
         rc |= ws_serialised(ctx, [&] {
             return fvad_launch_gru_ws2(ws.gi, m.r1v2.p, m.br1.p, m.s_w2frag.p, m.s_bw2.p, m.r2v2.p, m.br2.p, ws.h2, ws.hx, ws.ws_sync, err,
                                        n_pad, T, ctx->n_cu, tn.ws_spin_ticks, tn.ws2_variant, st);
         });
-        rc |= fvad_launch_gru_lat(ws.gi, m.r1v2.p, m.br1.p, ws.h1, n_pad, T, err, 1, st);
-        rc |= fvad_launch_panel_gemm_s(ws.h1, 400, m.s_gi2_w[fam].p, m.gi2_btm.p, ws.gi, 1200, rows, snt, nb_gi, 25, FVAD_ACT_NONE, 0, 0, st, 75, err);
-        rc |= fvad_launch_gru_lat(ws.gi, m.r2v2.p, m.br2.p, ws.h2, n_pad, T, err, 1, st);
-        fvad_launch_count_word(ws.ws_fallbacks, err, st);
+        // one launch behind it: the whole fallback (layer 1, layer 2's input projection, layer 2 -- run only if the
+        // error word was raised), the pass count, and the reset of the polled words for the next pass
+        rc |= fvad_launch_gru_ws2_fallback(ws.gi, m.r1v2.p, m.br1.p, m.s_gi2_w[0].p, m.gi2_btm.p, m.r2v2.p, m.br2.p, ws.h1, ws.h2, n_pad, T,
+                                           ws.ws_sync, ws.ws_fallbacks, st);
+        {   // the launch above leaves the words zeroed -- once it has RUN: a sequence under capture has not
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(st, &cap);
+            if (rc == 0 && cap == hipStreamCaptureStatusNone) ws.sync_clean = true;
+        }
         time_end(ctx);
     } else {
         time_begin(ctx, "gru1_rec");

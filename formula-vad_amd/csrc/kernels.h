@@ -94,6 +94,10 @@ int fvad_launch_gru_rec_h3(const float* gi, const float* Rfrag, const float* bR,
                            long n_seq_pad, int T, int waves, float sx, float sw, hipStream_t stream);
 // guard != nullptr: the kernel returns at once unless *guard != 0 (fallback behind fvad_launch_gru_ws)
 // tile_major: gi rows are [25 J][3 gates][16] (large-batch GEMM) instead of [3 gates][400] (small-batch GEMM)
+// the pipelined recurrence's whole fallback + pass count + reset of the polled words in one launch (kernels_nn.hip)
+int fvad_launch_gru_ws2_fallback(float* gi, const float* R1frag, const float* bR1, const float* W2frag_nt2, const float* bW2,
+                                 const float* R2frag, const float* bR2, float* h1, float* h2, long n_seq_pad, int T,
+                                 unsigned* sync, unsigned long long* fallbacks, hipStream_t stream);
 int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, float* hout,
                         long n_seq_pad, int T, const unsigned* guard, int tile_major, hipStream_t stream);
 // small batches: recurrent weights stationary in registers across 25 x G workgroups, h exchanged per step

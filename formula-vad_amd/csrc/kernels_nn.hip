@@ -842,20 +842,15 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec3_kernel(const float* __res
 //     tile J is the float4 the same lane index reads as super-step S = J), double-buffered, one
 //     barrier per step.
 // gi holds Wx + Wb; Rb is added here.
+// (the body is a device function: gru_lat_kernel runs it for one layer, gru_ws2_fallback_kernel for both)
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __restrict__ gi,
-                                                             const float* __restrict__ R2frag,
-                                                             const float* __restrict__ bR,
-                                                             float* hout, int T, const unsigned* guard,
-                                                             int gi_js, int gi_gs)
+__device__ __forceinline__ void gru_lat_body(const float* gi, const float* __restrict__ R2frag, const float* __restrict__ bR,
+                                             float* hout, int T, int gi_js, int gi_gs, float (*hs)[GRU_J * 256])
 {
     // gi_js / gi_gs: floats between unit tiles / between gates in a gi row (16, 400: gate-major rows of the
     // small-batch GEMM; 48, 16: the tile-major rows of the large-batch GEMM)
-    __shared__ __attribute__((aligned(16))) float hs[2][GRU_J * 256];
     typedef const __attribute__((address_space(1))) f32x4* gptr4;
     constexpr int D = 5;
-    // launched behind gru_ws_kernel as its fallback: runs only if that kernel raised *guard (kernels_ws.hip)
-    if (guard && *guard == 0) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -974,6 +969,88 @@ __global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __rest
         __syncthreads(); // h_t complete in hs[cur ^ 1]; everyone has read hs[cur]
         cur ^= 1;
     }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __restrict__ gi,
+                                                             const float* __restrict__ R2frag,
+                                                             const float* __restrict__ bR,
+                                                             float* hout, int T, const unsigned* guard,
+                                                             int gi_js, int gi_gs)
+{
+    __shared__ __attribute__((aligned(16))) float hs[2][GRU_J * 256];
+    // launched behind gru_ws_kernel as its fallback: runs only if that kernel raised *guard (kernels_ws.hip)
+    if (guard && *guard == 0) return;
+    gru_lat_body<WAVES>(gi, R2frag, bR, hout, T, gi_js, gi_gs, hs);
+}
+
+// The whole fallback of the pipelined two-layer recurrence (kernels_ws.hip: gru_ws2_kernel / gru_ws2k_kernel) in ONE
+// launch behind it -- it used to be three guarded launches (gru_lat, layer 2's input projection, gru_lat) and a fourth
+// that counted the pass, each ~4.5 us of a 0.5 ms call even when it returns at once.  A workgroup owns 16 sequences
+// through both layers: layer 1's recurrence (gru_lat_body), then gi2 = W_ih h1 + Wb for its own rows -- the
+// instruction sequence of panel_gemm_s_kernel per output: the k-ordered chain from zero, the bias added after it, so
+// the bits are the three-launch chain's -- written over its gi rows, then layer 2's recurrence.  Nothing crosses
+// workgroups.  It runs only if the error word was raised.  Either way every workgroup takes a ticket when it is done
+// (after it has read the error word), and the last one adds the pass to the fallback counter and zeroes the polled
+// words for the next pass, so the sequence needs no separate reset launch in front and no count launch behind.
+//   sync: [0, 512) the two layers' flags, [512] the error word, [513] the ticket counter.
+__global__ __launch_bounds__(512) void gru_ws2_fallback_kernel(float* gi, const float* __restrict__ R1frag, const float* __restrict__ bR1,
+                                                               const float* __restrict__ W2frag_nt2, const float* __restrict__ bW2,
+                                                               const float* __restrict__ R2frag, const float* __restrict__ bR2,
+                                                               float* h1, float* h2, int T, unsigned* sync,
+                                                               unsigned long long* fallbacks)
+{
+    __shared__ __attribute__((aligned(16))) float hs[2][GRU_J * 256];
+    __shared__ int s_last;
+    const bool run = *(const volatile unsigned*)(sync + 512) != 0u; // uniform: nobody writes the word while this launch runs
+    if (run) {
+        gru_lat_body<8>(gi, R1frag, bR1, h1, T, 48, 16, hs);
+        __threadfence(); // h1 rows written by the other wavefronts of this workgroup
+        __syncthreads();
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), m = lane & 15, q = lane >> 4;
+        const size_t row0 = ((size_t)blockIdx.x * 16 + m) * T;
+        for (int t = 0; t < T; ++t) {
+            const float* a_ptr = h1 + (row0 + t) * GRU_H + 4 * q;
+            float* c_ptr = gi + (row0 + t) * (3 * GRU_H) + 4 * q;
+            for (int u = wave; u < 3 * GRU_J; u += 8) { // unit tiles of the 1200 outputs (tile-major order: in the weights' row order)
+                const f32x4* wf = reinterpret_cast<const f32x4*>(W2frag_nt2) + ((size_t)(u >> 1) * GRU_J * 2 + (u & 1)) * 64 + lane;
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 5
+                for (int s = 0; s < GRU_J; ++s) {
+                    const f32x4 w4 = wf[(size_t)s * 2 * 64];
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(a_ptr + 16 * s);
+                    acc = MFMA16(w4.x, a.x, acc);
+                    acc = MFMA16(w4.y, a.y, acc);
+                    acc = MFMA16(w4.z, a.z, acc);
+                    acc = MFMA16(w4.w, a.w, acc);
+                }
+                *reinterpret_cast<f32x4*>(c_ptr + 16 * u) = acc + *reinterpret_cast<const f32x4*>(bW2 + 16 * u + 4 * q);
+            }
+        }
+        __threadfence(); // gi rows rewritten: this CU's L1 may still hold layer 1's gi in those lines
+        __syncthreads();
+        gru_lat_body<8>(gi, R2frag, bR2, h2, T, 48, 16, hs);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(sync + 513, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last) {
+        if (threadIdx.x == 0 && run) *fallbacks += 1ull;
+        for (int i = threadIdx.x; i < 514; i += 512) sync[i] = 0u;
+    }
+}
+
+int fvad_launch_gru_ws2_fallback(float* gi, const float* R1frag, const float* bR1, const float* W2frag_nt2, const float* bW2,
+                                 const float* R2frag, const float* bR2, float* h1, float* h2, long n_seq_pad, int T,
+                                 unsigned* sync, unsigned long long* fallbacks, hipStream_t stream)
+{
+    if (n_seq_pad <= 0 || n_seq_pad % 16) return -1;
+    hipLaunchKernelGGL(gru_ws2_fallback_kernel, dim3((unsigned)(n_seq_pad / 16)), dim3(512), 0, stream, gi, R1frag, bR1, W2frag_nt2, bW2,
+                       R2frag, bR2, h1, h2, T, sync, fallbacks);
+    return 0;
 }
 
 int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, float* hout,

@@ -256,9 +256,9 @@ __global__ __launch_bounds__(256) void gru_ws_kernel(const float* __restrict__ g
 //     BESIDE R h2_{t-1} on the second half's -> gates -> publish h2_t: the input projection costs a second 25 KB fetch,
 //     not a second product phase (a first version did the two products one after the other: 7.6 us per step
 //     against 5.3 us for gru_ws_kernel).
-// Bounded spins and the error word as in gru_ws_kernel; behind this kernel the engine queues the guarded fallback
-// chain gru_lat (layer 1) -> input-projection GEMM -> gru_lat (layer 2), each of which returns at once unless the
-// error word was raised.
+// Bounded spins and the error word as in gru_ws_kernel; behind this kernel the engine queues gru_ws2_fallback_kernel
+// (kernels_nn.hip): gru_lat's body for layer 1, layer 2's input projection and gru_lat's body for layer 2, per 16
+// sequences, run only if the error word was raised; it also counts the pass and zeroes the polled words.
 // Arithmetic: per output the same two accumulation chains (even / odd super-steps) as gru_ws_kernel; gi2 is
 // (W_ih h1 chains) + Wb instead of a GEMM's bias-last chain, so this family differs from the others in the last bits.
 __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ gi1, const float* __restrict__ R1frag,
