@@ -958,7 +958,7 @@ def side_measurements(pkg, fv, ctx, torch, dev):
                 ctx.synchronize()
                 res[mode] = (time.perf_counter() - t0) / reps * 1e3
             extra[f"hipgraph_replay_{tag}"] = {"direct_ms": res["direct"], "graph_ms": res["graph"],
-                                               "note": "per call of fvad_engine_enqueue_device; ~12 kernel launches per launch batch"}
+                                               "note": "per call of fvad_engine_enqueue_device; 9-12 kernel launches per launch batch"}
             del xg, bg, rg, dg
     except Exception as e:
         extra["hipgraph_replay"] = {"error": repr(e)}
