@@ -651,6 +651,9 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
         (__attribute__((address_space(1))) unsigned*)(lane < 32 ? flags1 + g * GRU_J + (lane < GRU_J ? lane : 0)
                                                                 : flags2 + g * GRU_J + (lane - 32 < GRU_J ? lane - 32 : 0));
 
+    // (Hand-off form: the guide's write-through one -- sc1 payload, drain, sc1 flag; the polling wavefront loads only after
+    // its poll has matched -- with sc1 LDS-DMA loads where the guide's measured table has sc1 loads to registers, and one
+    // flag per storing wavefront; tools/ws_stress.py is the evidence for both: DESIGN.md section 3.1.)
     // The polling wavefront (14) does the whole acquisition of a step's operand: it waits until layer 1 has published
     // `need1` steps and layer 2 `need2` (0 = no requirement), then fetches the row tile's h (25 KB, 25 blocks) straight
     // into LDS -- sc1 LDS-DMA loads, no registers, no second barrier -- and drains them; the other wavefronts meet it
