@@ -311,16 +311,29 @@ def cpu_model():
     return "unknown"
 
 
+def _code_only(text):
+    """the source without // comments, indentation and blank lines: a comment edit is not a kernel change"""
+    out = []
+    for line in text.splitlines():
+        i = line.find("//")
+        if i >= 0 and line[:i].count('"') % 2 == 0:
+            line = line[:i]
+        line = line.strip()
+        if line:
+            out.append(line)
+    return "\n".join(out).encode()
+
+
 def kernel_source_digest():
-    """sha256 over the kernel sources: profiles/*_pmc_summary.json records the digest of the build its counters were
-    taken from, so a stale profile is visible in the line instead of being quoted silently"""
+    """sha256 over the kernel sources (code only: _code_only): profiles/*_pmc_summary.json records the digest of the build
+    its counters were taken from, so a stale profile is visible in the line instead of being quoted silently"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "formula-vad_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".h")):
             h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+            h.update(_code_only(open(os.path.join(d, name), "r", errors="replace").read()))
     return h.hexdigest()[:16]
 
 

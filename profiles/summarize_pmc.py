@@ -49,13 +49,26 @@ import hashlib
 import subprocess
 
 
-def _digest():
+def _code_only(text):
+    """the source without // comments, indentation and blank lines: a comment edit is not a kernel change"""
+    out = []
+    for line in text.splitlines():
+        i = line.find("//")
+        if i >= 0 and line[:i].count('"') % 2 == 0:
+            line = line[:i]
+        line = line.strip()
+        if line:
+            out.append(line)
+    return "\n".join(out).encode()
+
+
+def _digest(): # bench.py's kernel_source_digest
     h = hashlib.sha256()
     d = os.path.join(here, "..", "formula-vad_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".h")):
             h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+            h.update(_code_only(open(os.path.join(d, name), "r", errors="replace").read()))
     return h.hexdigest()[:16]
 
 
