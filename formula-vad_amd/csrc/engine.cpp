@@ -1126,6 +1126,10 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
         if (r->base) hipHostFree(r->base);
         for (hipEvent_t& e : r->ev) if (e) hipEventDestroy(e);
     }
+    for (Workspace::PinSmall* r : {&ws.small_in, &ws.small_out}) {
+        if (r->base) hipHostFree(r->base);
+        if (r->ev) hipEventDestroy(r->ev);
+    }
     if (ws.graph.exec) hipGraphExecDestroy(ws.graph.exec);
     if (ws.graph.graph) hipGraphDestroy(ws.graph.graph);
     if (ws.graph.h_descs) hipHostFree(ws.graph.h_descs);
@@ -1438,6 +1442,7 @@ static int grow(fvad_ctx* ctx, float** p, size_t* cap, size_t need)
 // parallel memcpy and the PCIe DMA rather than their sum.
 namespace {
 constexpr size_t kPinSlotBytes = 8u << 20;
+constexpr size_t kPinSmallBytes = 4u << 20; // transfers below this total go through the small bounce buffers
 constexpr int kPinSlots = 16; // per half
 struct CopySeg { void* host; void* dev; size_t bytes; };
 
@@ -1469,12 +1474,42 @@ void parallel_memcpy(const std::vector<CopySeg>& blocks, size_t first, size_t n,
 int staged_copy(fvad_ctx* ctx, const std::vector<CopySeg>& segs, bool to_device, hipStream_t st)
 {
     Workspace::PinRing& ring = to_device ? ctx->ws.ring_in : ctx->ws.ring_out;
-    size_t total = 0;
-    for (const CopySeg& s : segs) total += s.bytes;
-    if (total < (4u << 20)) {
-        for (const CopySeg& s : segs)
-            if (s.bytes) FVAD_HIP(ctx, to_device ? hipMemcpyAsync(s.dev, s.host, s.bytes, hipMemcpyHostToDevice, st)
-                                                 : hipMemcpyAsync(s.host, s.dev, s.bytes, hipMemcpyDeviceToHost, st));
+    size_t total = 0, total_padded = 0;
+    for (const CopySeg& s : segs) { total += s.bytes; total_padded += (s.bytes + 63) & ~(size_t)63; }
+    if (total_padded <= kPinSmallBytes) {
+        // Small transfers -- every live push: hipMemcpyAsync to or from pageable memory blocks the calling thread (a
+        // device -> host copy until everything queued before it has run: two of them in a row cost a push ~25 us of
+        // tail), so the bytes go through one page-locked bounce buffer per direction: host -> device = memcpy + async
+        // copies that return at once; device -> host = async copies, ONE wait, memcpy.
+        Workspace::PinSmall& b = to_device ? ctx->ws.small_in : ctx->ws.small_out;
+        if (!b.base) {
+            FVAD_HIP(ctx, hipHostMalloc((void**)&b.base, kPinSmallBytes, hipHostMallocDefault));
+            FVAD_HIP(ctx, hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+        } else if (to_device) {
+            FVAD_HIP(ctx, hipEventSynchronize(b.ev)); // the previous use's copies have left the buffer
+        }
+        size_t off = 0;
+        for (const CopySeg& s : segs) {
+            if (!s.bytes) continue;
+            if (to_device) {
+                memcpy(b.base + off, s.host, s.bytes);
+                FVAD_HIP(ctx, hipMemcpyAsync(s.dev, b.base + off, s.bytes, hipMemcpyHostToDevice, st));
+            } else {
+                FVAD_HIP(ctx, hipMemcpyAsync(b.base + off, s.dev, s.bytes, hipMemcpyDeviceToHost, st));
+            }
+            off += (s.bytes + 63) & ~(size_t)63;
+        }
+        if (to_device) {
+            FVAD_HIP(ctx, hipEventRecord(b.ev, st));
+            return FVAD_OK;
+        }
+        FVAD_HIP(ctx, hipStreamSynchronize(st));
+        off = 0;
+        for (const CopySeg& s : segs) {
+            if (!s.bytes) continue;
+            memcpy(s.host, b.base + off, s.bytes);
+            off += (s.bytes + 63) & ~(size_t)63;
+        }
         return FVAD_OK;
     }
     std::vector<CopySeg> blocks;

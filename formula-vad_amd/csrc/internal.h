@@ -116,6 +116,10 @@ struct Workspace {
     // pinned staging ring for large host <-> device transfers (two halves of kPinSlots slots)
     struct PinRing { char* base = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
     PinRing ring_in, ring_out; // host->device staging / device->host draining (used by different threads)
+    // small transfers (a live push: 96 KB in, a few hundred bytes out): one page-locked bounce buffer per direction, so that
+    // the copies are truly asynchronous (a copy to or from pageable memory blocks the calling thread)
+    struct PinSmall { char* base = nullptr; hipEvent_t ev = nullptr; };
+    PinSmall small_in, small_out;
     unsigned generation = 0; // bumped whenever a device buffer of the workspace is reallocated
     // one captured launch sequence of fvad_engine_enqueue_device (opt-in, FVAD_GRAPH=1): replayed while the
     // call's arguments and the workspace are unchanged
