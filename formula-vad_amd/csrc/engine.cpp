@@ -1656,6 +1656,8 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
                                                    lanes[l].state->samples_consumed, lanes[l].state->next_frame_index});
     float* d_rms = ws.band + frames_total;
     std::vector<LaneJob> jobs(n_lanes);
+    struct Restore { float* dst; const float* src; size_t bytes; };
+    std::vector<Restore> restores; // the previous call's FFT remainder of every lane, to be put in front of its new audio
     std::vector<CopySeg> h2d;
     size_t scratch_i = 0;
     for (size_t l = 0; l < n_lanes; ++l) {
@@ -1683,7 +1685,9 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
         j.h_feat = L.features;
         if (L.state) {
             j.carry[0] = L.state->carry[0]; j.carry[1] = L.state->carry[1]; j.cur = L.state->cur;
-            if (n_rem[l]) FVAD_HIP(ctx, hipMemcpyAsync(den_base - n_rem[l], L.state->den_rem, n_rem[l] * sizeof(float), hipMemcpyDeviceToDevice, st));
+            // (queued behind the first group's kernels, in front of its K4: nothing earlier reads it, and the GPU
+            // idles until K1 is launched -- every host call in front of that launch is latency of a live push)
+            if (n_rem[l]) restores.push_back({den_base - n_rem[l], L.state->den_rem, n_rem[l] * sizeof(float)});
         } else {
             j.carry[0] = ws.carries + scratch_i; j.carry[1] = ws.carries + scratch_i + 1; j.cur = 0;
             scratch_i += 2;
@@ -1717,8 +1721,10 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
             if (acc * G >= chunks_total * g) gb[g++] = l + 1;
         }
     }
-    // K4 job table for every lane (pointers are known up front)
+    // K4 job table for every lane (pointers are known up front; uploaded in front of the first K4 launch)
     long max_frames = 0;
+    const VadFftJob* jobs_upload = nullptr;
+    int jobs_upload_slot = 0;
     {
         if (ws.fft_jobs_cap < n_lanes) {
             hipStreamSynchronize(st);
@@ -1743,10 +1749,8 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
                      L.fft_bins ? ws.bins + band_off[l] * NB : nullptr, (long)L.n_fft_frames};
             max_frames = std::max(max_frames, (long)L.n_fft_frames);
         }
-        if (max_frames) {
-            FVAD_HIP(ctx, hipMemcpyAsync(ws.fft_jobs, hj, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice, st));
-            FVAD_HIP(ctx, hipEventRecord(ws.jobs_ev[js], st));
-        }
+        jobs_upload = hj;
+        jobs_upload_slot = js;
     }
 
     auto outputs_of = [&](size_t l0, size_t l1) -> int {
@@ -1808,6 +1812,13 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
         for (size_t l = l0; l < l1; ++l) jobs[l].cur = jg[l - l0].cur;
         long mf = 0;
         for (size_t l = l0; l < l1; ++l) mf = std::max(mf, (long)lanes[l].n_fft_frames);
+        if (g == 0) { // what only K4 needs: the lanes' remainders in front of their new audio, the job table
+            for (const Restore& r : restores) FVAD_HIP(ctx, hipMemcpyAsync(r.dst, r.src, r.bytes, hipMemcpyDeviceToDevice, st));
+            if (max_frames) {
+                FVAD_HIP(ctx, hipMemcpyAsync(ws.fft_jobs, jobs_upload, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice, st));
+                FVAD_HIP(ctx, hipEventRecord(ws.jobs_ev[jobs_upload_slot], st));
+            }
+        }
         if (mf) {
             time_begin(ctx, "fft1024_bandsum");
             fvad_launch_vadfft_jobs(ws.fft_jobs + l0, (int)(l1 - l0), mf, plan, opts.min_bin, opts.max_bin, st);
