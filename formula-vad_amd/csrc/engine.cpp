@@ -1004,7 +1004,7 @@ static int apply_option(fvad_ctx* ctx, const std::string& name, const char* valu
         else { char* end = nullptr; tn.ws_spin_ticks = strtoull(v.c_str(), &end, 10); if (!end || *end) return FVAD_ERR_INVALID_ARGUMENT; }
     } else if (name == "ws2_variant") { // timing-only builds of gru_ws2_kernel's step (wrong results): tools/ws2_variants.py
         long c = 0;
-        if (!unset && (!to_long(c) || c < 0 || c > 127)) return FVAD_ERR_INVALID_ARGUMENT;
+        if (!unset && (!to_long(c) || c < 0 || c >= (1 << 25))) return FVAD_ERR_INVALID_ARGUMENT;
         tn.ws2_variant = (int)c;
     } else if (name == "no_pipeline") { if (!to_bool(tn.no_pipeline)) return FVAD_ERR_INVALID_ARGUMENT; }
     else if (name == "trace_kernels") { if (!to_bool(tn.trace_kernels)) return FVAD_ERR_INVALID_ARGUMENT; }

@@ -540,6 +540,9 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
 // One row tile per group (16 wavefronts x 128 VGPRs leave no room for a second one's operands): up to 6 groups = 96
 // sequences -- BASELINE config 3's 82 chunks, every live push; the 8-wavefront kernel above serves 2 to 4 row tiles
 // per group.
+// waits before a step's first poll, in 10 ns ticks (see `timed` in the kernel): layer 1 / layer 2, groups of 13 + 25 and of 25 + 25
+constexpr unsigned WS2K_WAIT_L1 = 150, WS2K_WAIT_L2 = 240, WS2K_WAIT_L1_ONE = 200, WS2K_WAIT_L2_ONE = 200;
+
 template <bool TRACE>
 __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict__ gi1, const float* __restrict__ R1frag,
                                                         const float* __restrict__ bR1, const float* __restrict__ W2frag,
@@ -559,10 +562,13 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     f32x4* xci = xch + 12 * 64;
     f32x4* hpv = xci + 12 * 64;
     f32x4* btab = hpv + 2 * 64;
-    volatile int* s_dead = reinterpret_cast<volatile int*>(btab + 48);
+    // (LDS-space pointers, not generic ones, for everything that is not plain array indexing: the flat -> LDS casts of
+    // generic pointers made the backend emit an illegal instruction in some variants of this kernel, ROCm 7.2)
+    __attribute__((address_space(3))) char* lds3 = (__attribute__((address_space(3))) char*)smem; // LDS-DMA targets, words, trace
+    __attribute__((address_space(3))) volatile int* s_dead = (__attribute__((address_space(3))) volatile int*)(lds3 + (2 * GRU_J * 64 + 24 * 64 + 2 * 64 + 48) * 16);
+    __attribute__((address_space(3))) volatile int* hA_ready = s_dead + 1; // layer 2: h1 of steps < *hA_ready is in hbA (set by wavefront 15)
     // variant & 64 (tools/ws2_trace.py): the first layer-1 and the first layer-2 workgroup of group 0 keep shader-clock
     // stamps of every step's events in LDS and copy them behind the polled words (flags1 + 520 ...) when they are done
-    __attribute__((address_space(3))) char* lds3 = (__attribute__((address_space(3))) char*)smem; // LDS-DMA targets, trace
     __attribute__((address_space(3))) unsigned* trl = (__attribute__((address_space(3))) unsigned*)(lds3 + (2 * GRU_J * 64 + 24 * 64 + 2 * 64 + 49) * 16);
 #define WS_STAMP(t_, k_) do { if (TRACE && tr && lane == 0) trl[(t_) * 12 + (k_)] = (unsigned)clock64(); } while (0)
 
@@ -592,7 +598,7 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     // who does the gate math, fetches gi and publishes: layer 1: wavefronts 12 / 13 for the two tiles; layer 2: 12
     const bool helper = layer ? wave == 12 : ((wave == 12 || wave == 13) && tile_ok);
 
-    if (tid == 0) *s_dead = (int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) { *s_dead = (int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *hA_ready = 0; }
     if (tid < 2 * 64) hpv[tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (tid >= 128 && tid < 128 + 48) { // biases of the workgroup's tile(s): read from LDS in the gate math
         const int e = tid - 128, sl = e / 24, k = (e % 24) / 4, qq = e & 3;
@@ -659,8 +665,25 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     // into LDS -- sc1 LDS-DMA loads, no registers, no second barrier -- and drains them; the other wavefronts meet it
     // at the workgroup barrier.  On a deadline it raises the error word instead.  Uniform false on a deadline.
     const unsigned row0 = (unsigned)(g * GRU_J) * 1024u;
-    auto acquire = [&](unsigned need1, unsigned need2, bool from_h2, unsigned slot, int st, int ev) {
-        if (wave == 14) {
+    // pw: the wavefront that does it (14; layer 2 also uses 15 for h1, so that the two acquisitions of a step run side by
+    // side); ready >= 0: afterwards *hA_ready = ready (the wavefronts that consume hbA wait for that word, not for a barrier)
+    // timed: wait before the first poll.  A poll of flags that cannot be up yet (the peers publish ~1 us after the barrier
+    // this follows, and a flag takes ~0.5 us more to become visible) is a wasted ~0.9 us round trip AND traffic on the
+    // group's flag lines, which slows every store and fetch of the step: the right wait took 70 us off the 350 us of a
+    // one-chunk launch and 55 off the 400 of 82 chunks (tools/ws2_delay.py).  The wait is a wall-clock interval from the
+    // barrier (s_memrealtime, 100 MHz), per layer and group shape, a little short of the measured optimum: too short only
+    // brings the wasted polls back, too long would sit on the critical path.  (A self-tuning wait -- longer after a step
+    // that needed several polls, shorter after a first-poll hit -- ratchets up across the group, because a late poller
+    // publishes late and makes its peers' polls miss: 400 us instead of 350.)  Timing only: results do not depend on it.
+    // Tuning: ws2_variant bit 24 = take the waits from bits 8..15 (layer 1) / 16..23 (layer 2), in units of 40 ns.
+    const unsigned wait_ticks = (variant & (1 << 24)) ? 4u * (unsigned)((layer ? variant >> 16 : variant >> 8) & 255)
+                                                      : (layer ? (one ? WS2K_WAIT_L2_ONE : WS2K_WAIT_L2) : (one ? WS2K_WAIT_L1_ONE : WS2K_WAIT_L1));
+    auto acquire = [&](int pw, unsigned need1, unsigned need2, bool from_h2, unsigned slot, int st, int ev, int ready, bool timed) {
+        if (wave == pw) {
+            if (timed && wait_ticks) {
+                const unsigned long long until = __builtin_amdgcn_s_memrealtime() + wait_ticks;
+                while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(1);
+            }
             WS_STAMP(st, ev);
             const unsigned need = lane < 32 ? need1 : need2;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -694,7 +717,18 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
                 __hip_atomic_store((__attribute__((address_space(1))) unsigned*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *s_dead = 1;
             }
+            if (lane == 0 && !dead && ready >= 0) *hA_ready = ready; // behind the drain: the bytes are in LDS
         }
+    };
+    // a consumer of hbA waits for the word (or for the error word); uniform
+    auto wait_hA = [&](int need) -> bool {
+        for (;;) {
+            if (*hA_ready >= need) break;
+            if (*s_dead) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        return true;
     };
     auto barrier_alive = [&]() -> bool {
         __syncthreads();
@@ -704,7 +738,7 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     // one chain of one gate of one matrix: this gate wavefront's fragments x the row tile's h in LDS -> its slot of
     // xch (layer 1: R1 h1; layer 2: R2 h2, second half) or xci (layer 2: W_ih h1, first half; xci follows xch)
     const unsigned xoff_s = (unsigned)__builtin_amdgcn_readfirstlane((((layer && !ws) ? 12 : 0) + (tslot * 3 + wg) * 2 + kp) * 1024);
-    auto chain = [&](const f32x4* hsrc) {
+    auto chain = [&](const f32x4* hsrc, unsigned xadd) {
         const f32x4* hb = hsrc + kp * 64 + lane; // chain kp: super-steps kp, kp + 2, ...
         f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -717,35 +751,37 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
                 a = MFMA16(w[i].w, hv.w, a);
             }
         }
-        unsigned xoff = xoff_s;
+        unsigned xoff = xoff_s + xadd;
         if (!TRACE) asm volatile("" : "+s"(xoff)); // the per-lane address is formed here, per step: hoisted, it would be spilled
         *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(xch) + xoff + lane16) = a;
     };
 
     // gate math + publish of step t: the helper wavefront of each tile.  `first`: h_{t-1} = 0, so R h + Rb = Rb.
     // Layer 1: gi from gpre; layer 2: W_ih h1_t from xci (+ Wb).
-    auto gates_and_publish = [&](int t, bool first) {
+    // xi0: where layer 2's input projection of this step sits in xci (the two halves of xci alternate by step parity)
+    auto gates_and_publish = [&](int t, bool first, int xi0) {
         if (helper) {
             if (wave == 12) WS_STAMP(t, 6);
             const f32x4* bt = btab + tslot * 24 + q;
             const int x0 = tslot * 6 * 64 + lane;
+            const int xi = xi0 + lane;
             f32x4 z4, r4, h;
             {
-                f32x4 gi = layer ? (xci[x0] + xci[x0 + 64]) + bt[12] : gpre[0];
+                f32x4 gi = layer ? (xci[xi] + xci[xi + 64]) + bt[12] : gpre[0];
                 f32x4 a = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : xch[x0] + xch[x0 + 64];
                 const f32x4 b = bt[0];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) z4[r] = fast_sigmoid(gi[r] + (a[r] + b[r]));
             }
             {
-                f32x4 gi = layer ? (xci[x0 + 128] + xci[x0 + 192]) + bt[16] : gpre[1];
+                f32x4 gi = layer ? (xci[xi + 128] + xci[xi + 192]) + bt[16] : gpre[1];
                 f32x4 a = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : xch[x0 + 128] + xch[x0 + 192];
                 const f32x4 b = bt[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) r4[r] = fast_sigmoid(gi[r] + (a[r] + b[r]));
             }
             {
-                f32x4 gi = layer ? (xci[x0 + 256] + xci[x0 + 320]) + bt[20] : gpre[2];
+                f32x4 gi = layer ? (xci[xi + 256] + xci[xi + 320]) + bt[20] : gpre[2];
                 f32x4 a = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : xch[x0 + 256] + xch[x0 + 320];
                 const f32x4 b = bt[8];
                 const f32x4 hp = hpv[tslot * 64 + lane];
@@ -779,39 +815,46 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
 
     if (layer == 0) {
         request_gi(0);
-        gates_and_publish(0, true); // t = 0: gi only (no product: h_{-1} = 0)
+        gates_and_publish(0, true, 0); // t = 0: gi only (no product: h_{-1} = 0)
         for (int t = 1; t < T; ++t) {
             // h1_{t-1} of every peer, and -- before slot t % 4 is overwritten -- h1_{t-4} consumed by every layer-2 peer
             // (layer 2 reads h1_s in its step s: it has published h2_{t-4}, flag t - 3, only after that)
             request_gi(t);
-            acquire((unsigned)t, (t >= 4 && !(variant & 4)) ? (unsigned)(t - 3) : 0u, false, (unsigned)(((t - 1) & 3) * n_rt * GRU_J) * 1024u, t, 0);
+            acquire(14, (unsigned)t, (t >= 4 && !(variant & 4)) ? (unsigned)(t - 3) : 0u, false, (unsigned)(((t - 1) & 3) * n_rt * GRU_J) * 1024u, t, 0, -1, true);
             if (!barrier_alive()) return;
             if (wave == 0) WS_STAMP(t, 4);
-            if (gate_wave && tile_ok) chain(hbA);
+            if (gate_wave && tile_ok) chain(hbA, 0u);
             if (wave == 0) WS_STAMP(t, 5);
             __syncthreads();
-            gates_and_publish(t, false);
+            gates_and_publish(t, false, 0);
         }
     } else {
-        // step t: gi2_t = W_ih h1_t on the first half's chains WHILE the poller waits for the peers' h2_{t-1} and fetches
-        // it; then R2 h2_{t-1} on the second half's; then the gates -- and while the helper does those and publishes, the
-        // poller already fetches h1_{t+1} (layer 1 runs ahead through its ring of four slots).  On the chain from one
-        // publish to the next: flag, fetch of h2, ONE product phase of 104 MFMAs per SIMD, gates, drain.
+        // Step t.  Right behind the barrier that ends step t - 1's R phase three things start side by side: the helper
+        // does that step's gates and publishes; wavefront 15 fetches h1_t (layer 1 runs ahead through its ring of four
+        // slots) and sets *hA_ready; wavefront 14 waits for the peers' h2_{t-1} and fetches it.  The first half's chains
+        // compute gi2_t = W_ih h1_t as soon as hA_ready says so -- no barrier: they wait for the LDS word, and the two
+        // halves of xci alternate so that they may overwrite nothing the helper still reads -- i.e. in the shadow of the
+        // h2 hand-off; then ONE barrier (h2 in LDS, W_ih chains done, helper back), R2 h2_{t-1} on the second half's
+        // chains, the barrier that ends the step.  On the chain from one publish to the next: flag, fetch of h2, ONE
+        // product phase of 104 MFMAs per SIMD, gates, drain.
         const bool useA = !(variant & 1);
-        acquire(useA ? 1u : 0u, 0u, false, 0u, 0, 0);
-        if (!barrier_alive()) return;
+        if (useA) acquire(15, 1u, 0u, false, 0u, 0, 0, 1, false);
         for (int t = 0; t < T; ++t) {
-            if (t >= 1) acquire(0u, (unsigned)t, true, (unsigned)(((t - 1) & 1) * n_rt * GRU_J) * 1024u, t, 0);
-            if (gate_wave && ws == 0 && useA && !(variant & 32)) chain(hbA);
+            const int par = t & 1;
+            if (gate_wave && ws == 0 && useA && !(variant & 32)) {
+                if (wait_hA(t + 1)) chain(hbA, (unsigned)par * 6144u);
+            }
             if (wave == 0) WS_STAMP(t, 3);
             if (!barrier_alive()) return;
             if (wave == 6) WS_STAMP(t, 4);
-            if (gate_wave && ws == 1 && t >= 1) chain(hbB);
+            if (gate_wave && ws == 1 && t >= 1) chain(hbB, 0u);
             if (wave == 6) WS_STAMP(t, 5);
             __syncthreads();
-            if (t + 1 < T) acquire(useA ? (unsigned)(t + 2) : 0u, 0u, false, (unsigned)(((t + 1) & 3) * n_rt * GRU_J) * 1024u, t, 9);
-            gates_and_publish(t, t == 0);
-            if (!barrier_alive()) return;
+            if (t + 1 < T) {
+                if (useA) acquire(15, (unsigned)(t + 2), 0u, false, (unsigned)(((t + 1) & 3) * n_rt * GRU_J) * 1024u, t, 9, t + 2, false);
+                acquire(14, 0u, (unsigned)(t + 1), true, (unsigned)((t & 1) * n_rt * GRU_J) * 1024u, t + 1, 0, -1, true);
+            }
+            gates_and_publish(t, t == 0, par * 6 * 64);
         }
     }
     if (TRACE && tr) {

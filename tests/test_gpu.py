@@ -895,7 +895,7 @@ def test_context_options_validate_their_values(fv, gpu_ctx):
     # fvad_ctx_set_option: unknown names and bad values are errors, not ignored settings; NULL / "" restores the default
     L = fv.lib()
     for name, value in (("gru_kernel", "v9w9"), ("gemm_kernel", "fast"), ("h3_waves", "10"), ("max_chunks", "0"), ("nn_math", "bf16"),
-                        ("reproducible", "yes"), ("copy_threads", "-1"), ("no_such_option", "1"), ("ws2_variant", "128")):
+                        ("reproducible", "yes"), ("copy_threads", "-1"), ("no_such_option", "1"), ("ws2_variant", "33554432")):
         assert L.fvad_ctx_set_option(gpu_ctx.h, name.encode(), value.encode()) == fv.FVAD_ERR_INVALID_ARGUMENT, (name, value)
         assert name.encode() in L.fvad_last_error(gpu_ctx.h)
     assert L.fvad_ctx_set_option(None, b"reproducible", b"1") == fv.FVAD_ERR_INVALID_ARGUMENT

@@ -1,0 +1,32 @@
+"""gru_ws2k: the delay of a step's first flag poll (ws2_variant bit 24 + bits 8..15 for layer 1, 16..23 for layer 2, units of 40 ns) against the time of the
+pipelined recurrence at 1 and 82 chunks.  python tools/ws2_delay.py"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_package
+pkg = load_package(); fv = pkg.binding
+ctx = fv.Context(0); ctx.load_synth(7)
+rng = np.random.default_rng(0)
+for n in [int(a) for a in sys.argv[1:]] or (1, 82):
+    f = rng.uniform(-11, 2, (n, 54, 161)).astype(np.float32)
+    ctx.nsnet2_forward(f)
+    ctx.enable_timing(True)
+    for _ in range(6):
+        ctx.nsnet2_forward(f)
+    kt = ctx.kernel_times()
+    ctx.enable_timing(False)
+    print(f"n={n:3d} built-in waits (the default): {sum(v for k, v in kt.items() if 'rec' in k) / 6 * 1e3:6.1f} us", flush=True)
+    for d1 in (0, 20, 30, 40, 50, 60, 70, 80):
+        row = []
+        for d2 in (0, 20, 30, 40, 50, 60, 70, 80, 100):
+            with ctx.options(ws2_variant=(1 << 24) | (d1 << 8) | (d2 << 16)):
+                ctx.nsnet2_forward(f)
+                ctx.enable_timing(True)
+                for _ in range(6):
+                    ctx.nsnet2_forward(f)
+                kt = ctx.kernel_times()
+                ctx.enable_timing(False)
+            rec = sum(v for k, v in kt.items() if "rec" in k) / 6
+            row.append(f"{rec * 1e3:6.1f}")
+        print(f"n={n:3d} layer-1 wait {d1 * 0.04:4.1f} us | layer-2 wait 0, 0.8, 1.2, 1.6, 2.0, 2.4, 2.8, 3.2, 4.0 us: " + " ".join(row), flush=True)
