@@ -36,6 +36,9 @@
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WS_AUX_SC1 = 16;                            // buffer cache-policy bit: sc1 (system-coherent level 1)
+// wait before a step's first poll, in 10 ns ticks (measured by building with other values: 634 -> 571 us for 130 sequences,
+// 1060 -> 1014 for 300, 1210 -> 1170 for 600): gru_ws_kernel; gru_ws2_kernel per row tile of a group on top of a base
+constexpr unsigned WS_WAIT_TICKS = 80, WS2_WAIT_BASE = 40, WS2_WAIT_PER_RT = 40;
 
 template <int OWN>
 __global__ __launch_bounds__(256) void gru_ws_kernel(const float* __restrict__ gi, const float* __restrict__ R2frag,
@@ -141,9 +144,12 @@ __global__ __launch_bounds__(256) void gru_ws_kernel(const float* __restrict__ g
                 gin[o] = *reinterpret_cast<const f32x4*>(gp + 2 * gi_gs);
             }
         }
-        // ---- wait until every workgroup of the group has published h_{t-1} (flag >= t)
+        // ---- wait until every workgroup of the group has published h_{t-1} (flag >= t).  The first poll is timed: the
+        // peers' flags cannot be visible before ~WS_WAIT_TICKS x 10 ns after this workgroup raised its own, and a poll
+        // before that is a wasted round trip and traffic on the group's flag line (gru_ws2k_kernel)
         if (wave == 3) {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < WS_WAIT_TICKS) __builtin_amdgcn_s_sleep(1);
             int dead = 0;
             for (;;) {
                 const unsigned v = __hip_atomic_load(poll_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -364,6 +370,7 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
         if (wave == 3) {
             const unsigned need = lane < 32 ? need1 : need2;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < WS2_WAIT_BASE + WS2_WAIT_PER_RT * (unsigned)RT) __builtin_amdgcn_s_sleep(1); // timed first poll (gru_ws_kernel)
             int dead = 0;
             for (;;) {
                 const unsigned v = __hip_atomic_load(poll_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
