@@ -699,7 +699,8 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
             // made every step SLOWER -- 15.8k clocks against 14.8k: the extra sc1 traffic to the groups' flag lines delays
             // the fetches and the drains more than the earlier notice saves; tools/ws2_trace.py)
             for (;;) {
-                const unsigned v = __hip_atomic_load(poll_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned v = 0xFFFFFFFFu; // only the lanes that wait for something load: one flag line per poll, not two
+                if (need) v = __hip_atomic_load(poll_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__all(v >= need)) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) { dead = 1; break; }
