@@ -549,6 +549,9 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
 // per group.
 // waits before a step's first poll, in 10 ns ticks (see `timed` in the kernel): layer 1 / layer 2, groups of 13 + 25 and of 25 + 25
 constexpr unsigned WS2K_WAIT_L1 = 150, WS2K_WAIT_L2 = 240, WS2K_WAIT_L1_ONE = 200, WS2K_WAIT_L2_ONE = 200;
+// layer 2's fetch of the next h1 (wavefront 15) in groups of 13 + 25: 0.505 -> 0.491 ms at 82 chunks (0.55 ms at twice this
+// wait: it is on the critical path then); none in groups of 25 + 25, where it costs a one-chunk push 10-25 us
+constexpr unsigned WS2K_WAIT_H1 = 120;
 
 template <bool TRACE>
 __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict__ gi1, const float* __restrict__ R1frag,
@@ -687,8 +690,9 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
                                                       : (layer ? (one ? WS2K_WAIT_L2_ONE : WS2K_WAIT_L2) : (one ? WS2K_WAIT_L1_ONE : WS2K_WAIT_L1));
     auto acquire = [&](int pw, unsigned need1, unsigned need2, bool from_h2, unsigned slot, int st, int ev, int ready, bool timed) {
         if (wave == pw) {
-            if (timed && wait_ticks) {
-                const unsigned long long until = __builtin_amdgcn_s_memrealtime() + wait_ticks;
+            const unsigned wt = timed ? wait_ticks : ((pw == 15 && !one && !(variant & (1 << 24))) ? WS2K_WAIT_H1 : 0u);
+            if (wt) {
+                const unsigned long long until = __builtin_amdgcn_s_memrealtime() + wt;
                 while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(1);
             }
             WS_STAMP(st, ev);
