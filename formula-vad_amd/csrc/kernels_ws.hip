@@ -540,13 +540,14 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
 // (tools/ws2_variants.py: 6.2 us per step for layer 1 alone against gru_ws_kernel's 5.4 with 100).  Here a workgroup
 // has 16 wavefronts: twelve gate wavefronts (wave % 4 = SIMD: three on each), each holding ONE of the two
 // accumulation chains of a gate -- the even or the odd super-steps, 13 or 12 fragment blocks, 52 VGPRs -- and four
-// others (two tile helpers, the poller, one that only loads).  The two chains of a gate meet in the gate math,
+// others (two tile helpers, two that poll flags and fetch operands).  The two chains of a gate meet in the gate math,
 // a0 + a1 as before: the same bits as gru_ws2_kernel.  156 MFMAs per SIMD and step instead of 200.
 // Also: one flag per unit tile, raised by the tile's helper wavefront itself right after its own drain (no workgroup
 // barrier between publish and flag), and layer 2's row-major copy of h2 is stored after the flag.
 // One row tile per group (16 wavefronts x 128 VGPRs leave no room for a second one's operands): up to 6 groups = 96
 // sequences -- BASELINE config 3's 82 chunks, every live push; the 8-wavefront kernel above serves 2 to 4 row tiles
-// per group.
+// per group.  What a step costs is memory round trips (flag, poll, fetch, drain: tools/ws2_trace.py), and what the polls
+// cost depends on WHEN they are made: see `timed` in the kernel.
 // waits before a step's first poll, in 10 ns ticks (see `timed` in the kernel): layer 1 / layer 2, groups of 13 + 25 and of 25 + 25
 constexpr unsigned WS2K_WAIT_L1 = 150, WS2K_WAIT_L2 = 240, WS2K_WAIT_L1_ONE = 200, WS2K_WAIT_L2_ONE = 200;
 // layer 2's fetch of the next h1 (wavefront 15) in groups of 13 + 25: 0.505 -> 0.491 ms at 82 chunks (0.55 ms at twice this
