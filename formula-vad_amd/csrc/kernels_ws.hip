@@ -549,7 +549,7 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
 // per group.  What a step costs is memory round trips (flag, poll, fetch, drain: tools/ws2_trace.py), and what the polls
 // cost depends on WHEN they are made: see `timed` in the kernel.
 // waits before a step's first poll, in 10 ns ticks (see `timed` in the kernel): layer 1 / layer 2, groups of 13 + 25 and of 25 + 25
-constexpr unsigned WS2K_WAIT_L1 = 150, WS2K_WAIT_L2 = 240, WS2K_WAIT_L1_ONE = 200, WS2K_WAIT_L2_ONE = 200;
+constexpr unsigned WS2K_WAIT_L1 = 150, WS2K_WAIT_L2 = 270, WS2K_WAIT_L1_ONE = 220, WS2K_WAIT_L2_ONE = 220;
 // layer 2's fetch of the next h1 (wavefront 15) in groups of 13 + 25: 0.505 -> 0.491 ms at 82 chunks (0.55 ms at twice this
 // wait: it is on the critical path then); none in groups of 25 + 25, where it costs a one-chunk push 10-25 us
 constexpr unsigned WS2K_WAIT_H1 = 120;

@@ -17,9 +17,12 @@ for n in [int(a) for a in sys.argv[1:]] or (1, 82):
     kt = ctx.kernel_times()
     ctx.enable_timing(False)
     print(f"n={n:3d} built-in waits (the default): {sum(v for k, v in kt.items() if 'rec' in k) / 6 * 1e3:6.1f} us", flush=True)
-    for d1 in (0, 20, 30, 40, 50, 60, 70, 80):
+    fine = os.environ.get("WS2_DELAY_FINE")
+    d1s = (0, 20, 30, 40, 50, 60, 70, 80) if not fine else ((28, 32, 36, 40, 44, 48) if n > 80 else (40, 45, 50, 55, 60, 65))
+    d2s = (0, 20, 30, 40, 50, 60, 70, 80, 100) if not fine else ((48, 54, 60, 66, 72, 78) if n > 80 else (40, 45, 50, 55, 60, 65))
+    for d1 in d1s:
         row = []
-        for d2 in (0, 20, 30, 40, 50, 60, 70, 80, 100):
+        for d2 in d2s:
             with ctx.options(ws2_variant=(1 << 24) | (d1 << 8) | (d2 << 16)):
                 ctx.nsnet2_forward(f)
                 ctx.enable_timing(True)
@@ -29,4 +32,4 @@ for n in [int(a) for a in sys.argv[1:]] or (1, 82):
                 ctx.enable_timing(False)
             rec = sum(v for k, v in kt.items() if "rec" in k) / 6
             row.append(f"{rec * 1e3:6.1f}")
-        print(f"n={n:3d} layer-1 wait {d1 * 0.04:4.1f} us | layer-2 wait 0, 0.8, 1.2, 1.6, 2.0, 2.4, 2.8, 3.2, 4.0 us: " + " ".join(row), flush=True)
+        print(f"n={n:3d} layer-1 wait {d1 * 0.04:4.2f} us | layer-2 waits " + ", ".join(f"{d * 0.04:.2f}" for d in d2s) + " us: " + " ".join(row), flush=True)
