@@ -60,7 +60,8 @@ pub extern "c" fn fvad_ctx_destroy(ctx: ?*Ctx) void;
 pub extern "c" fn fvad_last_error(ctx: ?*const Ctx) [*:0]const u8;
 pub extern "c" fn fvad_load_nsnet2_onnx(ctx: *Ctx, path: [*:0]const u8) c_int;
 pub extern "c" fn fvad_load_nsnet2_synth(ctx: *Ctx, seed: u64) c_int;
-/// 0 = f32 MFMA throughout, 1 = f16x3 (default): arithmetic of the large-batch NSNet2 matrix products; returns the previous mode
+/// arithmetic of the NSNet2 matrix products at every batch size; returns the previous mode.  The default is 0 (f32) since ABI 3
+/// (ABI 2 defaulted to f16x3: callers that relied on that must now opt in)
 pub extern "c" fn fvad_ctx_set_nn_math(ctx: *Ctx, mode: c_int) c_int; // 0 = f32 (default, the ORT CPU arithmetic), 1 = f16x3 emulation (22-bit operands), 2 = bf16x3 (24-bit operands, dense layers)
 pub extern "c" fn fvad_ctx_nn_math_effective(ctx: *const Ctx) c_int;
 pub extern "c" fn fvad_ctx_last_nn_path(ctx: *const Ctx) [*:0]const u8;

@@ -304,16 +304,22 @@ static void free_workspace_nn(Workspace& ws)
     ws.cap_rows = 0;
 }
 
-int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T)
+static long padded_batch(const fvad_ctx* ctx, long n, int T, int skip);
+
+int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T, int skip, long n_last)
 {
     Workspace& ws = ctx->ws;
-    const long need = ((n_chunks + 767) / 768) * 768; // 768 = lcm of every batch padding (32, 128, 192 -> 384, 256)
+    // chunk-count-sized buffers (descriptors, spectrogram): rounded to 768 = lcm of every batch padding (32, 128, 192 -> 384, 256)
+    const long need = ((n_chunks + 767) / 768) * 768;
     const DeviceModel& dm = ctx->dm;
     const bool same_widths = ws.w_a1 == dm.w_a1 && ws.w_gi == dm.w_gi && ws.w_h == dm.w_h && ws.w_f == dm.w_f;
     // bf16x3 mode: h1 / h2 and the fc2 / fc3 outputs as three-piece fragments (13 / 19 K-steps of 3 KB per 16 rows),
     // allocated only for contexts that run in that mode
     // (capacities are ROWS -- padded sequences x steps: a long sequence and a wide batch need not fit at once)
-    const size_t need_rows = (size_t)need * (size_t)T;
+    // the NSNet2 buffers hold the rows of the padding this launch really uses (a one-sequence call of 14400 steps is 32
+    // padded sequences, not 768: 2 GB of gi instead of 53)
+    // n_last: the size of a call's short last launch, whose padding need not be below the full launches'
+    const size_t need_rows = (size_t)std::max(padded_batch(ctx, n_chunks, T, skip), n_last > 0 ? padded_batch(ctx, n_last, T, skip) : 0L) * (size_t)T;
     if (nn_math_effective(ctx) == FVAD_NN_MATH_BF16X3 && need_rows > ws.b3_cap_rows) {
         hipStreamSynchronize(ctx->stream);
         float** b3bufs[] = {&ws.b3_hs1, &ws.b3_hs2, &ws.b3_f2, &ws.b3_f3};
@@ -488,10 +494,15 @@ static long padded_batch(const fvad_ctx* ctx, long n, int T, int skip)
     if (!tn.reproducible && (!force || force[1] == '5' || force[1] == '6') && tn.gemm_kernel.empty() && c < 2048 &&
         std::min(gru_ws_cost(c, cu), gru_ws2_cost_both_layers(c, cu) / 108.0) < std::min(gru_cost(b, 0, cu), gru_cost(b, 4, cu)))
         return c;
-    if (force || a == b) return a;
+    // the persistent GEMM takes 256-row panels of T n and of (T - skip) n rows: any multiple of 128 sequences at the
+    // engine's T = 54 / 50, a multiple of 256 for an odd sequence length (fvad_nsnet2_forward takes any); `reproducible`
+    // promises ONE kernel family, so there the batch is padded until the panels fit instead of changing family
+    auto fits256 = [&](long np) { return (np * T) % 256 == 0 && (np * (T - skip)) % 256 == 0; };
+    auto repro = [&](long np) { return (tn.reproducible && !fits256(np)) ? (np + 255) / 256 * 256 : np; };
+    if (force || a == b) return repro(a);
     const double cost_a = std::min(std::min(gru_cost(a, 12, cu), gru_cost(a, 8, cu)), std::min(gru_cost(a, 4, cu), gru_cost(a, 0, cu)));
     const double cost_b = std::min(gru_cost(b, 8, cu), std::min(gru_cost(b, 4, cu), gru_cost(b, 0, cu)));
-    return cost_b <= cost_a ? b : a;
+    return repro(cost_b <= cost_a ? b : a);
 }
 
 static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, bool allow_v3)
@@ -704,6 +715,8 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
         return FVAD_OK;
     }
     const bool big = h3 || (force ? force[1] != '1' : (tn.reproducible || n_pad >= 2048));
+    if (tn.reproducible && !force && (rows % 256 || rows_out % 256))
+        return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "reproducible: batch not padded to the persistent GEMM's 256-row panels");
     if (big && rows % 256 == 0 && rows_out % 256 == 0) {
         // The persistent kernel: one workgroup per CU walking all (row panel, column block) items; 15-, 13- and
         // 11-tile column blocks.  K is the true reduction length (S super-steps of 16 cover it, zero-padded).
@@ -857,7 +870,7 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
     long total = 0;
     for (auto& j : jobs) total += (long)j.n_chunks;
     if (total == 0) return FVAD_OK;
-    int rc = ensure_workspace(ctx, std::min(total, max_chunks), kRowsPerChunk);
+    int rc = ensure_workspace(ctx, std::min(total, max_chunks), kRowsPerChunk, kWarmupRows, total % std::min(total, max_chunks));
     if (rc) return rc;
     Workspace& ws = ctx->ws;
     const long cap = std::min<long>(max_chunks, ws.cap_chunks);
@@ -928,6 +941,8 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
                                                kNBins * sizeof(float), t.count * (size_t)kRowsPerChunk, hipMemcpyDeviceToHost, ctx->stream));
         }
         const long n_pad = padded_batch(ctx, n, kRowsPerChunk, kWarmupRows);
+        if ((size_t)n_pad * kRowsPerChunk > ws.cap_rows) // (the padding of a short last launch is not bounded by the first one's)
+            return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "NSNet2 workspace smaller than this launch's padded batch");
         rc = run_nn(ctx, n_pad, kRowsPerChunk, kWarmupRows);
         if (rc) return rc;
         time_begin(ctx, "istft320_ola_up3");
@@ -1340,7 +1355,7 @@ int fvad_nsnet2_forward(fvad_ctx* ctx, const float* features, size_t n_seq, size
 {
     if (!ctx || !features || !gains || n_seq == 0 || T == 0) return FVAD_ERR_INVALID_ARGUMENT;
     hipSetDevice(ctx->device);
-    int rc = ensure_workspace(ctx, (long)n_seq, (int)T);
+    int rc = ensure_workspace(ctx, (long)n_seq, (int)T, 0);
     if (rc) return rc;
     Workspace& ws = ctx->ws;
     const long n_pad = padded_batch(ctx, (long)n_seq, (int)T, 0);
@@ -1483,8 +1498,9 @@ int staged_copy(fvad_ctx* ctx, const std::vector<CopySeg>& segs, bool to_device,
         // copies that return at once; device -> host = async copies, ONE wait, memcpy.
         Workspace::PinSmall& b = to_device ? ctx->ws.small_in : ctx->ws.small_out;
         if (!b.base) {
+            // the event first: a buffer without its event would make every later call wait on a null event
+            if (!b.ev) FVAD_HIP(ctx, hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
             FVAD_HIP(ctx, hipHostMalloc((void**)&b.base, kPinSmallBytes, hipHostMallocDefault));
-            FVAD_HIP(ctx, hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
         } else if (to_device) {
             FVAD_HIP(ctx, hipEventSynchronize(b.ev)); // the previous use's copies have left the buffer
         }
@@ -1941,7 +1957,7 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
         long maxc = opts.max_chunks_per_launch;
         if (maxc <= 0) maxc = ctx->tune.max_chunks;
         const long total = (long)(n_lanes * n_chunks);
-        if ((rc = ensure_workspace(ctx, std::min(total, maxc), kRowsPerChunk))) return rc; // no allocation while capturing
+        if ((rc = ensure_workspace(ctx, std::min(total, maxc), kRowsPerChunk, kWarmupRows, total % std::min(total, maxc)))) return rc; // no allocation while capturing
         if ((rc = ensure_gru_ws(ctx))) return rc;
         Workspace::GraphCache& gc = ws.graph;
         const void* pcm_key = d_pcm ? (const void*)d_pcm : (const void*)d_pcm16;
@@ -1990,6 +2006,9 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
             gc.valid = true;
         }
         FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
+        // the replayed sequence may hold a pass of gru_ws_kernel (launches of 385..~1900 chunks), which leaves the polled
+        // words counted up: whatever a direct call knew about them is void after a replay
+        ws.sync_clean = false;
         FVAD_HIP(ctx, hipGraphLaunch(gc.exec, st));
         FVAD_HIP(ctx, hipStreamSynchronize(st));
         FVAD_HIP(ctx, hipGetLastError());

@@ -217,7 +217,7 @@ int hip_fail(const fvad_ctx* ctx, hipError_t e, const char* what);
 int upload_model(fvad_ctx* ctx);
 // FVAD_NN_MATH_F32 / FVAD_NN_MATH_F16X3: what run_nn uses on this context with the loaded model, at every batch size
 int nn_math_effective(const fvad_ctx* ctx);
-int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T);
+int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T, int skip, long n_last = 0);
 int ensure_gru_ws(fvad_ctx* ctx);
 // tables of the n-point VAD FFT (n = 512 / 1024 / 2048), cached per context
 int get_vad_plan(fvad_ctx* ctx, size_t n, VadFftPlan* out);

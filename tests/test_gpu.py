@@ -190,8 +190,15 @@ def test_nsnet2_forward_matches_oracle(fv, gpu_ctx, weights7):
         assert g.min() >= 0 and g.max() <= 1
     # one long sequence (its padded gi is 2.2 GB: past the 32-bit offsets of the 16-wavefront pipelined recurrence, which
     # must hand the launch to the kernel with 64-bit addresses)
+    # -- on a context of its own, closed afterwards: the workspace never shrinks, and the session-wide context should
+    # not carry 32 x 14400 rows (9 GB) through the rest of the session
     f = rng.uniform(-11, 2, (1, 14400, 161)).astype(np.float32)
-    g = gpu_ctx.nsnet2_forward(f)
+    own = fv.Context(0)
+    try:
+        own.load_weights(weights7)
+        g = own.nsnet2_forward(f)
+    finally:
+        own.close()
     ref = orc.nsnet2_forward(weights7, f[0])
     assert_rel(g[0], ref, 1e-4, floor=1e-2, what="gains of one 14400-step sequence")
     # the GRU state is reset for every sequence: batch order cannot matter
@@ -232,6 +239,24 @@ def test_nsnet2_large_batch_kernels_match_oracle(fv, gpu_ctx, weights7, opts):
     ref = np.stack([orc.nsnet2_forward(weights7, f[i]) for i in pick])
     assert_rel(g[pick], ref, 1e-4, floor=1e-2, what=f"gains large batch {env}")
     assert g.min() >= 0 and g.max() <= 1
+
+
+def test_reproducible_keeps_one_family_for_odd_sequence_lengths(fv, gpu_ctx, weights7):
+    # option `reproducible`: ONE kernel family (persistent GEMM + gru_rec3) for every launch.  A sequence length whose
+    # padded rows are not a multiple of the GEMM's 256-row panels (odd T) used to fall through to the small-batch
+    # family without saying so; now the batch is padded until the panels fit.
+    rng = np.random.default_rng(12)
+    with gpu_ctx.options(reproducible="1"):
+        for n_seq, T in ((5, 7), (131, 5), (3, 54), (40, 9)):
+            f = rng.uniform(-11, 2, (n_seq, T, 161)).astype(np.float32)
+            g = gpu_ctx.nsnet2_forward(f)
+            path = gpu_ctx.last_nn_path()
+            assert "panel_gemm3" in path and "gru_rec3" in path, (n_seq, T, path)
+            ref = np.stack([orc.nsnet2_forward(weights7, s) for s in f])
+            assert_rel(g, ref, 1e-4, floor=1e-2, what=f"reproducible gains n_seq={n_seq} T={T}")
+            # ... and the bits do not depend on the batch the sequence sits in
+            g1 = gpu_ctx.nsnet2_forward(f[:1])
+            assert np.array_equal(g1[0], g[0]), (n_seq, T)
 
 
 def test_f16x3_products_are_as_close_to_float64_as_f32(fv, weights7):
@@ -685,6 +710,34 @@ assert all(np.array_equal(u, v) for u, v in zip(run(x, 16 * 24000, bufs), ref8))
 many = [a[0][: 2 * 24000].copy() for _ in range(40)]                                     # 80 scratch carries, 40 jobs
 ctx.engine_run(many)
 assert all(np.array_equal(u, v) for u, v in zip(run(x, 16 * 24000, bufs), ref8))
+# A replayed graph may hold a pass of gru_ws_kernel (385..~1900 chunks per launch), which leaves the polled words of the
+# weight-stationary recurrences counted up; the direct small calls around it (gru_ws2: one chunk, 82 chunks) must not
+# take those words for clean.  32 lanes x 16 chunks = 512 chunks per launch.
+xw = torch.from_numpy(np.stack([np.roll(a[0], 499 * i) for i in range(32)])[:, : 16 * 24000].copy()).to(dev)
+x1 = xa[:1, : 24000].contiguous()
+x82 = torch.from_numpy(np.stack([np.roll(b[0], 313 * i)[: 2 * 24000] for i in range(41)]).copy()).to(dev)
+GRAPH = False
+ref_w, ref_1, ref_82 = run(xw, 16 * 24000), run(x1, 24000), run(x82, 2 * 24000)
+assert "gru_ws" in ctx.last_nn_path() and np.abs(ref_w[2]).max() > 0
+bw = (torch.zeros((32, 16 * 24000 // 1024), dtype=torch.float32, device=dev),
+      torch.zeros((32, 16), dtype=torch.float32, device=dev),
+      torch.zeros((32, 16 * 24000), dtype=torch.float32, device=dev))
+def graph_w():
+    global GRAPH
+    GRAPH = True
+    r = run(xw, 16 * 24000, bw)
+    GRAPH = False
+    return r
+eq = lambda u, v: all(np.array_equal(p, q) for p, q in zip(u, v))
+assert eq(graph_w(), ref_w)            # capture
+assert eq(run(x1, 24000), ref_1)       # direct, pipelined recurrence: leaves the words clean
+assert eq(graph_w(), ref_w)            # replay: leaves them counted up
+assert eq(run(x1, 24000), ref_1)       # must start from a reset
+assert eq(graph_w(), ref_w)
+assert eq(run(x82, 2 * 24000), ref_82)
+assert eq(run(x1, 24000), ref_1)
+n_fb = ctx.ws_fallbacks()
+assert n_fb == 0, n_fb
 ctx.close()
 print("GRAPH_OK")
 """

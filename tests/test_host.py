@@ -657,3 +657,99 @@ def test_golden_vad_stream_segments(fv):
     assert np.array_equal(np.array([s[2] for s in segs], np.float32), g["seg_ratio"])
     assert np.array_equal(np.array([s[3] for s in segs], np.float32), g["seg_met"])
     assert len(segs) == 9
+
+
+# ------------------------------------------------------------------ the one numeric fixture the reference holds for a16 / f3
+# /root/reference/README.md:28-61: the performance report of the reference's own 21-stream run (per-stream rows as
+# printed: whole seconds, rates to 0.1 %) and its aggregate block.  It pins statistics.aggregate's formulas
+# (statistics.zig:116-182: in-order sums, min / avg / max of the four rates, overall rates, f_score(0.7), fm_index) and
+# report_generator.zig:21-116's layout at printed precision.  (P, TP, FP, FN; TPR, PPV, FNR, FDR as printed.)
+README_ROWS = [
+    ("2023 Monaco FP1 - Perez", 1137, 1135, 5, 2, 99.8, 99.6, 0.2, 0.4),
+    ("2023 Miami Race - Sargeant", 1092, 1075, 6, 17, 98.4, 99.4, 1.6, 0.6),
+    ("2023 Miami Race - Gasly", 1447, 1362, 23, 86, 94.1, 98.3, 5.9, 1.7),
+    ("2023 Miami Race - Perez", 1025, 996, 5, 29, 97.2, 99.5, 2.8, 0.5),
+    ("2023 Miami Race - Leclerc", 1222, 1222, 0, 0, 100.0, 100.0, 0.0, 0.0),
+    ("2023 Miami Race - De Vries", 952, 940, 0, 12, 98.7, 100.0, 1.3, 0.0),
+    ("2023 Miami Race - Zhou", 1082, 1070, 11, 12, 98.9, 99.0, 1.1, 1.0),
+    ("2023 Miami Race - Magnussen", 1028, 1020, 6, 7, 99.3, 99.5, 0.7, 0.5),
+    ("2023 Miami Race - Russell", 1435, 1398, 8, 37, 97.4, 99.4, 2.6, 0.6),
+    ("2023 Miami Race - Norris", 513, 512, 0, 1, 99.8, 100.0, 0.2, 0.0),
+    ("2023 Miami Race - Stroll", 1114, 1108, 0, 6, 99.5, 100.0, 0.5, 0.0),
+    ("2023 Miami Race - Tsunoda", 671, 664, 0, 6, 99.1, 100.0, 0.9, 0.0),
+    ("2023 Miami Race - Verstappen", 1049, 1039, 0, 10, 99.0, 100.0, 1.0, 0.0),
+    ("2023 Miami Race - Sainz", 1447, 1436, 8, 11, 99.3, 99.4, 0.7, 0.6),
+    ("2023 Miami Race - Albon", 561, 547, 0, 14, 97.5, 100.0, 2.5, 0.0),
+    ("2023 Miami Race - Hulkenberg", 617, 617, 18, 0, 100.0, 97.2, 0.0, 2.8),
+    ("2023 Miami Race - Ocon", 597, 594, 14, 3, 99.5, 97.7, 0.5, 2.3),
+    ("2023 Miami Race - Hamilton", 1261, 1233, 10, 28, 97.8, 99.2, 2.2, 0.8),
+    ("2023 Miami Race - Alonso", 1172, 1154, 0, 18, 98.4, 100.0, 1.6, 0.0),
+    ("2023 Miami Race - Bottas", 575, 573, 0, 2, 99.6, 100.0, 0.4, 0.0),
+    ("2023 Miami Race - Piastri", 822, 782, 0, 40, 95.1, 100.0, 4.9, 0.0),
+]
+README_AGGREGATE = """
+=> Aggregate stats 
+
+Total speech duration  (P): 20822.3 sec
+True positives        (TP): 20480.1 sec
+False positives       (FP):   113.3 sec
+False negatives       (FN):   342.2 sec    Min.    Avg.    Max. 
+True positive rate   (TPR):    98.4%  |   94.1% / 98.5% /100.0% 
+Precision            (PPV):    99.4%  |   97.2% / 99.4% /100.0% 
+False negative rate  (FNR):     1.6%  |    0.0% /  1.5% /  5.9% 
+False discovery rate (FDR):     0.6%  |    0.0% /  0.6% /  2.8% 
+F-Score (β =  0.70)       :    99.1% 
+Fowlkes-Mallows index     :    98.9% 
+"""
+
+
+def test_readme_aggregate_block(fv, pkg):
+    f32 = np.float32
+    singles = []
+    for name, P, TP, FP, FN, tpr, ppv, fnr, fdr in README_ROWS:
+        s = fv.SingleStats()
+        s.total_positives_sec, s.true_positives_sec, s.false_positives_sec, s.false_negatives_sec = P, TP, FP, FN
+        # the rates as printed (to 0.1 %: closer to the run's own values than anything recomputed from seconds that were
+        # rounded to whole numbers -- 664 / 671 is 98.96 % where the run had 99.1 %)
+        s.true_positive_rate, s.precision, s.false_negative_rate, s.false_discovery_rate = tpr / 100, ppv / 100, fnr / 100, fdr / 100
+        s.f_score_beta = 0.7
+        # statistics.fromEvaluator's formulas (statistics.zig:105-112) on the printed seconds agree with them within that rounding
+        for got, want in ((f32(TP) / f32(P), tpr), (f32(TP) / (f32(TP) + f32(FP)), ppv), (f32(FN) / f32(P), fnr), (f32(FP) / (f32(FP) + f32(TP)), fdr)):
+            assert abs(got * 100 - want) <= 0.2, (name, got * 100, want)
+        singles.append(s)
+    agg = fv.stats_aggregate(singles)
+    sim = pkg.simulator
+    txt = sim.report_text([r[0] for r in README_ROWS], singles, agg)
+    # the per-stream table, byte for byte (report_generator.zig:21-27's row format)
+    want_rows = ["| {} | {:>4d} | {:>4d} | {:>4d} | {:>4d} | {:>5.1f}% | {:>5.1f}% | {:>7.1f}% | {:>7.1f}% |".format(r[0].rjust(30), *r[1:])
+                 for r in README_ROWS]
+    got_rows = [l for l in txt.split("\n") if l.startswith("| ") and "2023" in l]
+    assert len(got_rows) == 21
+    assert got_rows == want_rows
+    got_block = txt[txt.index("\n=> Aggregate stats"):]
+    got_lines, want_lines = got_block.split("\n"), README_AGGREGATE.split("\n")
+    assert len(got_lines) == len(want_lines)
+    # sums of 21 rows rounded to whole seconds: within 21 x 0.5 s of the printed sums, in the printed layout
+    for i, key in ((3, "total_positives_sec"), (4, "true_positives_sec"), (5, "false_positives_sec"), (6, "false_negatives_sec")):
+        g, w = got_lines[i], want_lines[i]
+        assert g[:28] == w[:28] and g[35:] == w[35:] and len(g) == len(w), (g, w)
+        assert abs(float(g[28:35]) - float(w[28:35])) <= 10.5, (g, w)
+    # the rate lines, F-score and Fowlkes-Mallows: byte for byte (overall rates, min / avg / max over the streams)
+    for i in (0, 1, 2, 7, 8, 9, 10, 11, 12, 13):
+        assert got_lines[i] == want_lines[i], (i, got_lines[i], want_lines[i])
+    # the formulas behind the block (statistics.zig:116-182)
+    assert abs(agg.f_score * 100 - 99.1) < 0.05 and abs(agg.fm_index * 100 - 98.9) < 0.05
+    assert agg.true_positive_rate.min == min(s.true_positive_rate for s in singles)
+    assert agg.precision.max == 1.0 and agg.false_discovery_rate.min == 0.0
+    # the oracle's aggregate (the CPU restatement the GPU tests are checked against) is pinned by the same block
+    O = orc.lib()
+    osingles = (orc.SingleStats * 21)()
+    for o, s in zip(osingles, singles):
+        for name, _ in fv.SingleStats._fields_:
+            setattr(o, name, getattr(s, name))
+    oagg = O.orc_stats_aggregate(osingles, 21)
+    for name in ("total_positives_sec", "true_positives_sec", "false_positives_sec", "false_negatives_sec", "fm_index", "f_score", "f_score_beta"):
+        assert getattr(agg, name) == getattr(oagg, name), name
+    for name in ("true_positive_rate", "false_negative_rate", "false_discovery_rate", "precision"):
+        for f in ("overall", "min", "max", "avg"):
+            assert getattr(getattr(agg, name), f) == getattr(getattr(oagg, name), f), (name, f)

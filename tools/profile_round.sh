@@ -13,13 +13,17 @@ export TMPDIR=/tmp
 biggest() { ls -S "$1"/*/*"$2" 2>/dev/null | head -1; }
 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG/stats --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra \
     > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/prof_${TAG}_stats.err || echo "stats run failed"
-cp "$(biggest $OUT/prof_$TAG/stats _kernel_stats.csv)" $OUT/${TAG}_kernel_stats.csv
+FAILED=0
+# a pass that produced no CSV is reported and skipped (cp with an empty argument would fail anyway), and the script exits non-zero
+keep() { if [ -n "$1" ] && [ -f "$1" ]; then cp "$1" "$2"; else echo "no CSV for $2: pass failed" >&2; FAILED=1; fi; }
+keep "$(biggest $OUT/prof_$TAG/stats _kernel_stats.csv)" $OUT/${TAG}_kernel_stats.csv
 for pass in "fetch_size FETCH_SIZE" "write_size WRITE_SIZE" "mfma_busy SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     set -- $pass
     name=$1; shift
     rocprofv3 --kernel-trace --pmc "$@" -d $OUT/prof_$TAG/pmc_$name --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra \
         > $OUT/prof_${TAG}_pmc_$name.json 2> $OUT/prof_${TAG}_pmc_$name.err || echo "pmc $name run failed"
-    cp "$(biggest $OUT/prof_$TAG/pmc_$name _counter_collection.csv)" $OUT/${TAG}_pmc_$name.csv
+    keep "$(biggest $OUT/prof_$TAG/pmc_$name _counter_collection.csv)" $OUT/${TAG}_pmc_$name.csv
     echo "pass $name done"
 done
 ls -la $OUT/${TAG}_*
+exit $FAILED
