@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--lanes", type=int, default=384, help="streams per GPU per step")
     ap.add_argument("--seconds", type=int, default=64, help="audio seconds per stream per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cfg4-strong", action="store_true", help="N > 1: skip the strong-scaling block (config 4's plan on the same ranks)")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-2 / config-3 side measurements")
     ap.add_argument("--vad-threads", type=int, default=0)
     ap.add_argument("--nn-math", default="f32", choices=("f32", "f16x3", "bf16x3"),
@@ -190,8 +191,9 @@ def roll_labels(labels, shift_s, period_s, reps):
     return sorted(out)
 
 
-def run_cfg4(args, pkg, fv, ctx, torch, dist, rank, world, cdev):
-    """BASELINE config 4: 21 independent streams (Miami-race sized) dealt round-robin to the ranks
+def run_cfg4(args, pkg, fv, ctx, torch, dist, rank, world, cdev, steps=None, warmup=None, emit=True):
+    """(emit=False: return rank 0's record instead of printing it -- the `cfg4_strong` block of a multi-GPU headline run.)
+    BASELINE config 4: 21 independent streams (Miami-race sized) dealt round-robin to the ranks
     (shard.streams_for_rank: 3,3,3,3,3,2,2,2 over 8), every rank runs the whole path for its streams -- GPU
     kernels, host VAD, Evaluator statistics against the streams' labels -- then ONE all-gather of the per-stream
     SingleStats and the plan-order aggregate (statistics.zig:116-172).  A step = the whole plan."""
@@ -267,11 +269,12 @@ def run_cfg4(args, pkg, fv, ctx, torch, dist, rank, world, cdev):
         timing.update(gpu=(t1 - t0), host=(t2 - t1), gather_aggregate=(t3 - t2), segments=n_seg)
         return allst, agg
 
-    for _ in range(args.warmup):
+    n_steps = args.steps if steps is None else steps
+    for _ in range(args.warmup if warmup is None else warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(n_steps):
         allst, agg = step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -279,13 +282,17 @@ def run_cfg4(args, pkg, fv, ctx, torch, dist, rank, world, cdev):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t[0])
+    rccl_ranks = comm.world if comm is not None else None
     if comm is not None:
         comm.close()
+    vb.close()
+    for d in (d_pcm, d_band, d_rms):
+        ctx.device_free(d)
     if rank == 0:
         frames = n_streams * n_chunks * FRAMES_PER_CHUNK
         out = {
-            "metric": "20ms audio frames/sec end-to-end VAD pipeline", "value": frames * args.steps / elapsed, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "metric": "20ms audio frames/sec end-to-end VAD pipeline", "value": frames * n_steps / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": n_steps, "warmup": args.warmup if warmup is None else warmup, "ms_per_step": elapsed / n_steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic 48 kHz mono (one 600 s seeded pattern, rolled per stream and tiled), random-init NSNet2 weights seed 7",
             "config": {"workload": f"BASELINE config 4: {n_streams} streams x {seconds} s, whole streams dealt round-robin to "
@@ -293,12 +300,15 @@ def run_cfg4(args, pkg, fv, ctx, torch, dist, rank, world, cdev):
                                    "per-rank GPU path + host VAD + Evaluator statistics, one all-gather, plan-order aggregate",
                        "streams": n_streams, "seconds_per_stream": seconds,
                        "parallelism": f"streams sharded over {world} rank(s), no data-path collective"},
-            "audio_seconds_per_s": frames * args.steps / elapsed / 100.0,
+            "audio_seconds_per_s": frames * n_steps / elapsed / 100.0,
             "aggregate": {"n_streams": n_streams, "tpr": agg.true_positive_rate.overall, "ppv": agg.precision.overall,
-                          "collective": collective},
+                          "collective": collective, "rccl_ranks": rccl_ranks},
             "rank0_step_s": timing,
         }
+        if not emit:
+            return out
         print(json.dumps(out))
+    return None
 
 
 def cpu_model():
@@ -591,6 +601,10 @@ def main():
              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
              # HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction)
              "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
+             # plain scalars beside the figure, so a record that keeps only `roofline`'s top level still says where the bytes
+             # come from and whether the kernels have changed since they were counted
+             "traffic_profile": pmc.get("profile") if pmc else None,
+             "traffic_stale": pmc.get("stale") if pmc else None,
              "traffic_source": pmc,
              "algorithmic_hbm_bytes_per_launch": hbm,
              "algorithmic_hbm_frac_of_8TBps": hbm / (gru_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if gru_ms > 0 else 0.0,
@@ -687,6 +701,16 @@ def main():
     else:
         rank_ms = [head["rank_elapsed"] / args.steps * 1e3]
 
+    # ---- N > 1: the same ranks also run BASELINE config 4's plan (21 x 7200 s streams dealt round-robin, the RCCL
+    # statistics gather, the plan-order aggregate) -- a FIXED amount of work, so one driver invocation per N records weak
+    # scaling (the headline: every rank the same batch) and strong scaling (`cfg4_strong`) side by side
+    cfg4_strong = None
+    if world > 1 and not args.no_cfg4_strong:
+        try:
+            cfg4_strong = run_cfg4(args, pkg, fv, ctx, torch, dist, rank, world, cdev, steps=2, warmup=1, emit=False)
+        except Exception as e:  # every rank takes the same path: an exception here is an allocation or a library error
+            cfg4_strong = {"error": repr(e)}
+
     if rank == 0:
         total_frames = frames_per_step * args.steps * world
         value = total_frames / elapsed
@@ -734,6 +758,8 @@ def main():
             "join_wait_ms": head["join_ms"],
             "host_stage_ms": head["host_ms"],
         }
+        if cfg4_strong is not None:
+            out["cfg4_strong"] = cfg4_strong
         # the CPU baseline and the side measurements belong to the single-GPU run only
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg, fv, weights, min(os.cpu_count() or 1, 16))

@@ -18,6 +18,10 @@
 
 #include "internal.h"
 
+#ifndef FVAD_DIAG
+#define FVAD_DIAG 0 // diagnostics build: see kernels_ws.hip
+#endif
+
 namespace fvad {
 
 int set_err(const fvad_ctx* ctx, int code, const std::string& msg)
@@ -302,6 +306,7 @@ static void free_workspace_nn(Workspace& ws)
     ws.descs = nullptr; ws.h_descs = nullptr;
     ws.cap_chunks = 0;
     ws.cap_rows = 0;
+    ws.a1_cap_rows = ws.h_cap_rows = ws.hs_cap_rows = 0;
 }
 
 static long padded_batch(const fvad_ctx* ctx, long n, int T, int skip);
@@ -313,54 +318,63 @@ int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T, int skip, long n_last)
     const long need = ((n_chunks + 767) / 768) * 768;
     const DeviceModel& dm = ctx->dm;
     const bool same_widths = ws.w_a1 == dm.w_a1 && ws.w_gi == dm.w_gi && ws.w_h == dm.w_h && ws.w_f == dm.w_f;
-    // bf16x3 mode: h1 / h2 and the fc2 / fc3 outputs as three-piece fragments (13 / 19 K-steps of 3 KB per 16 rows),
-    // allocated only for contexts that run in that mode
     // (capacities are ROWS -- padded sequences x steps: a long sequence and a wide batch need not fit at once)
     // the NSNet2 buffers hold the rows of the padding this launch really uses (a one-sequence call of 14400 steps is 32
     // padded sequences, not 768: 2 GB of gi instead of 53)
     // n_last: the size of a call's short last launch, whose padding need not be below the full launches'
     const size_t need_rows = (size_t)std::max(padded_batch(ctx, n_chunks, T, skip), n_last > 0 ? padded_batch(ctx, n_last, T, skip) : 0L) * (size_t)T;
-    if (nn_math_effective(ctx) == FVAD_NN_MATH_BF16X3 && need_rows > ws.b3_cap_rows) {
+    int rc;
+    if (!(need <= ws.cap_chunks && need_rows <= ws.cap_rows && same_widths)) {
         hipStreamSynchronize(ctx->stream);
-        float** b3bufs[] = {&ws.b3_hs1, &ws.b3_hs2, &ws.b3_f2, &ws.b3_f3};
-        for (float** b : b3bufs) { if (*b) hipFree(*b); *b = nullptr; }
-        const size_t rows3 = need_rows;
-        int rc3;
-        if ((rc3 = dev_alloc(ctx, &ws.b3_hs1, rows3 * 624, true))) return rc3;
-        if ((rc3 = dev_alloc(ctx, &ws.b3_hs2, rows3 * 624, true))) return rc3;
-        if ((rc3 = dev_alloc(ctx, &ws.b3_f2, rows3 * 912, true))) return rc3;
-        if ((rc3 = dev_alloc(ctx, &ws.b3_f3, rows3 * 912, true))) return rc3;
-        ws.b3_cap_rows = rows3;
+        const long G = std::max(need, ws.cap_chunks);
+        const size_t rows = std::max(need_rows, ws.cap_rows);
+        free_workspace_nn(ws);
+        FVAD_HIP(ctx, hipMalloc((void**)&ws.descs, (size_t)G * sizeof(ChunkDesc)));
+        FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_descs, 2 * (size_t)G * sizeof(ChunkDesc), hipHostMallocDefault));
+        for (hipEvent_t& e : ws.desc_ev) if (!e) FVAD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        // what every arithmetic uses.  Zero-filled: padded rows / padded columns are read by the GEMMs and must stay finite
+        if ((rc = dev_alloc(ctx, &ws.feat, rows * kFeatStride, true))) return rc;
+        if ((rc = dev_alloc(ctx, &ws.spec, (size_t)G * kFramesPerChunk * kNBins * 2, true))) return rc;
+        if ((rc = dev_alloc(ctx, &ws.gi, rows * (size_t)dm.w_gi, true))) return rc;
+        if ((rc = dev_alloc(ctx, &ws.f2, rows * (size_t)dm.w_f, true))) return rc;
+        if ((rc = dev_alloc(ctx, &ws.f3, rows * (size_t)dm.w_f, true))) return rc;
+        if ((rc = dev_alloc(ctx, &ws.gains, rows * kFeatStride, true))) return rc;
+        ws.w_a1 = dm.w_a1; ws.w_gi = dm.w_gi; ws.w_h = dm.w_h; ws.w_f = dm.w_f;
+        ws.cap_chunks = G;
+        ws.cap_rows = rows;
         ws.generation++;
     }
-    if (need <= ws.cap_chunks && need_rows <= ws.cap_rows && same_widths) return FVAD_OK;
-    hipStreamSynchronize(ctx->stream);
-    const long G = std::max(need, ws.cap_chunks);
-    const size_t rows = std::max(need_rows, ws.cap_rows);
-    free_workspace_nn(ws);
-    int rc;
-    FVAD_HIP(ctx, hipMalloc((void**)&ws.descs, (size_t)G * sizeof(ChunkDesc)));
-    FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_descs, 2 * (size_t)G * sizeof(ChunkDesc), hipHostMallocDefault));
-    for (hipEvent_t& e : ws.desc_ev) if (!e) FVAD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    // zero-filled: padded rows / padded columns are read by the GEMMs and must stay finite
-    if ((rc = dev_alloc(ctx, &ws.feat, rows * kFeatStride, true))) return rc;
-    if ((rc = dev_alloc(ctx, &ws.spec, (size_t)G * kFramesPerChunk * kNBins * 2, true))) return rc;
-    if ((rc = dev_alloc(ctx, &ws.a1, rows * (size_t)dm.w_a1, true))) return rc;
-    if ((rc = dev_alloc(ctx, &ws.gi, rows * (size_t)dm.w_gi, true))) return rc;
-    if ((rc = dev_alloc(ctx, &ws.h1, rows * (size_t)dm.w_h, true))) return rc;
-    if ((rc = dev_alloc(ctx, &ws.h2, rows * (size_t)dm.w_h, true))) return rc;
-    // f16x3 path (baseline dims only): h1 / h2 once more as split f16 fragments, 13 K-steps of 2 KB per 16 rows
-    if (!dm.generic) {
-        if ((rc = dev_alloc(ctx, &ws.hs1, rows * 416, true))) return rc;
-        if ((rc = dev_alloc(ctx, &ws.hs2, rows * 416, true))) return rc;
-    }
-    if ((rc = dev_alloc(ctx, &ws.f2, rows * (size_t)dm.w_f, true))) return rc;
-    if ((rc = dev_alloc(ctx, &ws.f3, rows * (size_t)dm.w_f, true))) return rc;
-    if ((rc = dev_alloc(ctx, &ws.gains, rows * kFeatStride, true))) return rc;
-    ws.w_a1 = dm.w_a1; ws.w_gi = dm.w_gi; ws.w_h = dm.w_h; ws.w_f = dm.w_f;
-    ws.cap_chunks = G;
-    ws.cap_rows = rows;
-    ws.generation++;
+    // ---- buffers only ONE arithmetic (or one kernel option) reads: allocated when a context first runs that way, so an
+    // f32 context does not carry the emulations' fragment buffers (at 49152 chunks: 8.8 GB of f16x3 fragments, 33 GB of
+    // bf16x3 ones) and an f16x3 context does not carry row-major h1 / h2
+    const int math = nn_math_effective(ctx);
+    auto group = [&](std::initializer_list<float**> bufs, std::initializer_list<size_t> widths, size_t& cap_rows) -> int {
+        if (need_rows <= cap_rows) return FVAD_OK;
+        hipStreamSynchronize(ctx->stream);
+        const size_t rows = std::max(need_rows, ws.cap_rows);
+        auto w = widths.begin();
+        for (float** b : bufs) {
+            if (*b) hipFree(*b);
+            *b = nullptr;
+            const int r = dev_alloc(ctx, b, rows * *w++, true);
+            if (r) { cap_rows = 0; return r; }
+        }
+        cap_rows = rows;
+        ws.generation++;
+        return FVAD_OK;
+    };
+    // fc1's output: generic models, and the baseline model only with the fold switched off (gemm_kernel = v3nofold)
+    if (dm.generic || ctx->tune.gemm_kernel.find("nofold") != std::string::npos)
+        if ((rc = group({&ws.a1}, {(size_t)dm.w_a1}, ws.a1_cap_rows))) return rc;
+    // h1 / h2 row-major f32: the f32 kernels and the bf16x3 mode's f32 recurrences
+    if (math != FVAD_NN_MATH_F16X3)
+        if ((rc = group({&ws.h1, &ws.h2}, {(size_t)dm.w_h, (size_t)dm.w_h}, ws.h_cap_rows))) return rc;
+    // f16x3: h1 / h2 as split f16 fragments, 13 K-steps of 2 KB per 16 rows
+    if (math == FVAD_NN_MATH_F16X3)
+        if ((rc = group({&ws.hs1, &ws.hs2}, {416, 416}, ws.hs_cap_rows))) return rc;
+    // bf16x3: h1 / h2 and the fc2 / fc3 outputs as three-piece fragments (13 / 19 K-steps of 3 KB per 16 rows)
+    if (math == FVAD_NN_MATH_BF16X3)
+        if ((rc = group({&ws.b3_hs1, &ws.b3_hs2, &ws.b3_f2, &ws.b3_f3}, {624, 624, 912, 912}, ws.b3_cap_rows))) return rc;
     return FVAD_OK;
 }
 
@@ -630,6 +644,8 @@ static int run_nn_generic(fvad_ctx* ctx, long n_pad, int T, int skip)
     hipStream_t st = ctx->stream;
     const long rows = n_pad * T, rows_out = n_pad * (T - skip);
     if (n_pad % 32) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "batch not padded to 32 sequences");
+    if ((size_t)rows > ws.cap_rows || (size_t)rows > ws.a1_cap_rows || (size_t)rows > ws.h_cap_rows)
+        return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "NSNet2 workspace not allocated for this batch");
     auto S = [](int K) { return (K + 15) / 16; };
     int rc = 0;
     ctx->last_nn_path = "f32: panel_gemm<8> + gru_gen (model dims " + std::to_string(g.F1) + "/" + std::to_string(g.H) + "/" +
@@ -678,6 +694,12 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     const int math = nn_math_effective(ctx);
     const bool h3 = math == FVAD_NN_MATH_F16X3, b3 = math == FVAD_NN_MATH_BF16X3;
     if ((h3 || b3) && n_pad % 128) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "the emulated kernels need a batch padded to 128 sequences");
+    {   // the buffers this arithmetic writes were sized by ensure_workspace for this very launch; a mismatch is a bug, not a reason to write past them
+        const size_t r = (size_t)rows;
+        const bool nofold = force && strstr(force, "nofold");
+        if (r > ws.cap_rows || (h3 ? r > ws.hs_cap_rows : r > ws.h_cap_rows) || (nofold && r > ws.a1_cap_rows))
+            return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "NSNet2 workspace not allocated for this arithmetic / batch");
+    }
     if (b3) {
         // bf16x3: the five dense layers as six bf16 MFMAs per product on exact three-piece splits (kernels_b3.hip), the
         // two recurrences on the f32 matrix cores (gru_rec3, which writes h a second time as three-piece fragments)
@@ -941,8 +963,6 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
                                                kNBins * sizeof(float), t.count * (size_t)kRowsPerChunk, hipMemcpyDeviceToHost, ctx->stream));
         }
         const long n_pad = padded_batch(ctx, n, kRowsPerChunk, kWarmupRows);
-        if ((size_t)n_pad * kRowsPerChunk > ws.cap_rows) // (the padding of a short last launch is not bounded by the first one's)
-            return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "NSNet2 workspace smaller than this launch's padded batch");
         rc = run_nn(ctx, n_pad, kRowsPerChunk, kWarmupRows);
         if (rc) return rc;
         time_begin(ctx, "istft320_ola_up3");
@@ -1017,9 +1037,14 @@ static int apply_option(fvad_ctx* ctx, const std::string& name, const char* valu
     } else if (name == "ws_spin_ticks") {
         if (unset) tn.ws_spin_ticks = def.ws_spin_ticks;
         else { char* end = nullptr; tn.ws_spin_ticks = strtoull(v.c_str(), &end, 10); if (!end || *end) return FVAD_ERR_INVALID_ARGUMENT; }
-    } else if (name == "ws2_variant") { // timing-only builds of gru_ws2_kernel's step (wrong results): tools/ws2_variants.py
+    } else if (name == "ws2_variant") { // shape / timing knobs of the pipelined recurrence (tools/ws2_variants.py, ws2_delay.py)
         long c = 0;
         if (!unset && (!to_long(c) || c < 0 || c >= (1 << 25))) return FVAD_ERR_INVALID_ARGUMENT;
+#if !FVAD_DIAG
+        // the timing-only bits (1, 2, 4, 32: WRONG results) and the step trace (64) exist in the diagnostics build only
+        // (make diag -> libfvad_hip_diag.so); the shipping library has no way to ask for wrong results
+        if (c & (1 | 2 | 4 | 32 | 64)) return FVAD_ERR_INVALID_ARGUMENT;
+#endif
         tn.ws2_variant = (int)c;
     } else if (name == "no_pipeline") { if (!to_bool(tn.no_pipeline)) return FVAD_ERR_INVALID_ARGUMENT; }
     else if (name == "trace_kernels") { if (!to_bool(tn.trace_kernels)) return FVAD_ERR_INVALID_ARGUMENT; }
@@ -1253,6 +1278,10 @@ const char* fvad_ctx_last_nn_path(const fvad_ctx* ctx) { return ctx ? ctx->last_
 // the polled words when the context option ws2_variant has bit 64 set (2 x 1000 shader-clock stamps)
 int fvad_debug_ws_trace(fvad_ctx* ctx, uint32_t* out, int n_words)
 {
+#if !FVAD_DIAG
+    (void)out; (void)n_words;
+    return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "the step trace exists in the diagnostics build only (make -C formula-vad_amd/csrc diag)");
+#endif
     if (!ctx || !out || n_words < 0 || n_words > 2000) return FVAD_ERR_INVALID_ARGUMENT;
     if (!ctx->ws.ws_sync) return FVAD_ERR_INVALID_ARGUMENT;
     hipSetDevice(ctx->device);

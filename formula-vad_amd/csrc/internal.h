@@ -88,6 +88,7 @@ struct Workspace {
     long cap_chunks = 0; // padded chunk capacity (multiple of 768: covers every batch padding)
     bool sync_clean = false; // the polled words of the weight-stationary recurrences are known to be zero (gru_ws2_fallback_kernel left them so)
     size_t cap_rows = 0; // rows (padded sequences x steps per sequence) the NSNet2 buffers hold
+    size_t a1_cap_rows = 0, h_cap_rows = 0, hs_cap_rows = 0; // the same for a1 / h1, h2 / hs1, hs2: allocated for the arithmetic that reads them
     int w_a1 = 0, w_gi = 0, w_h = 0, w_f = 0; // row widths the buffers were allocated for (DeviceModel::w_*)
     // bf16x3 mode only (allocated when a context first runs in it): h1 / h2 and the fc2 / fc3 outputs as three-piece
     // fragments, 13 and 19 K-steps of 3 KB per 16 rows

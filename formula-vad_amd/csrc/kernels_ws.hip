@@ -35,6 +35,14 @@
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostics build (make -C formula-vad_amd/csrc diag -> libfvad_hip_diag.so, for tools/ws2_variants.py and
+// tools/ws2_trace.py): only there do the TIMING-ONLY bits of the context option ws2_variant (1, 2, 4, 32: wrong results) and
+// the step trace (64) exist.  The shipping library compiles them out and fvad_ctx_set_option rejects them.
+#ifndef FVAD_DIAG
+#define FVAD_DIAG 0
+#endif
+#define WS_DIAG(variant_, bits_) (FVAD_DIAG != 0 && ((variant_) & (bits_)))
+
 constexpr int WS_AUX_SC1 = 16;                            // buffer cache-policy bit: sc1 (system-coherent level 1)
 // wait before a step's first poll, in 10 ns ticks (measured by building with other values: 634 -> 571 us for 130 sequences,
 // 1060 -> 1014 for 300, 1210 -> 1170 for 600): gru_ws_kernel; gru_ws2_kernel per row tile of a group on top of a base
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
     for (int i = tid; i < RT * 6 * 64; i += 512) xci[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     if (*s_dead) return;
-    if ((variant & 4) && layer) return;
+    if (WS_DIAG(variant, 4) && layer) return;
     __syncthreads();
 
     // ---- stationary weights of a gate wavefront: gate wg of tile J, all 25 super-steps: R1 (layer 1), or layer 2's
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
                     const unsigned off = (unsigned)((((t & 1) * n_rt + rtg) * GRU_J + J) * 1024);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs2, lane16, off, WS_AUX_SC1);
                     const size_t row = (size_t)rtg * 16 + (lane & 15);
-                    if (!(variant & 2)) *reinterpret_cast<f32x4*>(hout2 + (row * T + t) * GRU_H + 16 * J + 4 * q) = h;
+                    if (!WS_DIAG(variant, 2)) *reinterpret_cast<f32x4*>(hout2 + (row * T + t) * GRU_H + 16 * J + 4 * q) = h;
                 }
             }
         }
@@ -519,14 +527,14 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
             // h1_{t-1} of every peer, and -- before slot t % 4 is overwritten -- h1_{t-4} consumed by every layer-2 peer
             // (layer 2 reads h1_s in its step s: it has published h2_{t-4}, flag t - 3, only after that)
             request_gi(t);
-            if (!wait_for((unsigned)t, (t >= 4 && !(variant & 4)) ? (unsigned)(t - 3) : 0u)) return;
+            if (!wait_for((unsigned)t, (t >= 4 && !WS_DIAG(variant, 4)) ? (unsigned)(t - 3) : 0u)) return;
             product(true, (unsigned)(((t - 1) & 3) * n_rt * GRU_J) * 1024u, false, 0u, t);
             gates_and_publish(t, false);
         }
     } else {
         // step t: gi2_t = W_ih h1_t (first half) beside R2 h2_{t-1} (second half), both from one fetch phase
         for (int t = 0; t < T; ++t) {
-            const bool useA = !(variant & 1);
+            const bool useA = !WS_DIAG(variant, 1);
             if (!wait_for(useA ? (unsigned)(t + 1) : 0u, (unsigned)t)) return;
             product(useA, (unsigned)((t & 3) * n_rt * GRU_J) * 1024u, t >= 1, (unsigned)(((t - 1) & 1) * n_rt * GRU_J) * 1024u, -1);
             gates_and_publish(t, t == 0);
@@ -623,7 +631,7 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     }
     __syncthreads();
     if (*s_dead) return;
-    if ((variant & 4) && layer) return;
+    if (WS_DIAG(variant, 4) && layer) return;
     __syncthreads();
 
     // ---- stationary weights of a gate wavefront: chain kp of gate wg of tile J: R1 (layer 1), or layer 2's W_ih
@@ -817,7 +825,7 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (wave == 12) WS_STAMP(t, 8);
             if (lane == 0) __hip_atomic_store(my_flag, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (layer && !(variant & 2)) { // the row-major copy the next layer (fc2) reads: not part of the hand-off
+            if (layer && !WS_DIAG(variant, 2)) { // the row-major copy the next layer (fc2) reads: not part of the hand-off
                 unsigned l16 = lane16;
                 asm volatile("" : "+v"(l16)); // the lane's offset is formed here, per step: hoisted, it would be spilled
                 const unsigned out_lane = ((l16 >> 4) & 15u) * (unsigned)(T * GRU_H * 4) + (l16 >> 8) * 16u;
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
             // h1_{t-1} of every peer, and -- before slot t % 4 is overwritten -- h1_{t-4} consumed by every layer-2 peer
             // (layer 2 reads h1_s in its step s: it has published h2_{t-4}, flag t - 3, only after that)
             request_gi(t);
-            acquire(14, (unsigned)t, (t >= 4 && !(variant & 4)) ? (unsigned)(t - 3) : 0u, false, (unsigned)(((t - 1) & 3) * n_rt * GRU_J) * 1024u, t, 0, -1, true);
+            acquire(14, (unsigned)t, (t >= 4 && !WS_DIAG(variant, 4)) ? (unsigned)(t - 3) : 0u, false, (unsigned)(((t - 1) & 3) * n_rt * GRU_J) * 1024u, t, 0, -1, true);
             if (!barrier_alive()) return;
             if (wave == 0) WS_STAMP(t, 4);
             if (gate_wave && tile_ok) chain(hbA, 0u);
@@ -850,11 +858,11 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
         // h2 hand-off; then ONE barrier (h2 in LDS, W_ih chains done, helper back), R2 h2_{t-1} on the second half's
         // chains, the barrier that ends the step.  On the chain from one publish to the next: flag, fetch of h2, ONE
         // product phase of 104 MFMAs per SIMD, gates, drain.
-        const bool useA = !(variant & 1);
+        const bool useA = !WS_DIAG(variant, 1);
         if (useA) acquire(15, 1u, 0u, false, 0u, 0, 0, 1, false);
         for (int t = 0; t < T; ++t) {
             const int par = t & 1;
-            if (gate_wave && ws == 0 && useA && !(variant & 32)) {
+            if (gate_wave && ws == 0 && useA && !WS_DIAG(variant, 32)) {
                 if (wait_hA(t + 1)) chain(hbA, (unsigned)par * 6144u);
             }
             if (wave == 0) WS_STAMP(t, 3);
@@ -910,12 +918,14 @@ int fvad_launch_gru_ws2(const float* gi1, const float* R1frag, const float* bR1,
         // up to five row tiles (80 sequences) on 256 CUs: 25 + 25 workgroups per group; six: 13 + 25 (variant 16: always)
         const int nl1 = (G * 2 * GRU_J <= n_cu && !(variant & 16)) ? GRU_J : 13;
         const dim3 grid((unsigned)(G * (nl1 + GRU_J)));
+#if FVAD_DIAG
         if (variant & 64) { // step trace (tools/ws2_trace.py)
             if (hipFuncSetAttribute((const void*)gru_ws2k_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return -2;
             hipLaunchKernelGGL(gru_ws2k_kernel<true>, grid, dim3(1024), lds_k, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
                                hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant, nl1);
             return 0;
         }
+#endif
         if (hipFuncSetAttribute((const void*)gru_ws2k_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return -2;
         hipLaunchKernelGGL(gru_ws2k_kernel<false>, grid, dim3(1024), lds_k, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
                            hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant, nl1);

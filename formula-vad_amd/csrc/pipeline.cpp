@@ -168,6 +168,9 @@ struct fvad_nsnet2 {
     fvad_lane_state* state = nullptr;
     std::vector<float> staged;
     std::vector<float> band, rms;
+    // input rates other than 48 kHz (any multiple of 16 kHz, NSNet2.zig:157-162 / resample.zig:4-7): see fvad_nsnet2_denoise
+    std::vector<float> den48;
+    float last_sample = 0.0f; // NSNet2.zig:33
 };
 
 extern "C" {
@@ -182,16 +185,17 @@ size_t fvad_nsnet2_chunk_size(size_t in_sample_rate)
 int fvad_nsnet2_create(fvad_ctx* ctx, size_t sample_rate, fvad_nsnet2** out)
 {
     if (!ctx || !out) return FVAD_ERR_INVALID_ARGUMENT;
-    // the pipeline only ever runs at 48 kHz (VADPipeline.zig:55-58); the decimating kernels are
-    // built for that ratio
-    if (sample_rate != 48000) return set_err(ctx, FVAD_ERR_INVALID_SAMPLE_RATE, "only 48000 Hz input is supported");
+    // NSNet2.init takes any multiple of 16 kHz (calcDownsampleRate @panics otherwise, resample.zig:4-7); the pipeline
+    // itself only ever runs at 48 kHz (VADPipeline.zig:55-58), which is the ratio the kernels decimate by
+    if (sample_rate == 0 || sample_rate % 16000 != 0) return set_err(ctx, FVAD_ERR_INVALID_SAMPLE_RATE, "the input rate must be a multiple of 16000 Hz");
     if (!ctx->dm.loaded) return set_err(ctx, FVAD_ERR_NO_MODEL, "load the NSNet2 model into the context first");
     auto* d = new (std::nothrow) fvad_nsnet2();
     if (!d) return FVAD_ERR_ALLOC_FAILED;
     d->ctx = ctx; d->sample_rate = sample_rate;
     const int rc = fvad_lane_state_create(ctx, &d->state);
     if (rc) { delete d; return rc; }
-    d->staged.resize(kChunk48);
+    d->staged.assign(kChunk48, 0.0f);
+    if (sample_rate != 48000) d->den48.resize(kChunk48);
     d->band.resize(64);
     d->rms.resize(4);
     *out = d;
@@ -214,19 +218,49 @@ int fvad_nsnet2_denoise(fvad_nsnet2* d, const float* first, size_t n_first, cons
     if (n_first + n_second != chunk) return set_err(ctx, FVAD_ERR_INVALID_INPUT_LENGTH, "samples.len != chunk size"); // NSNet2.zig:166-169
     if (n_result != chunk) return set_err(ctx, FVAD_ERR_INVALID_RESULT_LENGTH, "denoised_result.len != chunk size");   // resample.zig:38-40 (@panic there)
     if ((n_first && !first) || (n_second && !second) || !denoised_result) return FVAD_ERR_INVALID_ARGUMENT;
-    if (n_first) memcpy(d->staged.data(), first, n_first * sizeof(float));
-    if (n_second) memcpy(d->staged.data() + n_first, second, n_second * sizeof(float));
+    const size_t rate = d->sample_rate / 16000; // calcDownsampleRate (resample.zig:4-7)
     fvad_lane lane;
     memset(&lane, 0, sizeof lane);
     lane.pcm = d->staged.data();
-    lane.n_samples = chunk;
+    lane.n_samples = kChunk48;
     lane.state = d->state;
-    lane.denoised = denoised_result;
     lane.band_sum = d->band.data();
     lane.band_sum_capacity = d->band.size();
     lane.chunk_rms = d->rms.data();
     lane.chunk_rms_capacity = d->rms.size();
-    return fvad_engine_run(ctx, &lane, 1, nullptr);
+    if (rate == 3) {
+        if (n_first) memcpy(d->staged.data(), first, n_first * sizeof(float));
+        if (n_second) memcpy(d->staged.data() + n_first, second, n_second * sizeof(float));
+        lane.denoised = denoised_result;
+        return fvad_engine_run(ctx, &lane, 1, nullptr);
+    }
+    // Another input rate.  Everything between the two resamplers runs at 16 kHz whatever the input rate is
+    // (NSNet2.zig:205-236), and both resamplers are index arithmetic: downsampleAudio keeps in[rate i] (resample.zig:9-29),
+    // upsampleAudio puts a 16 kHz sample at out[rate i + rate - 1] and lerps in between (resample.zig:32-79).  The kernels
+    // decimate by 3, so the chunk is presented to them as the 48 kHz chunk with the same decimation -- x48[3 i] = in[rate i],
+    // zeros elsewhere (they would only enter the chunk RMS, which this interface does not report) -- the 16 kHz output is
+    // read back from where the x3 upsampler puts it, y48[3 i + 2], and upsampled by `rate` here with the reference's
+    // arithmetic (std.math.lerp = one fused multiply-add).  A per-chunk streaming call: its cost is the launch chain, not
+    // these 8000 samples.
+    constexpr size_t n16 = (size_t)kFramesPerChunk * kNHop; // 8000
+    for (size_t i = 0; i < n16; ++i) {
+        const size_t src = i * rate;
+        d->staged[3 * i] = src < n_first ? first[src] : second[src - n_first];
+    }
+    lane.denoised = d->den48.data();
+    const int rc = fvad_engine_run(ctx, &lane, 1, nullptr);
+    if (rc) return rc;
+    const size_t n_interp = rate - 1;
+    float prev = d->last_sample;
+    for (size_t i = 0; i < n16; ++i) {
+        const float cur = d->den48[3 * i + 2];
+        for (size_t j = 0; j < n_interp; ++j) // resample.zig:67-79 interpolate
+            denoised_result[i * rate + j] = std::fmaf(cur - prev, (float)(j + 1) / (float)(n_interp + 1), prev);
+        denoised_result[i * rate + n_interp] = cur;
+        prev = cur;
+    }
+    d->last_sample = prev;
+    return FVAD_OK;
 }
 
 } // extern "C"

@@ -171,7 +171,9 @@ void fvad_nsnet2_window(float *window320);
 /* ------------------------------------------------------------------ B2: NSNet2 (src/NSNet2.zig) */
 typedef struct fvad_nsnet2 fvad_nsnet2;
 /* NSNet2.init(allocator, sample_rate, model_path)  NSNet2.zig:35-142.  The model comes from the
- * context.  One object per channel, like BufferedDenoiser.zig:38-41. */
+ * context.  One object per channel, like BufferedDenoiser.zig:38-41.  sample_rate: any multiple of
+ * 16000 Hz like the reference (resample.zig:4-7: calcDownsampleRate), FVAD_ERR_INVALID_SAMPLE_RATE
+ * otherwise; chunks are fvad_nsnet2_chunk_size(sample_rate) = 8000 * (sample_rate / 16000) samples. */
 int fvad_nsnet2_create(fvad_ctx *ctx, size_t sample_rate, fvad_nsnet2 **out);
 void fvad_nsnet2_destroy(fvad_nsnet2 *d);                               /* NSNet2.zig:144-155 */
 size_t fvad_nsnet2_chunk_size(size_t in_sample_rate);                   /* NSNet2.zig:157-159 */

@@ -1,6 +1,7 @@
 """Timeline of a step of gru_ws2k_kernel (context option ws2_variant = 64): shader-clock stamps of the first layer-1 and
 the first layer-2 workgroup of group 0, averaged over the steps of one pass at BASELINE config 3's 82 chunks.
-python tools/ws2_trace.py   (on the GPU box)"""
+python tools/ws2_trace.py   (on the GPU box)
+Needs the diagnostics build: make -C formula-vad_amd/csrc diag, then FVAD_LIB_PATH=formula-vad_amd/libfvad_hip_diag.so python tools/ws2_trace.py"""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

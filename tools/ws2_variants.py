@@ -1,7 +1,8 @@
 """Where a step of the pipelined two-layer recurrence goes: gru_ws2k_kernel (one row tile per group: K split over 16
 wavefronts) and gru_ws2_kernel (8 wavefronts; ws2_variant bit 8 forces it) timed as they are and as timing-only variants
 (context option ws2_variant; the variants give WRONG results) at BASELINE config 3's 82 chunks and at one chunk,
-next to gru_ws (two launches + layer 2's input projection).  Run on the GPU box: python tools/ws2_variants.py"""
+next to gru_ws (two launches + layer 2's input projection).  Run on the GPU box: python tools/ws2_variants.py
+Needs the diagnostics build: make -C formula-vad_amd/csrc diag, then FVAD_LIB_PATH=formula-vad_amd/libfvad_hip_diag.so python tools/ws2_variants.py"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
