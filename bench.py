@@ -777,6 +777,65 @@ def main():
     ctx.close()
 
 
+BATCH_CURVE_POINTS = ((1, 1), (8, 1), (2, 41), (16, 16), (64, 16), (128, 16), (128, 32), (128, 64), (128, 128), (384, 128))
+
+
+def batch_curve(fv, ctx, host_pcm, points=BATCH_CURVE_POINTS, budget_s=0.4):
+    """frames/s of the device-resident path (kernels + D2H of band sums and RMS, f32, denoised audio materialised) against
+    the batch of one call: (lanes, chunks per lane) per point, calls back to back, the mean over enough calls to fill
+    `budget_s`; `nn_path` says which kernels ran.  The smallest batch that sustains 1e7 frames/s is reported beside it."""
+    import ctypes as C
+    L = fv.lib()
+    out = []
+    src = np.concatenate([np.asarray(x, np.float32) for x in host_pcm[:2]])
+    for n_l, n_ch in points:
+        n = n_ch * CHUNK
+        nfr = max(1, n // 1024)
+        lane = np.resize(src, n).astype(np.float32)
+        d_in = ctx.device_alloc(n_l * n * 4)
+        d_den = ctx.device_alloc(n_l * n * 4)
+        d_band = ctx.device_alloc(n_l * nfr * 4)
+        d_rms = ctx.device_alloc(n_l * n_ch * 4)
+        h_band = np.empty((n_l, nfr), np.float32)
+        h_rms = np.empty((n_l, n_ch), np.float32)
+        try:
+            for i in range(n_l):
+                ctx.to_device(d_in + i * n * 4, np.roll(lane, 977 * i))
+
+            def call():
+                fv.check(L.fvad_engine_enqueue_device(ctx.h, C.c_void_p(d_in), n_l, n, n, C.c_void_p(d_den), C.c_void_p(d_band), C.c_void_p(d_rms), None),
+                         "batch curve", ctx.h)
+                fv.check(L.fvad_ctx_copy_to_host(ctx.h, h_band.ctypes.data, C.c_void_p(d_band), h_band.nbytes), "batch curve band", ctx.h)
+                fv.check(L.fvad_ctx_copy_to_host(ctx.h, h_rms.ctypes.data, C.c_void_p(d_rms), h_rms.nbytes), "batch curve rms", ctx.h)
+                ctx.synchronize()
+            call()
+            t0 = time.perf_counter()
+            call()
+            one = time.perf_counter() - t0
+            reps = int(max(3, min(200, budget_s / max(one, 1e-6))))
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                call()
+            dt = (time.perf_counter() - t0) / reps
+            chunks = n_l * n_ch
+            out.append({"chunks": chunks, "lanes": n_l, "frames": chunks * FRAMES_PER_CHUNK, "ms": dt * 1e3,
+                        "frames_per_s": chunks * FRAMES_PER_CHUNK / dt, "nn_path": ctx.last_nn_path(), "calls": reps})
+        finally:
+            for d in (d_in, d_den, d_band, d_rms):
+                ctx.device_free(d)
+    ok = [p["chunks"] for p in out if p["frames_per_s"] >= 1e7]
+    # "sustains": this point and every larger one measured is at or above 1e7
+    sustained = None
+    for p in sorted(out, key=lambda p: -p["chunks"]):
+        if p["frames_per_s"] >= 1e7:
+            sustained = p["chunks"]
+        else:
+            break
+    return {"points": out, "smallest_batch_at_1e7_frames_per_s": min(ok) if ok else None,
+            "smallest_batch_from_which_every_larger_point_is_at_1e7": sustained,
+            "note": "per call of fvad_engine_enqueue_device + D2H of band sums / RMS + synchronize, calls back to back (host-paired wall time)"}
+
+
 def side_measurements(pkg, fv, ctx, torch, dev):
     note = lambda m: print(f"bench.py: side measurement: {m}", file=sys.stderr, flush=True)  # noqa: E731
     """BASELINE config 2 (FFT isolation, 1024 frames and 2^20 frames) and config 3 at its literal
@@ -1001,6 +1060,11 @@ def side_measurements(pkg, fv, ctx, torch, dev):
             del xg, bg, rg, dg
     except Exception as e:
         extra["hipgraph_replay"] = {"error": repr(e)}
+    note("throughput against batch size")
+    try:
+        extra["batch_curve"] = batch_curve(fv, ctx, host_pcm)
+    except Exception as e:
+        extra["batch_curve"] = {"error": repr(e)}
     extra["cfg3_82_chunks_4100_frames"] = {"ms": dt * 1e3, "frames_per_s": 4100 / dt, "ms_as_hipgraph_replay": cfg3_graph_ms,
                                            "nn_path": cfg3_path,
                                            "note": "mean of 100 calls; latency-bound: 55 dependent, exchange-bound steps over only 82 sequences (gru_ws2k_kernel: both GRU layers in one launch, layer 2 a step behind layer 1, recurrent weights stationary in registers across 228 workgroups of 16 wavefronts, h exchanged per step)"}

@@ -192,6 +192,9 @@ int upload_model(fvad_ctx* ctx)
         // gru_ws2_kernel computes layer 2's input projection itself: W_ih2 as stationary fragments like R, Wb gate-major
         pack_gru_r2(w.gru2_w.data(), H, f);
         if ((rc = upload(ctx, m.s_w2frag, f))) return rc;
+        // ... and gru_ws2k_kernel layer 1's as well: the folded W' (gate-major rows, K = 161) in the same fragment order
+        pack_gru_frag(wf.data(), H, 161, f);
+        if ((rc = upload(ctx, m.s_w1frag, f))) return rc;
         if ((rc = upload(ctx, m.s_bw2, std::vector<float>(w.gru2_b.begin(), w.gru2_b.begin() + 3 * H)))) return rc;
         if ((rc = upload(ctx, m.gi1f_b, tile_major_rows(bf.data(), 1)))) return rc;
         // f16x3 form of the same folded layer; its input, the log-power features, is bounded by log10 of the
@@ -304,6 +307,7 @@ static void free_workspace_nn(Workspace& ws)
     if (ws.descs) hipFree(ws.descs);
     if (ws.h_descs) hipHostFree(ws.h_descs);
     ws.descs = nullptr; ws.h_descs = nullptr;
+    ws.descs_mirror.clear();
     ws.cap_chunks = 0;
     ws.cap_rows = 0;
     ws.a1_cap_rows = ws.h_cap_rows = ws.hs_cap_rows = 0;
@@ -437,11 +441,13 @@ static double gru_ws_cost(long n_pad, int n_cu)
 
 // both layers pipelined in one launch (gru_ws2_kernel): 55 steps instead of 2 x 54 and no input-projection GEMM for
 // layer 2; a step costs about what gru_ws's does at the same row tiles per group (fewer groups fit: 26 workgroups each)
-static double gru_ws2_cost_both_layers(long n_pad, int n_cu)
+static double gru_ws2_cost_both_layers(long n_pad, int T, int n_cu, int variant)
 {
     int RT = 0, G = 0;
-    if (!fvad_gru_ws2_shape(n_pad, n_cu, &RT, &G)) return 1e30;
-    return 55.0 * (6.2e3 + 9.4e3 * RT);
+    if (!fvad_gru_ws2_shape(n_pad, n_cu, &RT, &G) || !fvad_gru_ws2_ok(n_pad, T, n_cu, variant)) return 1e30;
+    if (variant & 8) return 55.0 * (6.2e3 + 9.4e3 * RT); // the 8-wavefront kernel (up to 4 row tiles per group)
+    // gru_ws2k (one row tile per group: the hand-off chain alone) / gru_ws2m (row tiles streamed: ~5.5k clocks each, MFMA-paced)
+    return RT == 1 ? 55.0 * 14e3 : 55.0 * (8e3 + 5.5e3 * RT);
 }
 
 static double gru_cost(long n_pad, int waves, int n_cu)
@@ -506,7 +512,7 @@ static long padded_batch(const fvad_ctx* ctx, long n, int T, int skip)
     long c = (n + 31) / 32 * 32;
     if ((c * T) % 64 != 0 || (c * (T - skip)) % 64 != 0) c = (n + 63) / 64 * 64;
     if (!tn.reproducible && (!force || force[1] == '5' || force[1] == '6') && tn.gemm_kernel.empty() && c < 2048 &&
-        std::min(gru_ws_cost(c, cu), gru_ws2_cost_both_layers(c, cu) / 108.0) < std::min(gru_cost(b, 0, cu), gru_cost(b, 4, cu)))
+        std::min(gru_ws_cost(c, cu), gru_ws2_cost_both_layers(c, T, cu, tn.ws2_variant) / 108.0) < std::min(gru_cost(b, 0, cu), gru_cost(b, 4, cu)))
         return c;
     // the persistent GEMM takes 256-row panels of T n and of (T - skip) n rows: any multiple of 128 sequences at the
     // engine's T = 54 / 50, a multiple of 256 for an odd sequence length (fvad_nsnet2_forward takes any); `reproducible`
@@ -519,13 +525,13 @@ static long padded_batch(const fvad_ctx* ctx, long n, int T, int skip)
     return repro(cost_b <= cost_a ? b : a);
 }
 
-static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, bool allow_v3)
+static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, int T, bool allow_v3)
 {
     const char* force = ctx->tune.gru_kernel.empty() ? nullptr : ctx->tune.gru_kernel.c_str(); // "v3w12", "v3w8", "v3w4", "v4w8" (gru_lat), "v5w0" (gru_ws)
     if (force) {
         GruChoice c{force[1] - '0', atoi(force + 3)};
         if (c.version == 3 && !allow_v3) c = {4, 8}; // gru_rec3 needs the folded biases of the large-batch path
-        if (c.version == 6 && allow_v3) c = {5, 0};  // the pipelined kernel belongs to the small-batch sequence
+        if (c.version == 6 && (allow_v3 || !fvad_gru_ws2_ok(n_pad, T, ctx->n_cu, ctx->tune.ws2_variant))) c = {5, 0}; // the pipelined kernels belong to the small-batch sequence, up to 16 row tiles per group
         return c;
     }
     const int cu = ctx->n_cu;
@@ -542,7 +548,7 @@ static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, bool allow_v3)
     if (n_pad % 192 == 0 && gru_cost(n_pad, 12, cu) < gru_cost(n_pad, best, cu)) best = 12;
     if (!allow_v3) { // small-batch GEMM path only
         // per layer: 54 steps of gru_ws (+ layer 2's share of its input-projection GEMM, ~1.5k cycles a step)
-        const double ws = 54.0 * gru_ws_cost(n_pad, cu), ws2 = gru_ws2_cost_both_layers(n_pad, cu);
+        const double ws = 54.0 * gru_ws_cost(n_pad, cu), ws2 = gru_ws2_cost_both_layers(n_pad, T, cu, ctx->tune.ws2_variant);
         const double other = 54.0 * gru_cost(n_pad, best, cu);
         if (ws2 < 2.0 * std::min(ws, other) + 54.0 * 1.5e3) return {6, 0};
         if (ws < other) return {5, 0};
@@ -786,7 +792,7 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
             return FVAD_OK;
         }
         const bool fold = !(force && strstr(force, "nofold"));
-        const GruChoice gc = pick_gru(ctx, n_pad, fold);
+        const GruChoice gc = pick_gru(ctx, n_pad, T, fold);
         ctx->last_nn_path = std::string("f32: panel_gemm3") + (fold ? " (fc1 folded)" : "") + " + " +
                             (gc.version == 3 ? "gru_rec3<" + std::to_string(gc.waves) + ">" : gc.version == 5 ? std::string("gru_ws") : std::string("gru_lat"));
         if (gc.version == 5 && (rc = prepare_gru_ws(ctx, n_pad))) return rc; // only when forced: tuning / tests
@@ -831,24 +837,30 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     // family; gi rows are tile-major
     const int fam = rows > 2048 ? 1 : 0, snt = fam ? 4 : 2;
     const int nb_gi = (75 + snt - 1) / snt, nb_fc = (38 + snt - 1) / snt, nb_fc4 = (11 + snt - 1) / snt;
-    time_begin(ctx, "gru1_in_gemm_fc1folded");
-    rc |= fvad_launch_panel_gemm_s(ws.feat, kFeatStride, m.s_gi1f_w[fam].p, m.gi1f_b.p, ws.gi, 1200, rows, snt, nb_gi, 11, FVAD_ACT_NONE, 0, 0, st, 75);
-    time_end(ctx);
-    const GruChoice gcs = pick_gru(ctx, n_pad, false);
+    const GruChoice gcs = pick_gru(ctx, n_pad, T, false);
+    // one row tile per group (up to 96 sequences: BASELINE config 3's 82 chunks, every live push): the pipelined kernel computes
+    // layer 1's input projection too, and the GEMM launch in front of it disappears
+    const bool gi1_in_kernel = gcs.version == 6 && fvad_gru_ws2_gi1_in_kernel(n_pad, T, ctx->n_cu, tn.ws2_variant);
+    if (!gi1_in_kernel) {
+        time_begin(ctx, "gru1_in_gemm_fc1folded");
+        rc |= fvad_launch_panel_gemm_s(ws.feat, kFeatStride, m.s_gi1f_w[fam].p, m.gi1f_b.p, ws.gi, 1200, rows, snt, nb_gi, 11, FVAD_ACT_NONE, 0, 0, st, 75);
+        time_end(ctx);
+    }
     if (gcs.version >= 5 && (rc = prepare_gru_ws(ctx, n_pad))) return rc;
-    ctx->last_nn_path = std::string("f32: panel_gemm (fc1 folded) + ") + (gcs.version == 6 ? "gru_ws2 (layers pipelined)" : gcs.version == 5 ? "gru_ws" : "gru_lat");
+    ctx->last_nn_path = std::string("f32: panel_gemm (fc1 folded) + ") + (gcs.version == 6 ? fvad_gru_ws2_kernel_name(n_pad, T, ctx->n_cu, tn.ws2_variant) :
+                        gcs.version == 5 ? "gru_ws" : "gru_lat");
     if (gcs.version == 6) {
         // both GRU layers in one launch, layer 2 a step behind layer 1, its input projection computed inside
         unsigned* err = ws.ws_sync + 512;
         time_begin(ctx, "gru12_rec_pipelined");
         rc |= ws_serialised(ctx, [&] {
-            return fvad_launch_gru_ws2(ws.gi, m.r1v2.p, m.br1.p, m.s_w2frag.p, m.s_bw2.p, m.r2v2.p, m.br2.p, ws.h2, ws.hx, ws.ws_sync, err,
-                                       n_pad, T, ctx->n_cu, tn.ws_spin_ticks, tn.ws2_variant, st);
+            return fvad_launch_gru_ws2(ws.gi, ws.feat, m.s_w1frag.p, m.gi1f_b.p, m.r1v2.p, m.br1.p, m.s_w2frag.p, m.s_bw2.p, m.r2v2.p, m.br2.p, ws.h2,
+                                       ws.hx, ws.ws_sync, err, n_pad, T, ctx->n_cu, tn.ws_spin_ticks, tn.ws2_variant, st);
         });
         // one launch behind it: the whole fallback (layer 1, layer 2's input projection, layer 2 -- run only if the
         // error word was raised), the pass count, and the reset of the polled words for the next pass
-        rc |= fvad_launch_gru_ws2_fallback(ws.gi, m.r1v2.p, m.br1.p, m.s_gi2_w[0].p, m.gi2_btm.p, m.r2v2.p, m.br2.p, ws.h1, ws.h2, n_pad, T,
-                                           ws.ws_sync, ws.ws_fallbacks, st);
+        rc |= fvad_launch_gru_ws2_fallback(ws.gi, gi1_in_kernel ? ws.feat : nullptr, m.s_gi1f_w[0].p, m.gi1f_b.p, m.r1v2.p, m.br1.p, m.s_gi2_w[0].p,
+                                           m.gi2_btm.p, m.r2v2.p, m.br2.p, ws.h1, ws.h2, n_pad, T, ws.ws_sync, ws.ws_fallbacks, st);
         {   // the launch above leaves the words zeroed -- once it has RUN: a sequence under capture has not
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(st, &cap);
@@ -939,11 +951,12 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
         }
         const ChunkDesc* dd = ws.descs;
         if (capture_descs) { dd = capture_dev + capture_off; capture_off += (size_t)n; }
-        else {
+        else if (ws.descs_mirror.size() < (size_t)n || memcmp(ws.descs_mirror.data(), hd, (size_t)n * sizeof(ChunkDesc)) != 0) {
             // the stream orders this copy after the previous launch's kernels
             FVAD_HIP(ctx, hipMemcpyAsync(ws.descs, hd, (size_t)n * sizeof(ChunkDesc), hipMemcpyHostToDevice, ctx->stream));
             FVAD_HIP(ctx, hipEventRecord(ws.desc_ev[slot], ctx->stream));
-        }
+            ws.descs_mirror.assign(hd, hd + n);
+        } // else: the device table already holds exactly these descriptors (the previous launch's: a steady-state loop)
         time_begin(ctx, "stft320_logpow");
         // a launch of a few chunks leaves most CUs idle and a chunk's frames are a latency chain on one workgroup:
         // cut them over 2 or 3 workgroups per chunk (the same instructions per frame: the same bits)
@@ -1191,7 +1204,7 @@ void fvad_ctx_destroy(fvad_ctx* ctx)
                        &m.gi1f_h3, &m.gi2_h3, &m.fc2_h3, &m.fc3_h3, &m.fc4_h3, &m.fc2h3_b, &m.fc3h3_b, &m.fc4h3_b, &m.r1_h3, &m.r2_h3};
     for (DevBuf* b : gbufs) if (b->p) hipFree(b->p);
     DevBuf* bufs[] = {&m.fc1_w, &m.fc1_b, &m.s_gi1f_w[0], &m.s_gi1f_w[1], &m.s_gi2_w[0], &m.s_gi2_w[1], &m.s_fc2_w[0], &m.s_fc2_w[1],
-                      &m.s_fc3_w[0], &m.s_fc3_w[1], &m.s_fc4_w[0], &m.s_fc4_w[1], &m.s_fc4_b, &m.s_w2frag, &m.s_bw2, &m.br1, &m.br2,
+                      &m.s_fc3_w[0], &m.s_fc3_w[1], &m.s_fc4_w[0], &m.s_fc4_w[1], &m.s_fc4_b, &m.s_w2frag, &m.s_bw2, &m.s_w1frag, &m.br1, &m.br2,
                       &m.fc2_b, &m.fc3_b, &m.fc4_w, &m.fc4_b, &m.r1v2, &m.r2v2, &m.gi1f_w, &m.gi1f_b, &m.gi1v2_w, &m.gi2v2_w, &m.gi1f_bzr, &m.gi2_bzr, &m.gi1_btm, &m.gi2_btm, &m.fc2v3_w, &m.fc3v3_w, &m.fc2v3_b, &m.fc3v3_b};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (ctx->d_tables) hipFree(ctx->d_tables);
@@ -1683,6 +1696,8 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
         ws.generation++;
     }
     if (n_scratch) FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
+    ws.carries_clean = 0;      // this call's launches write them
+    ws.jobs_mirror.clear();    // ... and the K4 job table
 
     // the host-side lane state (remainder length, current carry, counters) is committed only if the whole call
     // succeeds: a caller that retries after an error must not feed the same audio to an advanced state
@@ -1937,6 +1952,7 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
         ws.carries = nullptr; ws.carries_cap = 0;
         FVAD_HIP(ctx, hipMalloc((void**)&ws.carries, n_scratch * sizeof(LaneCarry)));
         ws.carries_cap = n_scratch * sizeof(LaneCarry);
+        ws.carries_clean = 0;
         ws.generation++;
     }
     if (ws.fft_jobs_cap < n_lanes) {
@@ -1947,6 +1963,7 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
         FVAD_HIP(ctx, hipMalloc((void**)&ws.fft_jobs, n_lanes * sizeof(VadFftJob)));
         FVAD_HIP(ctx, hipHostMalloc((void**)&ws.h_fft_jobs, 2 * n_lanes * sizeof(VadFftJob), hipHostMallocDefault));
         ws.fft_jobs_cap = n_lanes;
+        ws.jobs_mirror.clear();
         ws.generation++;
     }
 
@@ -1955,7 +1972,16 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
         // A captured sequence holds kernel nodes only: memset / memcpy nodes replayed after direct launches on
         // the same stream were observed to run with stale parameters (ROCm 7.2), so the carries are zeroed
         // on the stream in front of every hipGraphLaunch and the tables are graph-private device copies.
-        if (!capture_descs) FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
+        // (direct calls: a lane's first chunk reads carry 2 l, its last one writes 2 l + 1; only a call of several launches
+        // flips them and writes an even one -- after a single-launch call the carries that are read are still the zeros they were)
+        if (!capture_descs && ws.carries_clean < n_scratch) {
+            FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
+            ws.carries_clean = n_scratch;
+        }
+        {
+            long maxc = opts.max_chunks_per_launch > 0 ? opts.max_chunks_per_launch : ctx->tune.max_chunks;
+            if ((long)(n_lanes * n_chunks) > maxc) ws.carries_clean = 0; // several launches: the even carries get written
+        }
         std::vector<LaneJob> jobs(n_lanes);
         for (size_t l = 0; l < n_lanes; ++l) {
             jobs[l].d_in = d_pcm ? d_pcm + l * lane_stride : nullptr;
@@ -1972,7 +1998,10 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
         if (r) return r;
         // one K4 launch for every lane's frames
         for (size_t l = 0; l < n_lanes; ++l) h_jobs[l] = {den + l * n_den, d_band_sum + l * n_frames, nullptr, (long)n_frames};
-        if (!capture_descs) FVAD_HIP(ctx, hipMemcpyAsync(d_jobs, h_jobs, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice, st));
+        if (!capture_descs && (ws.jobs_mirror.size() != n_lanes || memcmp(ws.jobs_mirror.data(), h_jobs, n_lanes * sizeof(VadFftJob)) != 0)) {
+            FVAD_HIP(ctx, hipMemcpyAsync(d_jobs, h_jobs, n_lanes * sizeof(VadFftJob), hipMemcpyHostToDevice, st));
+            ws.jobs_mirror.assign(h_jobs, h_jobs + n_lanes);
+        }
         time_begin(ctx, "fft1024_bandsum");
         fvad_launch_vadfft_jobs(d_jobs, (int)n_lanes, (long)n_frames, plan, opts.min_bin, opts.max_bin, st);
         time_end(ctx);
@@ -2035,6 +2064,7 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
             gc.valid = true;
         }
         FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
+        ws.carries_clean = 0; // (a replayed sequence of several launches writes the even carries)
         // the replayed sequence may hold a pass of gru_ws_kernel (launches of 385..~1900 chunks), which leaves the polled
         // words counted up: whatever a direct call knew about them is void after a replay
         ws.sync_clean = false;

@@ -95,9 +95,11 @@ int fvad_launch_gru_rec_h3(const float* gi, const float* Rfrag, const float* bR,
 // guard != nullptr: the kernel returns at once unless *guard != 0 (fallback behind fvad_launch_gru_ws)
 // tile_major: gi rows are [25 J][3 gates][16] (large-batch GEMM) instead of [3 gates][400] (small-batch GEMM)
 // the pipelined recurrence's whole fallback + pass count + reset of the polled words in one launch (kernels_nn.hip)
-int fvad_launch_gru_ws2_fallback(float* gi, const float* R1frag, const float* bR1, const float* W2frag_nt2, const float* bW2,
-                                 const float* R2frag, const float* bR2, float* h1, float* h2, long n_seq_pad, int T,
-                                 unsigned* sync, unsigned long long* fallbacks, hipStream_t stream);
+// feat != nullptr: gi does not hold layer 1's input projection yet (the pipelined kernel computed it in-kernel): the fallback
+// computes it first from feat, W1frag_nt2 (the small-batch GEMM's 2-tile column blocks of W') and bG1 (tile-major)
+int fvad_launch_gru_ws2_fallback(float* gi, const float* feat, const float* W1frag_nt2, const float* bG1, const float* R1frag, const float* bR1,
+                                 const float* W2frag_nt2, const float* bW2, const float* R2frag, const float* bR2, float* h1, float* h2,
+                                 long n_seq_pad, int T, unsigned* sync, unsigned long long* fallbacks, hipStream_t stream);
 int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, float* hout,
                         long n_seq_pad, int T, const unsigned* guard, int tile_major, hipStream_t stream);
 // small batches: recurrent weights stationary in registers across 25 x G workgroups, h exchanged per step
@@ -119,9 +121,18 @@ int fvad_launch_gru_ws(const float* gi, const float* R2frag, const float* bR, fl
 // hx: fvad_gru_ws2_exchange_floats floats; flags: 512 zeroed words; returns -1 when the batch does not fit
 bool fvad_gru_ws2_shape(long n_seq_pad, int n_cu, int* RT, int* G);
 size_t fvad_gru_ws2_exchange_floats(long n_seq_pad);
-int fvad_launch_gru_ws2(const float* gi1, const float* R1frag, const float* bR1, const float* W2frag, const float* bW2,
-                        const float* R2frag, const float* bR2, float* hout2, float* hx, unsigned* flags, unsigned* err,
-                        long n_seq_pad, int T, int n_cu, unsigned long long spin_ticks, int variant, hipStream_t stream);
+// One row tile per group (up to 96 sequences): the 16-wavefront kernel, which computes layer 1's input projection itself from
+// feat (rows of kFeatStride floats), W1frag = pack_gru_frag of W' = W_ih W_fc1 and bG1 = its bias, tile-major -- gi1 is not
+// read and the GEMM in front is not needed (fvad_gru_ws2_gi1_in_kernel says which case a launch is)
+bool fvad_gru_ws2_gi1_in_kernel(long n_seq_pad, int T, int n_cu, int variant);
+// whether any of the pipelined kernels takes a launch of this shape (gru_ws2k: one row tile per group; gru_ws2m: 2..16 row tiles
+// per group; gru_ws2: the 8-wavefront form, up to 4, which ws2_variant bit 8 forces) and the name of the one that does
+bool fvad_gru_ws2_ok(long n_seq_pad, int T, int n_cu, int variant);
+const char* fvad_gru_ws2_kernel_name(long n_seq_pad, int T, int n_cu, int variant);
+int fvad_launch_gru_ws2(const float* gi1, const float* feat, const float* W1frag, const float* bG1, const float* R1frag, const float* bR1,
+                        const float* W2frag, const float* bW2, const float* R2frag, const float* bR2, float* hout2, float* hx,
+                        unsigned* flags, unsigned* err, long n_seq_pad, int T, int n_cu, unsigned long long spin_ticks, int variant,
+                        hipStream_t stream);
 int fvad_launch_gru_gen(const float* gi, int gi_ld, const float* R2frag, const float* bR, float* hout, int h_ld,
                         long n_seq_pad, int T, int J, hipStream_t stream);
 int fvad_launch_gru_rec3(const float* gi, const float* R2frag, const float* bR, float* hout,

@@ -994,7 +994,8 @@ __global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __rest
 // (after it has read the error word), and the last one adds the pass to the fallback counter and zeroes the polled
 // words for the next pass, so the sequence needs no separate reset launch in front and no count launch behind.
 //   sync: [0, 512) the two layers' flags, [512] the error word, [513] the ticket counter.
-__global__ __launch_bounds__(512) void gru_ws2_fallback_kernel(float* gi, const float* __restrict__ R1frag, const float* __restrict__ bR1,
+__global__ __launch_bounds__(512) void gru_ws2_fallback_kernel(float* gi, const float* __restrict__ feat, const float* __restrict__ W1frag_nt2,
+                                                               const float* __restrict__ bG1, const float* __restrict__ R1frag, const float* __restrict__ bR1,
                                                                const float* __restrict__ W2frag_nt2, const float* __restrict__ bW2,
                                                                const float* __restrict__ R2frag, const float* __restrict__ bR2,
                                                                float* h1, float* h2, int T, unsigned* sync,
@@ -1004,11 +1005,36 @@ __global__ __launch_bounds__(512) void gru_ws2_fallback_kernel(float* gi, const 
     __shared__ int s_last;
     const bool run = *(const volatile unsigned*)(sync + 512) != 0u; // uniform: nobody writes the word while this launch runs
     if (run) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), m = lane & 15, q = lane >> 4;
+        const size_t row0 = ((size_t)blockIdx.x * 16 + m) * T;
+        if (feat) {
+            // the pipelined kernel computed layer 1's input projection itself (gru_ws2k_kernel): gi1 = W' x + b' for this
+            // workgroup's rows first, the instruction sequence of the GEMM that otherwise runs in front (K = 176: 11 super-steps)
+            constexpr int XS = kFeatStride / 16;
+            for (int t = 0; t < T; ++t) {
+                const float* a_ptr = feat + (row0 + t) * kFeatStride + 4 * q;
+                float* c_ptr = gi + (row0 + t) * (3 * GRU_H) + 4 * q;
+                for (int u = wave; u < 3 * GRU_J; u += 8) {
+                    const f32x4* wf = reinterpret_cast<const f32x4*>(W1frag_nt2) + ((size_t)(u >> 1) * XS * 2 + (u & 1)) * 64 + lane;
+                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < XS; ++s) {
+                        const f32x4 w4 = wf[(size_t)s * 2 * 64];
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(a_ptr + 16 * s);
+                        acc = MFMA16(w4.x, a.x, acc);
+                        acc = MFMA16(w4.y, a.y, acc);
+                        acc = MFMA16(w4.z, a.z, acc);
+                        acc = MFMA16(w4.w, a.w, acc);
+                    }
+                    *reinterpret_cast<f32x4*>(c_ptr + 16 * u) = acc + *reinterpret_cast<const f32x4*>(bG1 + 16 * u + 4 * q);
+                }
+            }
+            __threadfence();
+            __syncthreads();
+        }
         gru_lat_body<8>(gi, R1frag, bR1, h1, T, 48, 16, hs);
         __threadfence(); // h1 rows written by the other wavefronts of this workgroup
         __syncthreads();
-        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), m = lane & 15, q = lane >> 4;
-        const size_t row0 = ((size_t)blockIdx.x * 16 + m) * T;
         for (int t = 0; t < T; ++t) {
             const float* a_ptr = h1 + (row0 + t) * GRU_H + 4 * q;
             float* c_ptr = gi + (row0 + t) * (3 * GRU_H) + 4 * q;
@@ -1043,12 +1069,12 @@ __global__ __launch_bounds__(512) void gru_ws2_fallback_kernel(float* gi, const 
     }
 }
 
-int fvad_launch_gru_ws2_fallback(float* gi, const float* R1frag, const float* bR1, const float* W2frag_nt2, const float* bW2,
-                                 const float* R2frag, const float* bR2, float* h1, float* h2, long n_seq_pad, int T,
-                                 unsigned* sync, unsigned long long* fallbacks, hipStream_t stream)
+int fvad_launch_gru_ws2_fallback(float* gi, const float* feat, const float* W1frag_nt2, const float* bG1, const float* R1frag, const float* bR1,
+                                 const float* W2frag_nt2, const float* bW2, const float* R2frag, const float* bR2, float* h1, float* h2,
+                                 long n_seq_pad, int T, unsigned* sync, unsigned long long* fallbacks, hipStream_t stream)
 {
     if (n_seq_pad <= 0 || n_seq_pad % 16) return -1;
-    hipLaunchKernelGGL(gru_ws2_fallback_kernel, dim3((unsigned)(n_seq_pad / 16)), dim3(512), 0, stream, gi, R1frag, bR1, W2frag_nt2, bW2,
+    hipLaunchKernelGGL(gru_ws2_fallback_kernel, dim3((unsigned)(n_seq_pad / 16)), dim3(512), 0, stream, gi, feat, W1frag_nt2, bG1, R1frag, bR1, W2frag_nt2, bW2,
                        R2frag, bR2, h1, h2, T, sync, fallbacks);
     return 0;
 }

@@ -562,8 +562,12 @@ constexpr unsigned WS2K_WAIT_L1 = 150, WS2K_WAIT_L2 = 270, WS2K_WAIT_L1_ONE = 22
 // wait: it is on the critical path then); none in groups of 25 + 25, where it costs a one-chunk push 10-25 us
 constexpr unsigned WS2K_WAIT_H1 = 120;
 
-template <bool TRACE>
-__global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict__ gi1, const float* __restrict__ R1frag,
+// GI1K: layer 1 computes its input projection in the kernel (feat = the features, rows of kFeatStride floats); otherwise
+// `feat` is gi1, the output of the GEMM launched in front (tile-major rows of 1200), as in round 3 -- kept for A/B runs on
+// one box (context option ws2_variant bit 1024) and as the form the 8-wavefront kernel still uses
+template <bool TRACE, bool GI1K>
+__global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict__ feat, const float* __restrict__ W1frag,
+                                                        const float* __restrict__ bG1, const float* __restrict__ R1frag,
                                                         const float* __restrict__ bR1, const float* __restrict__ W2frag,
                                                         const float* __restrict__ bW2, const float* __restrict__ R2frag,
                                                         const float* __restrict__ bR2, float* __restrict__ hout2,
@@ -571,24 +575,31 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
                                                         unsigned* err, int T, int n_rt, unsigned long long spin_ticks,
                                                         int variant, int nl1)
 {
-    // dynamic LDS, in float4s: hbuf[2][25][64] (the row tile's h1 and h2); per tile slot: xch[3 gates][2 chains][64]
-    // recurrent partial products, xci[3][2][64] layer 2's input projection, hpv[64] the previous h of the tile;
-    // btab[2 tile slots][6][4] the biases (Rb z, r, n; layer 2's Wb z, r, n) as the four float4s a lane quartet needs
+    // dynamic LDS, in float4s: hbA[25][64], hbB[25][64] (the row tile's h1 and h2; layer 1 has no h2 and keeps the step's
+    // input rows x_t there: two parities of 11 blocks); per tile slot: xch[3 gates][2 chains][64] recurrent partial products;
+    // xci[2 parities][12 blocks][64]: the input projection of the step (layer 1: W' x_t for its two tiles; layer 2: W_ih h1,
+    // 6 blocks per parity); hpv[64] the previous h of the tile; btab[2 tile slots][6][4] the biases (Rb z, r, n; the input
+    // projection's bias z, r, n) as the four float4s a lane quartet needs; words; the step trace; wx[2 tiles][3 gates][11][64]:
+    // layer 1's stationary input-projection fragments (W' = W_ih W_fc1, K = 176)
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int O_HBB = GRU_J * 64, O_XCH = 2 * GRU_J * 64, O_XCI = O_XCH + 12 * 64, O_HPV = O_XCI + 24 * 64, O_BTAB = O_HPV + 2 * 64,
+                  O_WORDS = O_BTAB + 48, O_TRACE = O_WORDS + 1, O_WX = O_WORDS + 176;
     f32x4* hbA = reinterpret_cast<f32x4*>(smem);
-    f32x4* hbB = hbA + GRU_J * 64;
-    f32x4* xch = hbB + GRU_J * 64;
-    f32x4* xci = xch + 12 * 64;
-    f32x4* hpv = xci + 12 * 64;
-    f32x4* btab = hpv + 2 * 64;
+    f32x4* hbB = hbA + O_HBB;
+    f32x4* xch = hbA + O_XCH;
+    f32x4* xci = hbA + O_XCI;
+    f32x4* hpv = hbA + O_HPV;
+    f32x4* btab = hbA + O_BTAB;
+    f32x4* wx = hbA + O_WX;
     // (LDS-space pointers, not generic ones, for everything that is not plain array indexing: the flat -> LDS casts of
     // generic pointers made the backend emit an illegal instruction in some variants of this kernel, ROCm 7.2)
     __attribute__((address_space(3))) char* lds3 = (__attribute__((address_space(3))) char*)smem; // LDS-DMA targets, words, trace
-    __attribute__((address_space(3))) volatile int* s_dead = (__attribute__((address_space(3))) volatile int*)(lds3 + (2 * GRU_J * 64 + 24 * 64 + 2 * 64 + 48) * 16);
+    __attribute__((address_space(3))) volatile int* s_dead = (__attribute__((address_space(3))) volatile int*)(lds3 + O_WORDS * 16);
     __attribute__((address_space(3))) volatile int* hA_ready = s_dead + 1; // layer 2: h1 of steps < *hA_ready is in hbA (set by wavefront 15)
+    __attribute__((address_space(3))) volatile int* g_done = s_dead + 2;   // layer 1: [tile slot] steps whose gate math is done (set by the tile's helper)
     // variant & 64 (tools/ws2_trace.py): the first layer-1 and the first layer-2 workgroup of group 0 keep shader-clock
     // stamps of every step's events in LDS and copy them behind the polled words (flags1 + 520 ...) when they are done
-    __attribute__((address_space(3))) unsigned* trl = (__attribute__((address_space(3))) unsigned*)(lds3 + (2 * GRU_J * 64 + 24 * 64 + 2 * 64 + 49) * 16);
+    __attribute__((address_space(3))) unsigned* trl = (__attribute__((address_space(3))) unsigned*)(lds3 + O_TRACE * 16);
 #define WS_STAMP(t_, k_) do { if (TRACE && tr && lane == 0) trl[(t_) * 12 + (k_)] = (unsigned)clock64(); } while (0)
 
     const int tid = threadIdx.x;
@@ -616,15 +627,21 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     const int tslot = layer ? 0 : ws;
     // who does the gate math, fetches gi and publishes: layer 1: wavefronts 12 / 13 for the two tiles; layer 2: 12
     const bool helper = layer ? wave == 12 : ((wave == 12 || wave == 13) && tile_ok);
+    // Everything on a step's critical path outside the product phase -- gate math, drain, flag, poll, fetch -- is done by
+    // wavefronts 12..15, the youngest on their SIMDs: without priority their instructions queue behind whatever the three gate
+    // wavefronts there issue (the input projections run in the hand-off's shadow, i.e. exactly then)
+    if (wave >= 12) __builtin_amdgcn_s_setprio(3);
 
-    if (tid == 0) { *s_dead = (int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *hA_ready = 0; }
+    if (tid == 0) { *s_dead = (int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *hA_ready = 0; g_done[0] = 0; g_done[1] = 0; }
     if (tid < 2 * 64) hpv[tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (tid >= 128 && tid < 128 + 48) { // biases of the workgroup's tile(s): read from LDS in the gate math
         const int e = tid - 128, sl = e / 24, k = (e % 24) / 4, qq = e & 3;
         const int Jb = (layer || one) ? pair : 2 * pair + sl;
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (Jb < GRU_J && (layer ? sl == 0 : (k < 3 && (!one || sl == 0)))) {
-            const float* src = (k < 3 ? (layer ? bR2 : bR1) : bW2) + (k % 3) * GRU_H + 16 * Jb + 4 * qq;
+        if (Jb < GRU_J && (layer ? sl == 0 : ((GI1K || k < 3) && (!one || sl == 0)))) {
+            // Rb and layer 2's Wb are gate-major [3][400]; layer 1's folded bias b' = W_ih b_fc1 + Wb comes tile-major [25][3][16]
+            const float* src = k < 3 ? (layer ? bR2 : bR1) + (k % 3) * GRU_H + 16 * Jb + 4 * qq
+                                     : (layer ? bW2 + (k % 3) * GRU_H + 16 * Jb + 4 * qq : bG1 + 48 * Jb + 16 * (k % 3) + 4 * qq);
             v = *reinterpret_cast<const f32x4*>(src);
         }
         btab[e] = v;
@@ -648,21 +665,40 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
             w[i] = (gate && S < GRU_J) ? src[(S < GRU_J ? S : 0) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
-    // layer 1's gi of the step: requested BEFORE the wait
+    // Layer 1 computes its own input projection gi1_t = W' x_t + b' (W' = W_ih W_fc1: fc1 folded, K = 161 -> 11 super-steps),
+    // like layer 2 does with W_ih h1: the fragments of its tile(s) are stationary in LDS (wx), the step's input rows -- the
+    // log-power features of the group's 16 sequences, 11 KB -- are fetched a step ahead by wavefront 15 straight into LDS, and
+    // the gate wavefronts run the 20-24 MFMAs of a chain in the shadow of the h1 hand-off, where they have nothing else to do.
     // (32-bit lane offsets into buffer resources, the step as the scalar offset: the 128-VGPR budget has no room for
     // 64-bit per-lane addresses)
-    const auto rs_gi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gi1), 0, n_rt * 16 * T * (3 * GRU_H) * 4, 0x00020000);
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feat), 0, n_rt * 16 * T * kFeatStride * 4, 0x00020000);
     const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(hout2, 0, n_rt * 16 * T * GRU_H * 4, 0x00020000);
-    const unsigned gi_lane = (unsigned)(((g * 16 + (lane & 15)) * T) * (3 * GRU_H) + 48 * Jc + 4 * q) * 4u; // tile-major rows: [25 J][3 gates][16]
     const unsigned out_base = (unsigned)((g * 16 * T) * GRU_H + 16 * Jc) * 4u;
+    // (not GI1K) layer 1's gi of the step comes from the GEMM in front: requested BEFORE the wait
+    const auto rs_gi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feat), 0, n_rt * 16 * T * (3 * GRU_H) * 4, 0x00020000);
+    const unsigned gi_lane = (unsigned)(((g * 16 + (lane & 15)) * T) * (3 * GRU_H) + 48 * Jc + 4 * q) * 4u; // tile-major rows: [25 J][3 gates][16]
     f32x4 gpre[3];
     auto request_gi = [&](int t) {
-        if (layer == 0 && helper) {
+        if (!GI1K && layer == 0 && helper) {
             const unsigned so = (unsigned)t * (3 * GRU_H * 4);
             gpre[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gi, gi_lane, so, 0));
             gpre[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gi, gi_lane + 64u, so, 0));
             gpre[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gi, gi_lane + 128u, so, 0));
         }
+    };
+    constexpr int XS = kFeatStride / 16; // 11 super-steps
+    // wavefront 15 of a layer-1 workgroup: rows t of the group's sequences -> hbB[parity of t], in MFMA operand layout
+    // (block S: lane (m, q) <- feat[sequence m][t][16 S + 4 q .. + 3])
+    auto stage_x = [&](int t) {
+        if (WS_DIAG(variant, 256)) return; // timing only: no input rows (garbage in, garbage out)
+        unsigned xl = (unsigned)(lane & 15);
+        asm volatile("" : "+v"(xl)); // the lane's offset is formed here, per step: hoisted, it would be spilled
+        const unsigned x_lane = ((unsigned)(g * 16) + xl) * (unsigned)(T * kFeatStride * 4) + (unsigned)q * 16u;
+#pragma unroll
+        for (int S = 0; S < XS; ++S)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(lds3 + (O_HBB + ((t & 1) * XS + S) * 64) * 16), 16,
+                                                     x_lane, (unsigned)t * (kFeatStride * 4) + S * 64, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
     const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(hx1, 0, 4 * n_rt * GRU_J * 1024, 0x00020000);
@@ -711,6 +747,8 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
             // (one load at a time: a flag load takes ~1800 clocks to come back, but four of them in flight ~450 clocks apart
             // made every step SLOWER -- 15.8k clocks against 14.8k: the extra sc1 traffic to the groups' flag lines delays
             // the fetches and the drains more than the earlier notice saves; tools/ws2_trace.py)
+            // (fetching each tile as its flag arrives instead of all 25 behind the last flag was measured and dropped: -6 us of
+            // 420 at 82 sequences, +14...+20 us at one chunk -- the group's flags arrive together, there is no skew to hide behind)
             for (;;) {
                 unsigned v = 0xFFFFFFFFu; // only the lanes that wait for something load: one flag line per poll, not two
                 if (need) v = __hip_atomic_load(poll_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -777,9 +815,31 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
         *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(xch) + xoff + lane16) = a;
     };
 
+    // layer 1's input projection of step t: chain kp (even / odd super-steps of 11) of gate wg of this wavefront's tile,
+    // fragments from wx, rows from hbB[parity of t] -> its slot of xci[parity of t]
+    auto chain_x = [&](int t) {
+        if (WS_DIAG(variant, 512)) return; // timing only: no input projection
+        const f32x4* wb = wx + ((tslot * 3 + wg) * XS + kp) * 64 + lane;
+        const f32x4* xb = hbB + ((t & 1) * XS + kp) * 64 + lane;
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < (XS + 1) / 2; ++i) {
+            if (i < (XS + 1) / 2 - 1 || kp == 0) { // the even chain has 6 blocks, the odd one 5
+                const f32x4 wv = wb[i * 128], xv = xb[i * 128];
+                a = MFMA16(wv.x, xv.x, a);
+                a = MFMA16(wv.y, xv.y, a);
+                a = MFMA16(wv.z, xv.z, a);
+                a = MFMA16(wv.w, xv.w, a);
+            }
+        }
+        unsigned xoff = (unsigned)__builtin_amdgcn_readfirstlane((12 + (t & 1) * 12 + (tslot * 3 + wg) * 2 + kp) * 1024);
+        if (!TRACE) asm volatile("" : "+s"(xoff));
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(xch) + xoff + lane16) = a;
+    };
+
     // gate math + publish of step t: the helper wavefront of each tile.  `first`: h_{t-1} = 0, so R h + Rb = Rb.
-    // Layer 1: gi from gpre; layer 2: W_ih h1_t from xci (+ Wb).
-    // xi0: where layer 2's input projection of this step sits in xci (the two halves of xci alternate by step parity)
+    // The input projection comes from xci (+ its bias): W' x_t (layer 1) or W_ih h1_t (layer 2).
+    // xi0: where this tile's input projection of this step sits in xci (the two halves of xci alternate by step parity)
     auto gates_and_publish = [&](int t, bool first, int xi0) {
         if (helper) {
             if (wave == 12) WS_STAMP(t, 6);
@@ -788,21 +848,21 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
             const int xi = xi0 + lane;
             f32x4 z4, r4, h;
             {
-                f32x4 gi = layer ? (xci[xi] + xci[xi + 64]) + bt[12] : gpre[0];
+                f32x4 gi = (GI1K || layer) ? (xci[xi] + xci[xi + 64]) + bt[12] : gpre[0];
                 f32x4 a = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : xch[x0] + xch[x0 + 64];
                 const f32x4 b = bt[0];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) z4[r] = fast_sigmoid(gi[r] + (a[r] + b[r]));
             }
             {
-                f32x4 gi = layer ? (xci[xi + 128] + xci[xi + 192]) + bt[16] : gpre[1];
+                f32x4 gi = (GI1K || layer) ? (xci[xi + 128] + xci[xi + 192]) + bt[16] : gpre[1];
                 f32x4 a = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : xch[x0 + 128] + xch[x0 + 192];
                 const f32x4 b = bt[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) r4[r] = fast_sigmoid(gi[r] + (a[r] + b[r]));
             }
             {
-                f32x4 gi = layer ? (xci[xi + 256] + xci[xi + 320]) + bt[20] : gpre[2];
+                f32x4 gi = (GI1K || layer) ? (xci[xi + 256] + xci[xi + 320]) + bt[20] : gpre[2];
                 f32x4 a = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : xch[x0 + 256] + xch[x0 + 320];
                 const f32x4 b = bt[8];
                 const f32x4 hp = hpv[tslot * 64 + lane];
@@ -822,6 +882,7 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
             }
             // this wavefront stored the whole tile: it drains and raises the tile's flag itself
             if (wave == 12) WS_STAMP(t, 7);
+            if (GI1K && layer == 0 && lane == 0) g_done[tslot] = t + 1; // the gate wavefronts may start the next step's input projection
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (wave == 12) WS_STAMP(t, 8);
             if (lane == 0) __hip_atomic_store(my_flag, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -835,8 +896,23 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     };
 
     if (layer == 0) {
+        if (GI1K) {
+            // the stationary input-projection fragments of this workgroup's tile(s): 33 or 66 blocks of 1 KB, all wavefronts
+            const int n_blk = (one ? 1 : 2) * 3 * XS;
+            for (int b = wave; b < n_blk; b += 16) {
+                const int sl = b / (3 * XS), r = b - sl * 3 * XS;
+                const int Jb = one ? pair : 2 * pair + sl;
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (Jb < GRU_J) v = reinterpret_cast<const f32x4*>(W1frag)[((size_t)Jb * 3 * XS + r) * 64 + lane];
+                wx[b * 64 + lane] = v;
+            }
+            if (wave == 15) { stage_x(0); if (T > 1) stage_x(1); }
+            __syncthreads();
+            if (gate_wave && tile_ok) { chain_x(0); if (T > 1) chain_x(1); }
+            __syncthreads();
+        }
         request_gi(0);
-        gates_and_publish(0, true, 0); // t = 0: gi only (no product: h_{-1} = 0)
+        gates_and_publish(0, true, tslot * 6 * 64); // t = 0: the input projection only (no recurrent product: h_{-1} = 0)
         for (int t = 1; t < T; ++t) {
             // h1_{t-1} of every peer, and -- before slot t % 4 is overwritten -- h1_{t-4} consumed by every layer-2 peer
             // (layer 2 reads h1_s in its step s: it has published h2_{t-4}, flag t - 3, only after that)
@@ -845,9 +921,20 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
             if (!barrier_alive()) return;
             if (wave == 0) WS_STAMP(t, 4);
             if (gate_wave && tile_ok) chain(hbA, 0u);
+            // the product phase is when the group exchanges nothing: the next step's input rows are fetched here (chain_x(t) is
+            // behind the barrier above: nobody reads either half of hbB now)
+            if (GI1K && wave == 15 && t + 1 < T) stage_x(t + 1);
             if (wave == 0) WS_STAMP(t, 5);
             __syncthreads();
-            gates_and_publish(t, false, 0);
+            gates_and_publish(t, false, (t & 1) * 12 * 64 + tslot * 6 * 64);
+            // The next step's input projection (the other half of xci) belongs in the hand-off's shadow -- drain, flag, the peers'
+            // polls: ~7k clocks in which the gate wavefronts have nothing to do -- and NOT beside the helper's gate math: started
+            // right behind the barrier its MFMAs and LDS reads took the gate math from 0.8k to 3.2k clocks, 1.5 us per step
+            // (tools/ws2_trace.py).  So the gate wavefronts wait for the word their tile's helper sets once h_t is stored.
+            if (GI1K && gate_wave && tile_ok && t + 1 < T) {
+                while (g_done[tslot] < t + 1 && *s_dead == 0) __builtin_amdgcn_s_sleep(2);
+                chain_x(t + 1);
+            }
         }
     } else {
         // Step t.  Right behind the barrier that ends step t - 1's R phase three things start side by side: the helper
@@ -885,6 +972,281 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
 #undef WS_STAMP
 }
 
+// ------------------------------------------------------------------ the same for several row tiles per group
+// gru_ws2k_kernel serves one row tile per group (up to 96 sequences).  From there to ~1500 sequences a group of 13 + 25
+// workgroups takes RT row tiles through every step, and what a step costs is no longer the hand-off alone but RT products:
+// the 8-wavefront gru_ws2_kernel spends 9.4k clocks per row tile (six gate wavefronts on three SIMDs, operands staged through
+// registers by all wavefronts, a barrier pair per row tile), 3x the 3.2k its MFMAs need.  This kernel keeps gru_ws2k's
+// wavefront layout -- twelve gate wavefronts, one accumulation chain each (the same two chains per gate: the same bits as
+// gru_ws2_kernel), three per SIMD; helpers 12 / 13; wavefronts 14 / 15 fetch -- and streams the row tiles through a
+// double-buffered operand area: while the gate wavefronts multiply row tile rt, wavefront 14 (h1) and 15 (h2) fetch row tile
+// rt + 1 straight into the other buffer (sc1 LDS-DMA, no registers) and the helper does row tile rt - 1's gate math and
+// publishes its tile; ONE barrier per row tile.  The flags are polled once per step (all RT row tiles of a step are
+// published before a flag is raised).  Layer 1's gi comes from the GEMM in front (tile-major rows), two row tiles ahead in
+// the helper's registers.  Hand-off form, bounded spins, error word, fallback launch: gru_ws2k_kernel's.
+constexpr unsigned WS2M_WAIT = 150; // 10 ns ticks before a step's first poll
+__global__ __launch_bounds__(1024) void gru_ws2m_kernel(const float* __restrict__ gi1, const float* __restrict__ R1frag,
+                                                        const float* __restrict__ bR1, const float* __restrict__ W2frag,
+                                                        const float* __restrict__ bW2, const float* __restrict__ R2frag,
+                                                        const float* __restrict__ bR2, float* __restrict__ hout2,
+                                                        float* hx1, float* hx2, unsigned* flags1, unsigned* flags2,
+                                                        unsigned* err, int T, int RT, int n_rt, unsigned long long spin_ticks)
+{
+    // dynamic LDS, in float4s: hb[2 buffers][A: 25 blocks of h1 | B: 25 blocks of h2][64]; xch[2 buffers][12 blocks][64]: a row
+    // tile's partial products (layer 1: [tile slot][gate][chain]; layer 2: R2 h2 in blocks 0..5, W_ih h1 in 6..11);
+    // hpv[RT][2 tile slots][64]: the previous h of the workgroup's tile(s), per row tile; btab[2][6][4]; words
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int O_XCH = 4 * GRU_J * 64, O_HPV = O_XCH + 24 * 64;
+    f32x4* hb = reinterpret_cast<f32x4*>(smem);
+    f32x4* xch = hb + O_XCH;
+    f32x4* hpv = hb + O_HPV;
+    f32x4* btab = hpv + (size_t)RT * 128;
+    __attribute__((address_space(3))) char* lds3 = (__attribute__((address_space(3))) char*)smem;
+    __attribute__((address_space(3))) volatile int* s_dead = (__attribute__((address_space(3))) volatile int*)(lds3 + (O_HPV + RT * 128 + 48) * 16);
+    __attribute__((address_space(3))) volatile int* s_go = s_dead + 1; // layer 2: steps whose flags wavefront 14 has seen (wavefront 15 fetches h2 behind it)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4;
+    const int g = blockIdx.x / 38;
+    const int r38 = blockIdx.x - g * 38;
+    const int layer = r38 >= 13;
+    const int pair = layer ? r38 - 13 : r38;
+    const bool gate_wave = wave < 12;
+    const int ws = gate_wave ? wave / 6 : (wave == 13);
+    const int gk = wave % 6;
+    const int wg = gk % 3;
+    const int kp = gk / 3;
+    const int J = layer ? pair : 2 * pair + ws;
+    const bool tile_ok = J < GRU_J;
+    const int Jc = tile_ok ? J : 0;
+    const int tslot = layer ? 0 : ws;
+    const bool helper = layer ? wave == 12 : ((wave == 12 || wave == 13) && tile_ok);
+    if (wave >= 12) __builtin_amdgcn_s_setprio(3); // helpers, poller, fetchers: few instructions, all of them on the critical path
+    const int my_rt = (n_rt - g * RT < RT) ? n_rt - g * RT : RT;
+
+    if (tid == 0) { *s_dead = (int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *s_go = 0; }
+    for (int i = tid; i < RT * 128; i += 1024) hpv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (tid >= 128 && tid < 128 + 48) {
+        const int e = tid - 128, sl = e / 24, k = (e % 24) / 4, qq = e & 3;
+        const int Jb = layer ? pair : 2 * pair + sl;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (Jb < GRU_J && (layer ? sl == 0 : k < 3)) {
+            const float* src = (k < 3 ? (layer ? bR2 : bR1) : bW2) + (k % 3) * GRU_H + 16 * Jb + 4 * qq;
+            v = *reinterpret_cast<const f32x4*>(src);
+        }
+        btab[e] = v;
+    }
+    __syncthreads();
+    if (*s_dead) return;
+    __syncthreads();
+
+    // stationary weights: chain kp of gate wg of tile J: R1 (layer 1), layer 2's W_ih (first half) / R2 (second half)
+    constexpr int NW = (GRU_J + 1) / 2;
+    f32x4 w[NW];
+    {
+        const bool gate = gate_wave && tile_ok;
+        const size_t blk = ((size_t)(Jc * 3 + wg) * GRU_J) * 64 + lane;
+        const f32x4* src = reinterpret_cast<const f32x4*>(layer ? (ws ? R2frag : W2frag) : R1frag) + blk;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int S = 2 * i + kp;
+            w[i] = (gate && S < GRU_J) ? src[(S < GRU_J ? S : 0) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // (buffer descriptors are formed where they are used: four of them held across the loops would be 16 spilled SGPRs)
+    const unsigned lane16 = (unsigned)lane * 16u;
+    __attribute__((address_space(1))) unsigned* my_flag = (__attribute__((address_space(1))) unsigned*)((layer ? flags2 : flags1) + g * GRU_J + Jc);
+    __attribute__((address_space(1))) unsigned* poll_flag =
+        (__attribute__((address_space(1))) unsigned*)(lane < 32 ? flags1 + g * GRU_J + (lane < GRU_J ? lane : 0)
+                                                                : flags2 + g * GRU_J + (lane - 32 < GRU_J ? lane - 32 : 0));
+
+    // layer 1's gi of (row tile rt, step t) for this helper's tile: tile-major rows [25 J][3 gates][16]
+    // (one row tile ahead: requested right after the gate math of the row tile before has consumed the registers, used a
+    // whole product phase later)
+    f32x4 gpre[3];
+    auto request_gi = [&](int rt, int t) {
+        const auto rs_gi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gi1), 0, n_rt * 16 * T * (3 * GRU_H) * 4, 0x00020000);
+        unsigned ml = (unsigned)(lane & 15);
+        asm volatile("" : "+v"(ml)); // formed per use: hoisted, the lane's offsets would be spilled
+        const unsigned gl = (unsigned)((((g * RT + rt) * 16 + (int)ml) * T + t) * (3 * GRU_H) + 48 * Jc + 4 * q) * 4u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gpre[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gi, gl + 64u * k, 0, 0));
+    };
+    // fetch row tile rt of ring rs at byte offset slot_base (of row tile 0 of the batch) into half `b_half` of buffer `buf`
+    auto fetch = [&](bool from_h2, unsigned slot_base, int rt, int buf) {
+        const unsigned row0 = (unsigned)((g * RT + rt) * GRU_J) * 1024u;
+        const unsigned dst = (unsigned)((buf * 2 + (from_h2 ? 1 : 0)) * GRU_J) * 1024u;
+        const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(hx1, 0, 4 * n_rt * GRU_J * 1024, 0x00020000);
+        const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(hx2, 0, 2 * n_rt * GRU_J * 1024, 0x00020000);
+        // (rolled loops: unrolled, the 25 scalar offsets and LDS addresses of every call site were 65 spilled SGPRs)
+        if (from_h2) {
+#pragma unroll 1
+            for (int S = 0; S < GRU_J; ++S)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void*)(lds3 + dst + S * 1024), 16, lane16,
+                                                         slot_base + row0 + S * 1024, 0, WS_AUX_SC1);
+        } else {
+#pragma unroll 1
+            for (int S = 0; S < GRU_J; ++S)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)(lds3 + dst + S * 1024), 16, lane16,
+                                                         slot_base + row0 + S * 1024, 0, WS_AUX_SC1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // wavefront 14: wait (timed first poll) until layer 1 has published need1 steps and layer 2 need2; false on the deadline
+    auto poll = [&](unsigned need1, unsigned need2) -> bool {
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + WS2M_WAIT;
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(1);
+        const unsigned need = lane < 32 ? need1 : need2;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            unsigned v = 0xFFFFFFFFu;
+            if (need) v = __hip_atomic_load(poll_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(v >= need)) return true;
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) return false;
+        }
+    };
+    auto give_up = [&]() {
+        if (lane == 0) {
+            __hip_atomic_store((__attribute__((address_space(1))) unsigned*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_dead = 1;
+        }
+    };
+    // one chain of one gate: this wavefront's fragments x the row tile's operand in buffer `buf`
+    auto chain = [&](int buf) {
+        const bool srcB = layer && ws;
+        const f32x4* hbp = hb + ((buf * 2 + (srcB ? 1 : 0)) * GRU_J + kp) * 64 + lane;
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            if (i < NW - 1 || kp == 0) {
+                const f32x4 hv = hbp[i * 128];
+                a = MFMA16(w[i].x, hv.x, a);
+                a = MFMA16(w[i].y, hv.y, a);
+                a = MFMA16(w[i].z, hv.z, a);
+                a = MFMA16(w[i].w, hv.w, a);
+            }
+        }
+        const int blk = layer ? (ws ? 0 : 6) + wg * 2 + kp : (tslot * 3 + wg) * 2 + kp;
+        unsigned xoff = (unsigned)__builtin_amdgcn_readfirstlane((buf * 12 + blk) * 1024);
+        asm volatile("" : "+s"(xoff));
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(xch) + xoff + lane16) = a;
+    };
+    // gate math + publish of (row tile rt, step t) by the tile's helper; products in xch[buf]; layer 1's gi in gpre[slot]
+    auto gates = [&](int rt, int t, bool first, int buf) {
+        const f32x4* bt = btab + tslot * 24 + q;
+        const f32x4* xr = xch + (buf * 12 + (layer ? 0 : tslot * 6)) * 64 + lane; // recurrent products: [gate][chain]
+        const f32x4* xi = xch + (buf * 12 + 6) * 64 + lane;                       // layer 2: its input projection
+        f32x4 z4, r4, h;
+        {
+            const f32x4 gi = layer ? (xi[0] + xi[64]) + bt[12] : gpre[0];
+            const f32x4 a = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : xr[0] + xr[64];
+            const f32x4 b = bt[0];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z4[r] = fast_sigmoid(gi[r] + (a[r] + b[r]));
+        }
+        {
+            const f32x4 gi = layer ? (xi[128] + xi[192]) + bt[16] : gpre[1];
+            const f32x4 a = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : xr[128] + xr[192];
+            const f32x4 b = bt[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) r4[r] = fast_sigmoid(gi[r] + (a[r] + b[r]));
+        }
+        {
+            const f32x4 gi = layer ? (xi[256] + xi[320]) + bt[20] : gpre[2];
+            const f32x4 a = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : xr[256] + xr[320];
+            const f32x4 b = bt[8];
+            const f32x4 hp = hpv[(rt * 2 + tslot) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float n = fast_tanh(gi[r] + r4[r] * (a[r] + b[r]));
+                h[r] = (1.0f - z4[r]) * n + z4[r] * hp[r];
+            }
+        }
+        hpv[(rt * 2 + tslot) * 64 + lane] = h;
+        const int rtg = g * RT + rt;
+        if (layer == 0) {
+            const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(hx1, 0, 4 * n_rt * GRU_J * 1024, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs1, lane16, (unsigned)((((t & 3) * n_rt + rtg) * GRU_J + J) * 1024), WS_AUX_SC1);
+        } else {
+            const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(hx2, 0, 2 * n_rt * GRU_J * 1024, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs2, lane16, (unsigned)((((t & 1) * n_rt + rtg) * GRU_J + J) * 1024), WS_AUX_SC1);
+        }
+    };
+    // every tile of the step is stored: the storing wavefront drains, raises its tile's flag, then (layer 2) writes the
+    // row-major copy fc2 reads -- not part of the hand-off -- from hpv
+    auto publish_step = [&](int t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(my_flag, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (layer) {
+            const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(hout2, 0, n_rt * 16 * T * GRU_H * 4, 0x00020000);
+            for (int rt = 0; rt < my_rt; ++rt) {
+                unsigned l16 = lane16;
+                asm volatile("" : "+v"(l16));
+                const unsigned out_lane = (unsigned)((g * RT + rt) * 16 * T * GRU_H * 4) + ((l16 >> 4) & 15u) * (unsigned)(T * GRU_H * 4) + (l16 >> 8) * 16u +
+                                          (unsigned)(16 * Jc * 4);
+                const f32x4 h = hpv[(rt * 2) * 64 + lane];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs_out, out_lane, (unsigned)t * (GRU_H * 4), 0);
+            }
+        }
+    };
+
+    // the row tiles of one step: products of row tile rt beside the fetch of rt + 1 and the gate math of rt - 1 (ONE call site
+    // of the gate math: inlined three times it cost 12 spilled VGPRs)
+    auto step_products = [&](int t, bool useA, unsigned slotA, bool useB, unsigned slotB) {
+        const bool first = layer ? !useB : !useA; // h_{t-1} = 0: no recurrent product
+        for (int rt = 0; rt <= my_rt; ++rt) {
+            const int buf = rt & 1;
+            if (rt < my_rt) {
+                if (rt + 1 < my_rt) {
+                    if (wave == 14 && useA) fetch(false, slotA, rt + 1, buf ^ 1);
+                    if (wave == 15 && useB) fetch(true, slotB, rt + 1, buf ^ 1);
+                }
+                if (gate_wave && tile_ok && (layer ? (ws ? useB : useA) : useA)) chain(buf);
+            }
+            if (helper && rt >= 1) {
+                gates(rt - 1, t, first, buf ^ 1);
+                if (layer == 0 && rt < my_rt) request_gi(rt, t);
+            }
+            if (rt < my_rt) __syncthreads();
+        }
+        if (helper) publish_step(t);
+    };
+
+    if (layer == 0) {
+        for (int t = 0; t < T; ++t) {
+            const unsigned slotA = (unsigned)(((t - 1) & 3) * n_rt * GRU_J) * 1024u;
+            if (helper) request_gi(0, t);
+            if (t >= 1) {
+                if (wave == 14) {
+                    if (poll((unsigned)t, t >= 4 ? (unsigned)(t - 3) : 0u)) fetch(false, slotA, 0, 0);
+                    else give_up();
+                }
+                __syncthreads();
+                if (*s_dead) return;
+            }
+            step_products(t, t >= 1, slotA, false, 0u); // t = 0: gi only
+        }
+    } else {
+        for (int t = 0; t < T; ++t) {
+            const unsigned slotA = (unsigned)((t & 3) * n_rt * GRU_J) * 1024u, slotB = (unsigned)(((t - 1) & 1) * n_rt * GRU_J) * 1024u;
+            if (wave == 14) {
+                if (poll((unsigned)(t + 1), (unsigned)t)) { if (lane == 0) *s_go = t + 1; fetch(false, slotA, 0, 0); }
+                else give_up();
+            }
+            if (wave == 15 && t >= 1) {
+                while (*s_go < t + 1 && *s_dead == 0) __builtin_amdgcn_s_sleep(1);
+                if (*s_dead == 0) fetch(true, slotB, 0, 0);
+            }
+            __syncthreads();
+            if (*s_dead) return;
+            step_products(t, true, slotA, t >= 1, slotB);
+        }
+    }
+}
+
 // geometry of the pipelined launch: G groups of 38 workgroups, RT row tiles per group
 bool fvad_gru_ws2_shape(long n_seq_pad, int n_cu, int* RT, int* G)
 {
@@ -893,42 +1255,109 @@ bool fvad_gru_ws2_shape(long n_seq_pad, int n_cu, int* RT, int* G)
     const int g_max = n_cu / 38;
     if (g_max < 1) return false;
     const int rt = (n_rt + g_max - 1) / g_max;
-    if (rt > 4) return false; // LDS: 50 KB + 14 KB per row tile; beyond a few row tiles the throughput kernels win anyway
+    if (rt > 16) return false; // LDS: 125 KB + 2 KB per row tile (gru_ws2m_kernel)
     *RT = rt;
     *G = (n_rt + rt - 1) / rt;
     return true;
 }
 
+static bool ws2k_fits(long n_seq_pad, int T, int n_cu, int variant, bool gi1k);
+// which kernel a pipelined launch of n_seq_pad sequences of T steps runs: 0 none fits, 1 gru_ws2k (one row tile per group),
+// 2 gru_ws2m (2..16 row tiles per group, 32-bit offsets into gi and h2), 3 gru_ws2 (8 wavefronts, up to 4 row tiles)
+static int ws2_kernel_for(long n_seq_pad, int T, int n_cu, int variant, bool* gi1k)
+{
+    int RT = 0, G = 0;
+    *gi1k = false;
+    if (!fvad_gru_ws2_shape(n_seq_pad, n_cu, &RT, &G)) return 0;
+    if (!(variant & 8)) {
+        if (RT == 1) {
+            if (!(variant & 1024) && ws2k_fits(n_seq_pad, T, n_cu, variant, true)) { *gi1k = true; return 1; }
+            if (ws2k_fits(n_seq_pad, T, n_cu, variant, false)) return 1;
+        } else if ((long long)n_seq_pad * T * (3 * GRU_H) * 4 < (1ll << 32)) return 2;
+    }
+    return RT <= 4 ? 3 : 0;
+}
+
+bool fvad_gru_ws2_ok(long n_seq_pad, int T, int n_cu, int variant)
+{
+    bool k;
+    return ws2_kernel_for(n_seq_pad, T, n_cu, variant, &k) != 0;
+}
+
 size_t fvad_gru_ws2_exchange_floats(long n_seq_pad) { return (size_t)6 * (size_t)(n_seq_pad / 16) * GRU_J * 256; }
 
-int fvad_launch_gru_ws2(const float* gi1, const float* R1frag, const float* bR1, const float* W2frag, const float* bW2,
-                        const float* R2frag, const float* bR2, float* hout2, float* hx, unsigned* flags, unsigned* err,
-                        long n_seq_pad, int T, int n_cu, unsigned long long spin_ticks, int variant, hipStream_t stream)
+// the 16-wavefront kernel (one row tile per group) computes layer 1's input projection itself: no GEMM launch in front of it.
+// It addresses the features and h2 through 32-bit buffer offsets, so a launch whose h2 exceeds 2 GiB keeps the other kernel.
+static bool ws2k_fits(long n_seq_pad, int T, int n_cu, int variant, bool gi1k)
+{
+    int RT = 0, G = 0;
+    if (!fvad_gru_ws2_shape(n_seq_pad, n_cu, &RT, &G)) return false;
+    // 32-bit buffer offsets into h2 and into the features (GI1K) or gi1 (a few sequences of tens of thousands of steps do not fit)
+    const long long per_row = gi1k ? GRU_H : 3 * GRU_H;
+    const bool fits32 = (long long)(n_seq_pad / 16) * 16 * T * per_row * 4 < (1ll << 31);
+    return RT == 1 && fits32 && !(variant & 8);
+}
+
+bool fvad_gru_ws2_gi1_in_kernel(long n_seq_pad, int T, int n_cu, int variant)
+{
+    bool k;
+    return ws2_kernel_for(n_seq_pad, T, n_cu, variant, &k) == 1 && k;
+}
+
+const char* fvad_gru_ws2_kernel_name(long n_seq_pad, int T, int n_cu, int variant)
+{
+    bool k;
+    switch (ws2_kernel_for(n_seq_pad, T, n_cu, variant, &k)) {
+    case 1: return k ? "gru_ws2k (layers pipelined, both input projections in the kernel)" : "gru_ws2k (layers pipelined)";
+    case 2: return "gru_ws2m (layers pipelined, row tiles streamed)";
+    case 3: return "gru_ws2 (layers pipelined)";
+    default: return "none";
+    }
+}
+
+int fvad_launch_gru_ws2(const float* gi1, const float* feat, const float* W1frag, const float* bG1, const float* R1frag, const float* bR1,
+                        const float* W2frag, const float* bW2, const float* R2frag, const float* bR2, float* hout2, float* hx,
+                        unsigned* flags, unsigned* err, long n_seq_pad, int T, int n_cu, unsigned long long spin_ticks, int variant,
+                        hipStream_t stream)
 {
     int RT = 0, G = 0;
     if (!fvad_gru_ws2_shape(n_seq_pad, n_cu, &RT, &G)) return -1;
     const int n_rt = (int)(n_seq_pad / 16);
     float* hx1 = hx;                                    // four slots
     float* hx2 = hx + (size_t)4 * n_rt * GRU_J * 256;   // two slots
-    // K split over 16 wavefronts (variant 8: the 8-wavefront kernel, for comparison); it addresses gi and h2 through 32-bit
-    // buffer offsets, so a launch whose gi exceeds 2 GiB (a few sequences of tens of thousands of steps) keeps the other kernel
-    const bool fits32 = (long long)n_rt * 16 * T * (3 * GRU_H) * 4 < (1ll << 31);
-    if (RT == 1 && fits32 && !(variant & 8)) {
-        const size_t lds_k = 84 * 1024; // 65 KB used; more than half of a CU's LDS: one workgroup per CU
+    bool gi1k = false;
+    const int which = ws2_kernel_for(n_seq_pad, T, n_cu, variant, &gi1k);
+    if (which == 0) return -1;
+    if (which == 1) { // one row tile per group: K split over 16 wavefronts
+        // 158 KB: h1 / h2 operands, partial products, layer 1's 66 KB of stationary input-projection fragments (the kernel's
+        // layout constants); more than half of a CU's LDS either way: one workgroup per CU
+        const size_t lds_k = (size_t)(2 * GRU_J * 64 + 12 * 64 + 24 * 64 + 2 * 64 + 48 + 176 + 2 * 3 * (kFeatStride / 16) * 64) * 16;
         // up to five row tiles (80 sequences) on 256 CUs: 25 + 25 workgroups per group; six: 13 + 25 (variant 16: always)
         const int nl1 = (G * 2 * GRU_J <= n_cu && !(variant & 16)) ? GRU_J : 13;
         const dim3 grid((unsigned)(G * (nl1 + GRU_J)));
+        const float* in1 = gi1k ? feat : gi1;
+#define WS2K_LAUNCH(TRACE_, GI1K_)                                                                                                              \
+        {                                                                                                                                       \
+            if (hipFuncSetAttribute((const void*)gru_ws2k_kernel<TRACE_, GI1K_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return -2; \
+            hipLaunchKernelGGL((gru_ws2k_kernel<TRACE_, GI1K_>), grid, dim3(1024), lds_k, stream, in1, W1frag, bG1, R1frag, bR1, W2frag, bW2, R2frag, bR2, \
+                               hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant, nl1);                                   \
+            return 0;                                                                                                                           \
+        }
 #if FVAD_DIAG
         if (variant & 64) { // step trace (tools/ws2_trace.py)
-            if (hipFuncSetAttribute((const void*)gru_ws2k_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return -2;
-            hipLaunchKernelGGL(gru_ws2k_kernel<true>, grid, dim3(1024), lds_k, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
-                               hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant, nl1);
-            return 0;
+            if (gi1k) WS2K_LAUNCH(true, true)
+            WS2K_LAUNCH(true, false)
         }
 #endif
-        if (hipFuncSetAttribute((const void*)gru_ws2k_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return -2;
-        hipLaunchKernelGGL(gru_ws2k_kernel<false>, grid, dim3(1024), lds_k, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
-                           hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant, nl1);
+        if (gi1k) WS2K_LAUNCH(false, true)
+        WS2K_LAUNCH(false, false)
+#undef WS2K_LAUNCH
+    }
+    if (which == 2) { // 2..16 row tiles per group, streamed through LDS
+        const size_t lds_m = (size_t)(4 * GRU_J * 64 + 24 * 64 + RT * 128 + 48 + 1) * 16; // >= 129 KB: one workgroup per CU
+        if (hipFuncSetAttribute((const void*)gru_ws2m_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m) != hipSuccess) return -2;
+        hipLaunchKernelGGL(gru_ws2m_kernel, dim3((unsigned)(G * 38)), dim3(1024), lds_m, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
+                           hout2, hx1, hx2, flags, flags + 256, err, T, RT, n_rt, spin_ticks);
         return 0;
     }
     // more than half of a CU's 160 KB of LDS: one workgroup per CU (all workgroups of the launch spin on each other)

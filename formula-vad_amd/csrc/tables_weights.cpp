@@ -210,6 +210,23 @@ void pack_gru_r2(const float* R, int H, std::vector<float>& out)
                     }
 }
 
+// the same fragment order for a GRU input matrix W [3 H][K]: [H/16 unit tiles][3 gates][ceil(K/16) super-steps][64 lanes][4],
+// K zero-padded (kernels_ws.hip: layer 1's stationary input-projection fragments)
+void pack_gru_frag(const float* W, int H, int K, std::vector<float>& out)
+{
+    const int J = H / 16, S = (K + 15) / 16;
+    out.assign((size_t)J * 3 * S * 256, 0.0f);
+    for (int j = 0; j < J; ++j)
+        for (int g = 0; g < 3; ++g)
+            for (int s = 0; s < S; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = g * H + 16 * j + (lane & 15);
+                        const int k = 16 * s + 4 * (lane >> 4) + r;
+                        if (k < K) out[(((size_t)j * 3 + g) * S + s) * 256 + lane * 4 + r] = W[(size_t)n * K + k];
+                    }
+}
+
 // ---- f16x3 layouts (kernels_h3.hip): every weight as two f16 pieces of W * sw
 // f32 -> f16 bits, round to nearest even (weights are finite; |v| < 65520 by the choice of sw)
 static uint16_t f32_to_f16_bits(float f)

@@ -1637,23 +1637,24 @@ ctx.set_option("ws_spin_ticks", None)
 assert np.array_equal(g2, lat), np.abs(g2 - lat).max()
 assert np.abs(p2 - lat).max() <= 2e-6              # its own family: layer 2's input projection is computed in the kernel
 assert (np.abs(g[:3] - ref) / np.maximum(np.abs(ref), 1e-2)).max() <= 1e-4
-# 82 sequences = one row tile per group: the 16-wavefront form of the pipelined kernel (gru_ws2k_kernel).  Same bits
-# as the 8-wavefront form (ws2_variant 8 forces it); same fallback chain behind it
+# 82 sequences = one row tile per group: the 16-wavefront form of the pipelined kernel (gru_ws2k_kernel), which computes
+# layer 1's input projection too (two chains + bias instead of the GEMM's one chain: its own bits, round-off apart from
+# the 8-wavefront form behind a GEMM, which ws2_variant 8 forces); same fallback chain behind it
 f82 = f[:82]
 k16 = ctx.nsnet2_forward(f82)
-assert "gru_ws2" in ctx.last_nn_path(), ctx.last_nn_path()
-assert np.array_equal(k16, p2[:82])                # a sequence's bits do not depend on the batch it sits in
-for variant in ("8",):
-    ctx.set_option("ws2_variant", variant)
-    assert np.array_equal(ctx.nsnet2_forward(f82), k16), variant
+assert "gru_ws2k" in ctx.last_nn_path() and "both input projections" in ctx.last_nn_path(), ctx.last_nn_path()
+assert np.abs(k16 - p2[:82]).max() <= 2e-6
+assert np.array_equal(ctx.nsnet2_forward(f[40:122])[:42], k16[40:])   # a sequence's bits do not depend on where in a batch it sits
+ctx.set_option("ws2_variant", "8")
+assert np.array_equal(ctx.nsnet2_forward(f82), p2[:82])               # the 8-wavefront kernel: the bits of the 130-sequence launch
+assert "gru_ws2 (" in ctx.last_nn_path(), ctx.last_nn_path()
 ctx.set_option("ws2_variant", None)
 # up to five row tiles the groups have 25 + 25 workgroups (one layer-1 tile each) instead of 13 + 25 (16 forces those)
 f50 = f[:50]
 k50 = ctx.nsnet2_forward(f50)
-assert np.array_equal(k50, p2[:50])
-for variant in ("16", "8"):
-    ctx.set_option("ws2_variant", variant)
-    assert np.array_equal(ctx.nsnet2_forward(f50), k50), variant
+assert np.array_equal(k50, k16[:50])
+ctx.set_option("ws2_variant", "16")
+assert np.array_equal(ctx.nsnet2_forward(f50), k50)
 ctx.set_option("ws2_variant", None)
 assert ctx.ws_fallbacks() == 2
 ctx.set_option("ws_spin_ticks", "0")
@@ -1772,7 +1773,10 @@ def test_config4_one_rank_share_at_full_size_matches_oracle(fv, gpu_ctx, weights
         assert [(s[0], s[1]) for s in segs[j]] == [(s[0], s[1]) for s in ref["segs"]], f"cfg4 segments stream {sid}"
         assert [s[3] for s in segs[j]] == [s[3] for s in ref["segs"]], f"cfg4 vad_met_sec stream {sid}"
         margin = vb.audit(j)
-        assert margin[0] > 1e-3, margin          # no decision within 10x the band-sum tolerance of its threshold
+        # the closest any of the stream's 337500 decisions comes to its threshold (relative) is further than the band sums are
+        # from the oracle's: the identical segments are not luck
+        err = float((np.abs(band[j].astype(np.float64) - ref["band"]) / np.abs(ref["band"])).max())
+        assert margin[0] > 2 * err, (margin, err)
         total_segments += len(ref["segs"])
         labels = bench.roll_labels(big["base_labels"], 4801 * sid / 48000.0, 600.0, 12)
         to_sec = lambda ss: [(np.float32(s[0]) / np.float32(48000), np.float32(s[1]) / np.float32(48000)) for s in ss]  # noqa: E731
@@ -1801,7 +1805,7 @@ def test_config5_one_rank_share_graph_replay_loop_matches_oracle(fv, weights7, p
         ctx.load_weights(weights7)
         got = pkg.shard.run_time_split_rank_graph(ctx, x5, c0, c1, window=496, lanes=4, use_graph=True)
         assert got["replays"] >= 5 and got["lane_starts"][0] == 8976
-        assert "gru_rec3" in ctx.last_nn_path()
+        assert "panel_gemm3" in ctx.last_nn_path()      # 2048 chunks per launch: the large-batch family
         # the same loop with direct launches: a replay must not differ from launching
         direct = pkg.shard.run_time_split_rank_graph(ctx, x5, c0, min(c1, c0 + 1100), window=496, lanes=4, use_graph=False)
     finally:
@@ -1825,4 +1829,7 @@ def test_config5_one_rank_share_graph_replay_loop_matches_oracle(fv, weights7, p
     vb.close()
     want = [s for s in ref["segs"] if s[1] <= f_hi * 1024]
     assert [(s[0], s[1], s[3]) for s in segs[: len(want)]] == [(s[0], s[1], s[3]) for s in want]
-    assert len(segs) - len(want) <= 1 and len(want) >= 200 and margin[0] > 1e-3, (len(segs), len(want), margin)
+    # the closest any decision comes to its threshold (relative) is further than the band sums are from the oracle's: the
+    # identical segments are not luck
+    err = float((np.abs(got["band_sum"].astype(np.float64) - ref["band"][f_lo:f_hi]) / np.abs(ref["band"][f_lo:f_hi])).max())
+    assert len(segs) - len(want) <= 1 and len(want) >= 200 and margin[0] > 2 * err, (len(segs), len(want), margin, err)

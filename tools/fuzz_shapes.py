@@ -37,7 +37,7 @@ for c in range(cases):
     k = int(rng.integers(1, n + 1))
     g2 = ctx.nsnet2_forward(f[:k])
     path2 = ctx.last_nn_path()
-    if family(path) == family(path2) and "ws2" in path and "ws2" in path2 or path == path2:
+    if path == path2:
         if not np.array_equal(g2, g[:k]):
             bad += 1; print(f"nsnet2 n={n} T={T}: first {k} sequences alone differ ({path} | {path2})", flush=True)
     elif np.abs(g2 - g[:k]).max() > 2e-5:
@@ -54,7 +54,10 @@ def same(a, b, what):
 t0 = time.time()
 for c in range(cases):
     n_l = int(rng.integers(1, 7))
-    lens = [int(rng.integers(1, 41)) for _ in range(n_l)]
+    # default mode: launches of up to 96 chunks are ONE selection (gru_ws2k, both input projections in the kernel), larger
+    # ones another (a GEMM in front of gru_ws2 / gru_ws): bit-equality across launch splits holds within a selection, so
+    # the default-mode cases stay within 96 chunks; the `reproducible` cases (every third) take any size
+    lens = [int(rng.integers(1, 41 if c % 3 == 2 else max(2, 96 // n_l + 1))) for _ in range(n_l)]
     i16 = bool(rng.integers(0, 2))
     streams = []
     for i, nc in enumerate(lens):

@@ -11,7 +11,9 @@ pkg = load_package(); fv = pkg.binding
 L = fv.lib()
 ctx = fv.Context(0); ctx.load_synth(7)
 f = np.random.default_rng(0).uniform(-11, 2, (82, 54, 161)).astype(np.float32)
-with ctx.options(ws2_variant=64):
+VAR = 64 + (int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+print("ws2_variant", VAR)
+with ctx.options(ws2_variant=VAR):
     for _ in range(3):
         ctx.nsnet2_forward(f)
     buf = (C.c_uint32 * 2000)()
