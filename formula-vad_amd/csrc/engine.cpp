@@ -557,6 +557,18 @@ static GruChoice pick_gru(const fvad_ctx* ctx, long n_pad, int T, bool allow_v3)
     return {3, best};
 }
 
+// Deadline of one spin wait of a weight-stationary launch, in 100 MHz ticks: every wait of such a launch ends within the
+// launch's own duration when its workgroups are co-resident, so 20 x the cost model's estimate of the whole launch (cycles at
+// ~2.1 GHz = 21 cycles per tick), at least 2 ms, tells "not making progress" from "slow" with a wide margin -- and a launch
+// that shares the GPU with another process's kernels gives up after milliseconds and takes the fallback, where a fixed
+// 0.25 s deadline stalled a 0.4 ms push for 250 ms.
+static unsigned long long ws_spin_deadline(const fvad_ctx* ctx, double est_cycles)
+{
+    if (!ctx->tune.ws_spin_auto) return ctx->tune.ws_spin_ticks;
+    const double ticks = 20.0 * est_cycles / 21.0;
+    return (unsigned long long)std::max(200000.0, std::min(ticks, 25000000.0));
+}
+
 // buffers of the weight-stationary recurrence, sized once for the largest batch that kernel takes (2560
 // sequences: 8 MB of h exchange) so that nothing is allocated inside a stream capture
 int ensure_gru_ws(fvad_ctx* ctx)
@@ -626,7 +638,7 @@ static int launch_gru(fvad_ctx* ctx, GruChoice c, const float* gi, const DevBuf&
         unsigned* err = ws.ws_sync + 512;
         int rc = ws_serialised(ctx, [&] {
             return fvad_launch_gru_ws(gi, r_v2.p, bR, hout, ws.hx, ws.ws_sync + 256 * layer, err, n_pad, T, ctx->n_cu, tile_major,
-                                      ctx->tune.ws_spin_ticks, ctx->stream);
+                                      ws_spin_deadline(ctx, (double)T * gru_ws_cost(n_pad, ctx->n_cu)), ctx->stream);
         });
         if (rc) return rc;
         // fallback behind it: returns at once unless a workgroup of the launch above gave up waiting; the last layer
@@ -855,7 +867,7 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
         time_begin(ctx, "gru12_rec_pipelined");
         rc |= ws_serialised(ctx, [&] {
             return fvad_launch_gru_ws2(ws.gi, ws.feat, m.s_w1frag.p, m.gi1f_b.p, m.r1v2.p, m.br1.p, m.s_w2frag.p, m.s_bw2.p, m.r2v2.p, m.br2.p, ws.h2,
-                                       ws.hx, ws.ws_sync, err, n_pad, T, ctx->n_cu, tn.ws_spin_ticks, tn.ws2_variant, st);
+                                       ws.hx, ws.ws_sync, err, n_pad, T, ctx->n_cu, ws_spin_deadline(ctx, gru_ws2_cost_both_layers(n_pad, T, ctx->n_cu, tn.ws2_variant) * T / 55.0), tn.ws2_variant, st);
         });
         // one launch behind it: the whole fallback (layer 1, layer 2's input projection, layer 2 -- run only if the
         // error word was raised), the pass count, and the reset of the polled words for the next pass
@@ -892,6 +904,23 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     return FVAD_OK;
 }
 
+// Chunks per launch of a call over `total` chunks; max_chunks <= 0: the caller leaves it to the engine.
+// Launch planning (only then, f32, default kernel selection): between the largest batch the pipelined recurrence takes
+// (1536 chunks: 16 row tiles per group) and ~2700 chunks ONE launch would fall to the large-batch family's low-latency
+// recurrence, which keeps 128-170 of the 256 CUs busy (2048 chunks: 7.4 ms = 13.8 M frames/s); two launches of half the size
+// stay on the pipelined kernels (2 x 3.1 ms = 16.5 M frames/s).  Measured crossover (bench.py's batch curve): 4.86 ms + 1.26 us
+// per chunk against 3.03 us per chunk.
+static long planned_max_chunks(const fvad_ctx* ctx, long total, long max_chunks)
+{
+    if (max_chunks > 0) return max_chunks;
+    max_chunks = ctx->tune.max_chunks;
+    const Tuning& tn = ctx->tune;
+    if (!ctx->dm.generic && nn_math_effective(ctx) == FVAD_NN_MATH_F32 && !tn.reproducible && tn.gru_kernel.empty() && tn.gemm_kernel.empty() &&
+        total > 1536 && total <= 2700 && max_chunks >= total)
+        max_chunks = (total / 2 + 15) / 16 * 16;
+    return max_chunks;
+}
+
 // K1 -> NSNet2 -> K3 over every chunk of every job, in launches of <= max_chunks chunks.
 int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, ChunkDesc* capture_descs, ChunkDesc* capture_dev)
 {
@@ -900,10 +929,10 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
     // uploaded once by the caller after the capture): the graph holds no copy node and does not depend on
     // the workspace's shared table, which direct calls overwrite.  No event is waited for or recorded.
     size_t capture_off = 0;
-    if (max_chunks <= 0) max_chunks = ctx->tune.max_chunks;
     long total = 0;
     for (auto& j : jobs) total += (long)j.n_chunks;
     if (total == 0) return FVAD_OK;
+    max_chunks = planned_max_chunks(ctx, total, max_chunks);
     int rc = ensure_workspace(ctx, std::min(total, max_chunks), kRowsPerChunk, kWarmupRows, total % std::min(total, max_chunks));
     if (rc) return rc;
     Workspace& ws = ctx->ws;
@@ -1048,8 +1077,13 @@ static int apply_option(fvad_ctx* ctx, const std::string& name, const char* valu
         if (!unset && (!to_long(c) || c < 1 || c > 256)) return FVAD_ERR_INVALID_ARGUMENT;
         tn.copy_threads = (int)c;
     } else if (name == "ws_spin_ticks") {
-        if (unset) tn.ws_spin_ticks = def.ws_spin_ticks;
-        else { char* end = nullptr; tn.ws_spin_ticks = strtoull(v.c_str(), &end, 10); if (!end || *end) return FVAD_ERR_INVALID_ARGUMENT; }
+        if (unset) { tn.ws_spin_ticks = def.ws_spin_ticks; tn.ws_spin_auto = true; }
+        else {
+            char* end = nullptr;
+            tn.ws_spin_ticks = strtoull(v.c_str(), &end, 10);
+            if (!end || *end) return FVAD_ERR_INVALID_ARGUMENT;
+            tn.ws_spin_auto = false;
+        }
     } else if (name == "ws2_variant") { // shape / timing knobs of the pipelined recurrence (tools/ws2_variants.py, ws2_delay.py)
         long c = 0;
         if (!unset && (!to_long(c) || c < 0 || c >= (1 << 25))) return FVAD_ERR_INVALID_ARGUMENT;
@@ -1978,10 +2012,8 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
             FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
             ws.carries_clean = n_scratch;
         }
-        {
-            long maxc = opts.max_chunks_per_launch > 0 ? opts.max_chunks_per_launch : ctx->tune.max_chunks;
-            if ((long)(n_lanes * n_chunks) > maxc) ws.carries_clean = 0; // several launches: the even carries get written
-        }
+        if ((long)(n_lanes * n_chunks) > planned_max_chunks(ctx, (long)(n_lanes * n_chunks), opts.max_chunks_per_launch))
+            ws.carries_clean = 0; // several launches: the even carries get written
         std::vector<LaneJob> jobs(n_lanes);
         for (size_t l = 0; l < n_lanes; ++l) {
             jobs[l].d_in = d_pcm ? d_pcm + l * lane_stride : nullptr;
@@ -2012,9 +2044,8 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
     // and the workspace stay the same -- BASELINE config 5's "hipGraph-captured steady-state loop".  A step
     // is ~12 launches per 100 ms of GPU work, so this saves well under 1 % (measured in bench.py's extras).
     if (opts.use_graph && !ctx->timing) {
-        long maxc = opts.max_chunks_per_launch;
-        if (maxc <= 0) maxc = ctx->tune.max_chunks;
         const long total = (long)(n_lanes * n_chunks);
+        const long maxc = planned_max_chunks(ctx, total, opts.max_chunks_per_launch);
         if ((rc = ensure_workspace(ctx, std::min(total, maxc), kRowsPerChunk, kWarmupRows, total % std::min(total, maxc)))) return rc; // no allocation while capturing
         if ((rc = ensure_gru_ws(ctx))) return rc;
         Workspace::GraphCache& gc = ws.graph;

@@ -170,7 +170,11 @@ struct Tuning {
     bool trace_kernels = false;  // name every NSNet2 stage on stderr and wait for it
     bool reproducible = false;   // one kernel family (the large-batch one) at every batch size
     int ws2_variant = 0;         // timing-only variants of gru_ws2_kernel (tools/ws2_variants.py); 0 in production
-    unsigned long long ws_spin_ticks = 25000000ull; // spin deadline of gru_ws_kernel (100 MHz ticks: 0.25 s)
+    // spin deadline of the weight-stationary kernels' waits in 100 MHz ticks.  Default (ws_spin_auto): derived per launch from
+    // the launch's own expected duration -- 20 x the cost model's estimate, at least 2 ms -- so that a launch that cannot make
+    // progress (another process holds the CUs its workgroups need) costs milliseconds, not the 0.25 s of a fixed deadline
+    unsigned long long ws_spin_ticks = 0ull;
+    bool ws_spin_auto = true;
 };
 
 } // namespace fvad

