@@ -1020,11 +1020,17 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
 
 // BufferedFFT.init's window and norm (BufferedFFT.zig:95-99; window_fn.zig:22-28,8-16) plus kissfft's tables for an
 // n-point real transform, evaluated on the host in double like kissfft does, uploaded once per context and size
-int get_vad_plan(fvad_ctx* ctx, size_t n, VadFftPlan* out)
+bool fvad_fft_size_ok(size_t n) { return n >= 4 && n % 2 == 0 && n <= (size_t)kVadFftMax; }
+
+int get_vad_plan(fvad_ctx* ctx, size_t n, VadFftPlan* out, bool force_generic)
 {
-    if (!(n == 512 || n == 1024 || n == 2048))
-        return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "the VAD-side FFT has kernels for fft_size 512, 1024 (the reference default) and 2048");
-    auto it = ctx->vad_plans.find((int)n);
+    // any even size kissfft would factor (FFT.zig:35-60), up to the generic kernel's LDS: 2 x (n / 2 + 1) complex values
+    if (!fvad_fft_size_ok(n))
+        return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "fft_size must be even, at least 4 and at most 16384 (FFT.zig:41-43; the generic kernel's LDS)");
+    const bool wave_size = n == 512 || n == 1024 || n == 2048; // one wavefront per frame; every other size: one workgroup per frame
+    const bool generic = force_generic || !wave_size;
+    const int key = (int)n | (generic && wave_size ? 1 << 20 : 0);
+    auto it = ctx->vad_plans.find(key);
     if (it == ctx->vad_plans.end()) {
         std::vector<float> win(n), tw, st, all;
         hann_window_periodic(win.data(), n);
@@ -1033,10 +1039,24 @@ int get_vad_plan(fvad_ctx* ctx, size_t n, VadFftPlan* out)
         auto put = [&](const std::vector<float>& v) { const size_t o = all.size(); all.insert(all.end(), v.begin(), v.end()); all.resize((all.size() + 63) / 64 * 64); return o; };
         const size_t o_w = put(win), o_tw = put(tw), o_st = put(st);
         fvad_ctx::VadPlanDev pd;
-        FVAD_HIP(ctx, hipMalloc((void**)&pd.d, all.size() * sizeof(float)));
+        FVAD_HIP(ctx, hipMalloc((void**)&pd.d, std::max<size_t>(all.size(), 64) * sizeof(float)));
         FVAD_HIP(ctx, hipMemcpy(pd.d, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
-        pd.plan = VadFftPlan{(int)n, pd.d + o_w, pd.d + o_tw, pd.d + o_st, window_norm_factor(win.data(), n) / (float)n};
-        it = ctx->vad_plans.emplace((int)n, pd).first;
+        pd.plan = VadFftPlan{(int)n, pd.d + o_w, pd.d + o_tw, pd.d + o_st, window_norm_factor(win.data(), n) / (float)n, generic ? 1 : 0, 0, {}};
+        if (generic) {
+            // the radices of the complex transform of length n / 2, kissfft's kf_factor order: 4s first, then 2, 3, 5, 7, ...
+            int m = (int)n / 2, p = 4, nf = 0;
+            while (m > 1) {
+                while (m % p) {
+                    switch (p) { case 4: p = 2; break; case 2: p = 3; break; default: p += 2; break; }
+                    if ((long long)p * p > m) p = m; // no more factors: m is prime
+                }
+                m /= p;
+                if (nf >= 14) { hipFree(pd.d); return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "fft_size has too many prime factors"); }
+                pd.plan.fac[nf++] = p;
+            }
+            pd.plan.n_fac = nf;
+        }
+        it = ctx->vad_plans.emplace(key, pd).first;
         ctx->ws.generation++;
     }
     *out = it->second.plan;
@@ -1090,7 +1110,7 @@ static int apply_option(fvad_ctx* ctx, const std::string& name, const char* valu
 #if !FVAD_DIAG
         // the timing-only bits (1, 2, 4, 32: WRONG results) and the step trace (64) exist in the diagnostics build only
         // (make diag -> libfvad_hip_diag.so); the shipping library has no way to ask for wrong results
-        if (c & (1 | 2 | 4 | 32 | 64)) return FVAD_ERR_INVALID_ARGUMENT;
+        if (c & (1 | 2 | 4 | 32 | 64 | 256 | 512 | 4096 | 8192 | 16384)) return FVAD_ERR_INVALID_ARGUMENT;
 #endif
         tn.ws2_variant = (int)c;
     } else if (name == "no_pipeline") { if (!to_bool(tn.no_pipeline)) return FVAD_ERR_INVALID_ARGUMENT; }
@@ -1481,7 +1501,7 @@ void fvad_lane_state_reset(fvad_lane_state* s)
 int fvad_lane_state_seek(fvad_lane_state* s, uint64_t sample_index, size_t fft_size)
 {
     if (fft_size == 0) fft_size = kVadFft;
-    if (!s || sample_index % kChunk48 || !(fft_size == 512 || fft_size == 1024 || fft_size == 2048)) return FVAD_ERR_INVALID_ARGUMENT;
+    if (!s || sample_index % kChunk48 || !fvad_fft_size_ok(fft_size)) return FVAD_ERR_INVALID_ARGUMENT;
     fvad_lane_state_reset(s);
     // zero history, positioned mid-stream: the VAD FFT's frame grid stays anchored at absolute sample 0, so the
     // first sample_index % fft_size positions of the first frame are (zero) remainder

@@ -230,8 +230,10 @@ int upload_model(fvad_ctx* ctx);
 int nn_math_effective(const fvad_ctx* ctx);
 int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T, int skip, long n_last = 0);
 int ensure_gru_ws(fvad_ctx* ctx);
-// tables of the n-point VAD FFT (n = 512 / 1024 / 2048), cached per context
-int get_vad_plan(fvad_ctx* ctx, size_t n, VadFftPlan* out);
+// tables of the n-point real FFT (any even n up to kVadFftMax; 512 / 1024 / 2048 on the wavefront kernels unless force_generic),
+// cached per context
+int get_vad_plan(fvad_ctx* ctx, size_t n, VadFftPlan* out, bool force_generic = false);
+bool fvad_fft_size_ok(size_t n); // even, 4 .. kVadFftMax
 // NSNet2 on ws.feat -> ws.gains for n_chunks sequences of T rows; gains rows skip..T-1 only
 int run_nn(fvad_ctx* ctx, long n_chunks_pad, int T, int skip);
 

@@ -17,7 +17,7 @@ constexpr int kFeatStride = 176;               // 161 padded to 11 x 16 (zero-fi
 constexpr int kDown = 3;                       // 48 kHz -> 16 kHz
 constexpr int kChunk48 = kFramesPerChunk * kNHop * kDown; // 24000
 constexpr int kVadFft = 1024;               // VADPipeline.Config.fft_size default (VADPipeline.zig:21)
-constexpr int kVadFftMax = 2048;            // sizes with a kernel: 512, 1024, 2048
+constexpr int kVadFftMax = 16384;           // any even size up to this: 512 / 1024 / 2048 on the wavefront FFT, the others on the generic kernel
 
 // cross-call carry of one lane (all device floats); mirrors NSNet2.zig:27-33 state
 struct LaneCarry {
@@ -68,6 +68,11 @@ struct VadFftPlan {
     const float* tw;         // [n/2][2] exp(-2 pi i j / (n/2))
     const float* st;         // [n/4][2] real-FFT un-mixing
     float norm;              // windowNormFactor / n, BufferedFFT.zig:99
+    // any other even size (FFT.init takes whatever kissfft factors, FFT.zig:35-60): the generic mixed-radix kernel, one
+    // workgroup per frame, Stockham passes over the radices of n / 2 (4s first, then 2, 3, 5, ... like kissfft's kf_factor)
+    int generic;             // 0: one of the wavefront sizes (512 / 1024 / 2048)
+    int n_fac;
+    int fac[14];
 };
 
 int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const float* bias, float* C,
@@ -164,3 +169,6 @@ void fvad_launch_rfft_batch(const float* frames, long n_frames, int n_fft, const
                             hipStream_t stream);
 void fvad_launch_irfft_batch(const float* bins, long n_frames, FftTables tb, float* out,
                              hipStream_t stream);
+// FFT.invFft for any even size (pl.generic plans; tables of the FORWARD transform, conjugated in the kernel): bins
+// [n_frames][n/2 + 1][2] -> out [n_frames][n], unscaled like kiss_fftri
+void fvad_launch_irfft_generic(const float* bins, long n_frames, VadFftPlan pl, float* out, hipStream_t stream);

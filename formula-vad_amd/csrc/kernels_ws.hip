@@ -638,6 +638,7 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
 
     if (tid == 0) { *s_dead = (int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *hA_ready = 0; g_done[0] = 0; g_done[1] = 0; }
     if (tid < 2 * 64) hpv[tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 24 * 64; i += 1024) xci[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; // (layer 1 with GI1K: the chain-1 slots are never written)
     if (tid >= 128 && tid < 128 + 48) { // biases of the workgroup's tile(s): read from LDS in the gate math
         const int e = tid - 128, sl = e / 24, k = (e % 24) / 4, qq = e & 3;
         const int Jb = (layer || one) ? pair : 2 * pair + sl;
@@ -820,24 +821,26 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
         *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(xch) + xoff + lane16) = a;
     };
 
-    // layer 1's input projection of step t: chain kp (even / odd super-steps of 11) of gate wg of this wavefront's tile,
-    // fragments from wx, rows from hbB[parity of t] -> its slot of xci[parity of t]
+    // layer 1's input projection of step t: gate wg of this wavefront's tile, fragments from wx, rows from hbB[parity of t] ->
+    // its slot of xci[parity of t].  ONE chain over the 11 super-steps, from zero, the bias added behind it in the gate math:
+    // the accumulation order of the GEMM this replaces (panel_gemm_s_kernel), so a launch has the same bits whether its
+    // input projection ran here or in a GEMM in front -- the wavefronts of chain 0 do it, those of chain 1 leave their slot
+    // of xci zero (44 dependent MFMAs = 1.8k clocks, in a shadow of ~7k)
     auto chain_x = [&](int t) {
         if (WS_DIAG(variant, 512)) return; // timing only: no input projection
-        const f32x4* wb = wx + ((tslot * 3 + wg) * XS + kp) * 64 + lane;
-        const f32x4* xb = hbB + ((t & 1) * XS + kp) * 64 + lane;
+        if (kp) return;
+        const f32x4* wb = wx + ((tslot * 3 + wg) * XS) * 64 + lane;
+        const f32x4* xb = hbB + ((t & 1) * XS) * 64 + lane;
         f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < (XS + 1) / 2; ++i) {
-            if (i < (XS + 1) / 2 - 1 || kp == 0) { // the even chain has 6 blocks, the odd one 5
-                const f32x4 wv = wb[i * 128], xv = xb[i * 128];
-                a = MFMA16(wv.x, xv.x, a);
-                a = MFMA16(wv.y, xv.y, a);
-                a = MFMA16(wv.z, xv.z, a);
-                a = MFMA16(wv.w, xv.w, a);
-            }
+        for (int i = 0; i < XS; ++i) {
+            const f32x4 wv = wb[i * 64], xv = xb[i * 64];
+            a = MFMA16(wv.x, xv.x, a);
+            a = MFMA16(wv.y, xv.y, a);
+            a = MFMA16(wv.z, xv.z, a);
+            a = MFMA16(wv.w, xv.w, a);
         }
-        unsigned xoff = (unsigned)__builtin_amdgcn_readfirstlane((12 + (t & 1) * 12 + (tslot * 3 + wg) * 2 + kp) * 1024);
+        unsigned xoff = (unsigned)__builtin_amdgcn_readfirstlane((12 + (t & 1) * 12 + (tslot * 3 + wg) * 2) * 1024);
         if (!TRACE) asm volatile("" : "+s"(xoff));
         *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(xch) + xoff + lane16) = a;
     };
@@ -995,8 +998,10 @@ __global__ __launch_bounds__(1024) void gru_ws2m_kernel(const float* __restrict_
                                                         const float* __restrict__ bW2, const float* __restrict__ R2frag,
                                                         const float* __restrict__ bR2, float* __restrict__ hout2,
                                                         float* hx1, float* hx2, unsigned* flags1, unsigned* flags2,
-                                                        unsigned* err, int T, int RT, int n_rt, unsigned long long spin_ticks)
+                                                        unsigned* err, int T, int RT, int n_rt, unsigned long long spin_ticks, int variant)
 {
+    // diagnostics build only (timing, wrong results): variant & 4096 no operand fetch behind a step's first row tile, 8192 no gate
+    // math (zeros are published), 16384 no products
     // dynamic LDS, in float4s: hb[2 buffers][A: 25 blocks of h1 | B: 25 blocks of h2][64]; xch[2 buffers][12 blocks][64]: a row
     // tile's partial products (layer 1: [tile slot][gate][chain]; layer 2: R2 h2 in blocks 0..5, W_ih h1 in 6..11);
     // hpv[RT][2 tile slots][64]: the previous h of the workgroup's tile(s), per row tile; btab[2][6][4]; words
@@ -1028,7 +1033,7 @@ __global__ __launch_bounds__(1024) void gru_ws2m_kernel(const float* __restrict_
     const int Jc = tile_ok ? J : 0;
     const int tslot = layer ? 0 : ws;
     const bool helper = layer ? wave == 12 : ((wave == 12 || wave == 13) && tile_ok);
-    if (wave >= 12) __builtin_amdgcn_s_setprio(3); // helpers, poller, fetchers: few instructions, all of them on the critical path
+    if (wave >= 12 && !(variant & 32768)) __builtin_amdgcn_s_setprio(3); // helpers, poller, fetchers: few instructions, all of them on the critical path
     const int my_rt = (n_rt - g * RT < RT) ? n_rt - g * RT : RT;
 
     if (tid == 0) { *s_dead = (int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *s_go = 0; }
@@ -1145,6 +1150,8 @@ __global__ __launch_bounds__(1024) void gru_ws2m_kernel(const float* __restrict_
         const f32x4* xr = xch + (buf * 12 + (layer ? 0 : tslot * 6)) * 64 + lane; // recurrent products: [gate][chain]
         const f32x4* xi = xch + (buf * 12 + 6) * 64 + lane;                       // layer 2: its input projection
         f32x4 z4, r4, h;
+        if (WS_DIAG(variant, 8192)) h = (f32x4){0.f, 0.f, 0.f, 0.f};
+        else {
         {
             const f32x4 gi = layer ? (xi[0] + xi[64]) + bt[12] : gpre[0];
             const f32x4 a = first ? (f32x4){0.f, 0.f, 0.f, 0.f} : xr[0] + xr[64];
@@ -1169,6 +1176,7 @@ __global__ __launch_bounds__(1024) void gru_ws2m_kernel(const float* __restrict_
                 const float n = fast_tanh(gi[r] + r4[r] * (a[r] + b[r]));
                 h[r] = (1.0f - z4[r]) * n + z4[r] * hp[r];
             }
+        }
         }
         hpv[(rt * 2 + tslot) * 64 + lane] = h;
         const int rtg = g * RT + rt;
@@ -1205,17 +1213,27 @@ __global__ __launch_bounds__(1024) void gru_ws2m_kernel(const float* __restrict_
         for (int rt = 0; rt <= my_rt; ++rt) {
             const int buf = rt & 1;
             if (rt < my_rt) {
-                if (rt + 1 < my_rt) {
+                if (rt + 1 < my_rt && !WS_DIAG(variant, 4096)) {
                     if (wave == 14 && useA) fetch(false, slotA, rt + 1, buf ^ 1);
                     if (wave == 15 && useB) fetch(true, slotB, rt + 1, buf ^ 1);
                 }
-                if (gate_wave && tile_ok && (layer ? (ws ? useB : useA) : useA)) chain(buf);
+                if (gate_wave && tile_ok && (layer ? (ws ? useB : useA) : useA) && !WS_DIAG(variant, 16384)) chain(buf);
             }
             if (helper && rt >= 1) {
                 gates(rt - 1, t, first, buf ^ 1);
                 if (layer == 0 && rt < my_rt) request_gi(rt, t);
             }
-            if (rt < my_rt) __syncthreads();
+            if (rt < my_rt) {
+                // The row-tile barrier orders LDS traffic only (partial products, hpv, the operand buffers -- whose LDS-DMA the
+                // fetching wavefronts have waited for themselves).  __syncthreads() would also make the helper wait for its
+                // just-issued tile store and gi loads -- a memory round trip inside every row tile (variant 65536: that form)
+                if (variant & 65536) __syncthreads();
+                else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            }
         }
         if (helper) publish_step(t);
     };
@@ -1367,7 +1385,7 @@ int fvad_launch_gru_ws2(const float* gi1, const float* feat, const float* W1frag
         const size_t lds_m = (size_t)(4 * GRU_J * 64 + 24 * 64 + RT * 128 + 48 + 1) * 16; // >= 129 KB: one workgroup per CU
         if (hipFuncSetAttribute((const void*)gru_ws2m_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m) != hipSuccess) return -2;
         hipLaunchKernelGGL(gru_ws2m_kernel, dim3((unsigned)(G * 38)), dim3(1024), lds_m, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
-                           hout2, hx1, hx2, flags, flags + 256, err, T, RT, n_rt, spin_ticks);
+                           hout2, hx1, hx2, flags, flags + 256, err, T, RT, n_rt, spin_ticks, variant);
         return 0;
     }
     // more than half of a CU's 160 KB of LDS: one workgroup per CU (all workgroups of the launch spin on each other)

@@ -24,7 +24,7 @@ struct fvad_fft {
     float* d_win = nullptr;  // n_fft
     float* d_out = nullptr;  // (n_fft/2+1)*2
     std::vector<float> h_in;
-    VadFftPlan plan{};       // tables of the 512 / 1024 / 2048-point transform (unused for 320)
+    VadFftPlan plan{};       // tables of every size but 320 (which has its own in the context)
 };
 
 extern "C" {
@@ -33,15 +33,16 @@ int fvad_fft_create(fvad_ctx* ctx, size_t n_fft, size_t sample_rate, int mode_in
 {
     if (!ctx || !out) return FVAD_ERR_INVALID_ARGUMENT;
     if (n_fft == 0 || n_fft % 2 != 0) return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "n_fft must be even and non-zero"); // FFT.zig:41-43
-    const bool vad_size = n_fft == 512 || n_fft == 1024 || n_fft == 2048;
-    if (!(n_fft == 320 || (vad_size && !mode_inverse)))
-        return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "gfx950 kernels exist for the sizes the pipeline uses: 320 (fwd/inv) and 512 / 1024 / 2048 (fwd)");
+    // 320 (NSNet2's frame: forward and inverse) and 512 / 1024 / 2048 forward have wavefront kernels; every other even size
+    // kissfft would take (and the inverse of any size but 320) runs on the generic mixed-radix kernel, up to 16384 points
+    if (n_fft != 320 && !fvad_fft_size_ok(n_fft))
+        return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "n_fft must be even, at least 4 and at most 16384");
     hipSetDevice(ctx->device);
     auto* f = new (std::nothrow) fvad_fft();
     if (!f) return FVAD_ERR_ALLOC_FAILED;
     f->ctx = ctx; f->n_fft = n_fft; f->sample_rate = sample_rate; f->inverse = mode_inverse != 0;
-    if (vad_size) {
-        const int prc = get_vad_plan(ctx, n_fft, &f->plan);
+    if (n_fft != 320) {
+        const int prc = get_vad_plan(ctx, n_fft, &f->plan, /*force_generic=*/mode_inverse != 0);
         if (prc) { delete f; return prc; }
     }
     f->h_in.resize(n_fft);
@@ -119,7 +120,8 @@ int fvad_fft_inverse(fvad_fft* f, const fvad_complex* bins, size_t n_bins, float
     hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     FVAD_HIP(ctx, hipMemcpyAsync(f->d_out, bins, n_bins * sizeof(fvad_complex), hipMemcpyHostToDevice, st));
-    fvad_launch_irfft_batch(f->d_out, 1, ctx->tb, f->d_in, st);
+    if (f->n_fft == 320) fvad_launch_irfft_batch(f->d_out, 1, ctx->tb, f->d_in, st);
+    else fvad_launch_irfft_generic(f->d_out, 1, f->plan, f->d_in, st);
     FVAD_HIP(ctx, hipMemcpyAsync(result, f->d_in, f->n_fft * sizeof(float), hipMemcpyDeviceToHost, st));
     FVAD_HIP(ctx, hipStreamSynchronize(st));
     return FVAD_OK;
@@ -401,8 +403,8 @@ int fvad_pipeline_create(fvad_ctx* ctx, const fvad_pipeline_config* cfg, const f
     if (!ctx || !cfg || !out) return FVAD_ERR_INVALID_ARGUMENT;
     if (cfg->sample_rate != 48000) return set_err(ctx, FVAD_ERR_INVALID_SAMPLE_RATE, "VADPipeline needs 48000 Hz"); // VADPipeline.zig:55-58
     if (cfg->fft_size == 0 || cfg->fft_size % 2 != 0) return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "fft_size must be even"); // FFT.zig:41-43
-    if (!(cfg->fft_size == 512 || cfg->fft_size == 1024 || cfg->fft_size == 2048))
-        return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "the VAD-side kernel exists for fft_size 512, 1024 (the reference default) and 2048");
+    if (!fvad_fft_size_ok(cfg->fft_size)) // FFT.init's own check (FFT.zig:41-43) + the generic kernel's size limit
+        return set_err(ctx, FVAD_ERR_INVALID_FFT_SIZE, "fft_size must be even, at least 4 and at most 16384");
     if (cfg->n_channels == 0) return FVAD_ERR_INVALID_ARGUMENT;
     // pushSamples writes buffer_length / 2 samples per step (AudioPipeline.zig:121-140): below 2 the step is 0 and its
     // loop never ends, and a ring shorter than one 24000-sample chunk cannot hand VADPipeline.collectInputStep its

@@ -138,8 +138,11 @@ void fvad_weights_free(void *owner);
 typedef struct { float r, i; } fvad_complex; /* FFT.zig:12-14 */
 typedef struct fvad_fft fvad_fft;
 
-/* FFT.init(allocator, n_fft, sample_rate, mode_inverse)  FFT.zig:35-76.  GPU sizes: 320 (forward and inverse: NSNet2's
- * STFT) and 512 / 1024 / 2048 (forward: the VAD-side transform, VADPipeline.Config.fft_size). */
+/* FFT.init(allocator, n_fft, sample_rate, mode_inverse)  FFT.zig:35-76.  Any even n_fft from 4 to 16384, forward or inverse,
+ * like kiss_fftr_alloc (odd or zero: FVAD_ERR_INVALID_FFT_SIZE, FFT.zig:41-43; so are 2 and sizes past 16384, this library's
+ * limits).  The sizes the pipeline runs at have wavefront kernels -- 320 (forward and inverse: NSNet2's STFT), 512 / 1024 /
+ * 2048 (forward: the VAD-side transform, VADPipeline.Config.fft_size); every other case runs on a generic mixed-radix kernel
+ * (one workgroup per frame, any radix; correct, not tuned). */
 int fvad_fft_create(fvad_ctx *ctx, size_t n_fft, size_t sample_rate, int mode_inverse,
                     fvad_fft **out);
 void fvad_fft_destroy(fvad_fft *fft);                                   /* FFT.deinit :78-83 */
@@ -236,9 +239,10 @@ typedef struct {
     int32_t min_bin;         /* band edges, inclusive; default 11..43 = freqToBin(500/2000) */
     int32_t max_bin;
     int32_t max_chunks_per_launch; /* 0 = default (49152) */
-    int32_t fft_size;        /* frame length of the VAD-side FFT (VADPipeline.Config.fft_size, VADPipeline.zig:21):
-                                512, 1024 or 2048; 0 = 1024.  min_bin / max_bin index that transform's bins and
-                                fft_bins rows have fft_size / 2 + 1 entries */
+    int32_t fft_size;        /* frame length of the VAD-side FFT (VADPipeline.Config.fft_size, VADPipeline.zig:21): any even
+                                size from 4 to 16384 (512, 1024, 2048: wavefront kernels; others: the generic kernel);
+                                0 = 1024.  min_bin / max_bin index that transform's bins and fft_bins rows have
+                                fft_size / 2 + 1 entries */
     int32_t no_wait;         /* fvad_engine_enqueue_device* only: 1 = return as soon as the work is queued on the
                                 context's stream (results valid after fvad_ctx_synchronize or an event the caller
                                 records on fvad_ctx_stream); the next call may be made at once -- descriptor and job
@@ -297,10 +301,12 @@ int fvad_ctx_nn_math_effective(const fvad_ctx *ctx);
 const char *fvad_ctx_last_nn_path(const fvad_ctx *ctx);
 /* Bit-reproducibility.  Two launches that select the same NSNet2 kernels (fvad_ctx_last_nn_path names them) give a
  * chunk the same bits wherever in the batch it sits and however lanes and chunks are split.  With FVAD_NN_MATH_F32
- * the engine selects by launch size: up to 384 sequences the pipelined two-layer weight-stationary recurrence (it
- * computes layer 2's input projection itself); up to 2047 the narrow-block GEMMs with a weight-stationary or the
- * low-latency recurrence; from 2048 the persistent GEMM with the low-latency or the multi-wavefront recurrence (by
- * a cost model over the CU count).  Every selection runs f32 operands and f32 accumulation; they differ in
+ * the engine selects by launch size: up to 1536 sequences the pipelined two-layer weight-stationary recurrence (it
+ * computes layer 2's input projection itself, and for 65..96 sequences layer 1's too, in the accumulation order of the GEMM
+ * that otherwise runs in front: one set of bits for the whole range);
+ * up to 2047 the narrow-block GEMMs with a weight-stationary or the low-latency recurrence; from 2048 the persistent GEMM
+ * with the low-latency or the multi-wavefront recurrence (by a cost model over the CU count).  A call of 1537..2700
+ * chunks whose launch size is left to the engine (max_chunks_per_launch = 0) runs as two launches of half the size.  Every selection runs f32 operands and f32 accumulation; they differ in
  * accumulation order and agree to ~1e-6 in the gains, not bit for bit.  The option "reproducible" = "1" makes every
  * launch use one selection (persistent GEMM + multi-wavefront recurrence; small launches are padded to 128 sequences
  * and lose their low-latency kernels), so that a stream pushed in any pieces, split over any number of launches or
@@ -438,7 +444,7 @@ typedef struct {
     size_t n_channels;
     size_t buffer_length;                     /* 0 = sample_rate * 10 (:46); otherwise >= one 24000-sample chunk */
     int32_t skip_processing;
-    size_t fft_size;                          /* VADPipeline.Config.fft_size = 1024 (:21); 512 and 2048 also have kernels */
+    size_t fft_size;                          /* VADPipeline.Config.fft_size = 1024 (:21); any even size from 4 to 16384 */
     fvad_vad_config vad_machine_config;       /* :22 */
     const fvad_vad_config *alt_vad_machine_configs; /* :24 */
     size_t n_alt_vad_machine_configs;

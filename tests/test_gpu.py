@@ -129,6 +129,36 @@ def test_inverse_fft_unscaled_like_kissfft(fv, gpu_ctx):
     assert e.value.status == -4
 
 
+@pytest.mark.parametrize("n_fft", [4, 6, 250, 254, 960, 1000, 1024, 4096, 6250, 16384])
+def test_fft_any_even_size_matches_oracle(fv, gpu_ctx, n_fft):
+    # B3: FFT.init(n_fft) for any even size (FFT.zig:35-60 -> kiss_fftr_alloc), forward and inverse, single frames and
+    # batches: 4 and 6 (the smallest), 250 = 2 x 5^3, 254 = 2 x 127, 960, 1000, 6250 = 2 x 5^5, the powers of two, the
+    # largest the generic kernel takes.  1024 forward runs on its wavefront kernel, its inverse on the generic one.
+    rng = np.random.default_rng(n_fft)
+    f = fv.FFT(gpu_ctx, n_fft, 48000)
+    fi = fv.FFT(gpu_ctx, n_fft, 48000, inverse=True)
+    assert f.bin_count() == n_fft // 2 + 1
+    w = rng.uniform(0.2, 1.0, n_fft).astype(np.float32)
+    x = rng.uniform(-1, 1, (5, n_fft)).astype(np.float32)
+    ref = np.stack([orc.rfft(r * w) for r in x])
+    assert_bins_close(f.fft(x[0], w), ref[0], f"rfft{n_fft}")
+    assert_bins_close(f.fft(x[1][: n_fft // 3], w, second=x[1][n_fft // 3:]), ref[1], f"rfft{n_fft} SplitSlice")
+    b, m = f.fft_batch(x, w)
+    assert_bins_close(b, ref, f"rfft{n_fft} batch")
+    assert np.abs(m - np.abs(ref)).max() <= 1e-4 * np.abs(ref).max()
+    for k in range(2):
+        y = fi.inv_fft(ref[k])
+        want = orc.irfft_unscaled(ref[k], n_fft)
+        assert np.abs(y - want).max() <= 1e-5 * np.abs(want).max(), n_fft
+        assert np.abs(y / n_fft - x[k] * w).max() < 3e-6 * max(1.0, np.log2(n_fft)), n_fft   # inverse(forward(x)) == n x
+    f.close()
+    fi.close()
+    for bad in (2, 7, 16386):
+        with pytest.raises(fv.FvadError) as e:
+            fv.FFT(gpu_ctx, bad, 48000)
+        assert e.value.status == -1                  # InvalidFFTSize
+
+
 def test_config2_fft_isolation_1024_frames(fv, gpu_ctx):
     # BASELINE config 2: 1024 frames x 320, U(-1,1), seed 1 -> bins + magnitudes
     rng = np.random.default_rng(1)
@@ -949,7 +979,8 @@ def test_pipeline_stereo_channel_ratio_near_threshold(fv, gpu_ctx, weights7, pkg
     assert_rel(ratio, ref.frame_vol_ratio(), 1e-4, what="volume ratio near 0.5")
     assert 0.5 < ratio.min() and ratio.max() < 0.51
     segs, segs_ref = p.segments(), ref.segments()
-    assert len(segs_ref) >= 2 and [(s[0], s[1]) for s in segs] == [(s[0], s[1]) for s in segs_ref]
+    assert [(s[0], s[1]) for s in segs] == [(s[0], s[1]) for s in segs_ref]
+    assert len(segs_ref) >= 2 or fft_size < 512      # (nine 189 Hz bins at fft_size 254: the synthetic bursts do not trip the detector)
     _, ratio_margin, _ = p.audit()
     # the closest frame is further from 0.5 than 10x the largest GPU/oracle ratio difference seen
     worst = np.abs(ratio - ref.frame_vol_ratio()).max()
@@ -965,7 +996,7 @@ def test_pipeline_errors_and_skip_processing(fv, gpu_ctx):
         fv.AudioPipeline(gpu_ctx, fft_size=1023)
     assert e.value.status == -1
     with pytest.raises(fv.FvadError) as e:
-        fv.AudioPipeline(gpu_ctx, fft_size=4096)   # even, but no kernel: 512 / 1024 / 2048 only
+        fv.AudioPipeline(gpu_ctx, fft_size=32768)  # even, but past the generic kernel's 16384 points
     assert e.value.status == -1
     p = fv.AudioPipeline(gpu_ctx, skip_processing=True)
     assert p.push_samples(np.zeros((1, 50000), np.float32)) == 0
@@ -1535,11 +1566,13 @@ def test_nsnet2_saturated_gates_match_oracle(fv, weights7):
 
 
 # ------------------------------------------------------------------ VADPipeline.Config.fft_size (VADPipeline.zig:21)
-@pytest.mark.parametrize("fft_size", [512, 2048])
+@pytest.mark.parametrize("fft_size", [512, 2048, 960, 1000, 4096, 254])
 def test_pipeline_other_fft_sizes_match_oracle(fv, gpu_ctx, weights7, pkg, fft_size):
-    # fft_size is a user field of the reference's VADPipeline.Config: besides the default 1024 the VAD-side
-    # transform has kernels for 512 and 2048 (band edges, frame indices, metadata weights and the state machine's
-    # ring lengths all follow it).  Stereo stream, uneven pushes, segments bit-identical to the oracle.
+    # fft_size is a user field of the reference's VADPipeline.Config and FFT.init takes any even size kissfft factors
+    # (FFT.zig:35-60): besides the default 1024 the VAD-side transform has wavefront kernels for 512 and 2048 and a
+    # generic mixed-radix kernel for every other even size up to 16384 -- 960 = 2^6 3 5, 1000 = 2^3 5^3, 4096,
+    # 254 = 2 x 127 (a prime radix) -- with band edges, frame indices, metadata weights and the state machine's ring
+    # lengths all following it.  Stereo stream, uneven pushes, segments bit-identical to the oracle.
     pcm, _ = pkg.synth.make_stream(70.0, seed=48, n_channels=2)
     ref = orc.Pipeline(weights7, n_channels=2, fft_size=fft_size)
     ref.push(pcm)
@@ -1554,7 +1587,8 @@ def test_pipeline_other_fft_sizes_match_oracle(fv, gpu_ctx, weights7, pkg, fft_s
     assert_rel(band, ref.band_volumes(), 1e-4, what=f"band volumes fft {fft_size}")
     assert_rel(ratio, ref.frame_vol_ratio(), 1e-4, what="volume ratio")
     segs, segs_ref = p.segments(), ref.segments()
-    assert len(segs_ref) >= 2 and [(s[0], s[1]) for s in segs] == [(s[0], s[1]) for s in segs_ref]
+    assert [(s[0], s[1]) for s in segs] == [(s[0], s[1]) for s in segs_ref]
+    assert len(segs_ref) >= 2 or fft_size < 512      # (nine 189 Hz bins at fft_size 254: the synthetic bursts do not trip the detector)
     # the FFT object of that size (B3) and the engine's full-spectrum tap
     f = fv.FFT(gpu_ctx, fft_size, 48000)
     wp = orc.hann_periodic(fft_size)
@@ -1639,13 +1673,13 @@ ctx.set_option("ws_spin_ticks", None)
 assert np.array_equal(g2, lat), np.abs(g2 - lat).max()
 assert np.abs(p2 - lat).max() <= 2e-6              # its own family: layer 2's input projection is computed in the kernel
 assert (np.abs(g[:3] - ref) / np.maximum(np.abs(ref), 1e-2)).max() <= 1e-4
-# 82 sequences = one row tile per group: the 16-wavefront form of the pipelined kernel (gru_ws2k_kernel), which computes
-# layer 1's input projection too (two chains + bias instead of the GEMM's one chain: its own bits, round-off apart from
-# the 8-wavefront form behind a GEMM, which ws2_variant 8 forces); same fallback chain behind it
+# 82 sequences = one row tile per group: the 16-wavefront form of the pipelined kernel (gru_ws2k_kernel), which in groups of
+# 13 + 25 computes layer 1's input projection too, in the GEMM's accumulation order: the bits of the 8-wavefront form behind
+# a GEMM (which ws2_variant 8 forces) and of every other pipelined launch; same fallback chain behind it
 f82 = f[:82]
 k16 = ctx.nsnet2_forward(f82)
 assert "gru_ws2k" in ctx.last_nn_path() and "both input projections" in ctx.last_nn_path(), ctx.last_nn_path()
-assert np.abs(k16 - p2[:82]).max() <= 2e-6
+assert np.array_equal(k16, p2[:82])                                   # the in-kernel projection keeps the GEMM's accumulation order: same bits
 assert np.array_equal(ctx.nsnet2_forward(f[40:122])[:42], k16[40:])   # a sequence's bits do not depend on where in a batch it sits
 ctx.set_option("ws2_variant", "8")
 assert np.array_equal(ctx.nsnet2_forward(f82), p2[:82])               # the 8-wavefront kernel: the bits of the 130-sequence launch
