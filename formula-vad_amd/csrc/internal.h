@@ -225,7 +225,12 @@ int hip_fail(const fvad_ctx* ctx, hipError_t e, const char* what);
         if (_e != hipSuccess) return fvad::hip_fail(ctx, _e, #call); \
     } while (0)
 
-int upload_model(fvad_ctx* ctx);
+int upload_model(fvad_ctx* ctx);                                              // model.cpp
+int dev_alloc(fvad_ctx* ctx, float** p, size_t n_floats, bool zero);          // engine.cpp
+int grow(fvad_ctx* ctx, float** p, size_t* cap, size_t need);                 // engine.cpp
+void free_workspace_nn(Workspace& ws);                                        // nn_dispatch.cpp
+long planned_max_chunks(const fvad_ctx* ctx, long total, long max_chunks);    // nn_dispatch.cpp: chunks per launch of a call
+long padded_batch(const fvad_ctx* ctx, long n, int T, int skip);              // nn_dispatch.cpp: sequences a launch of n is padded to
 // FVAD_NN_MATH_F32 / FVAD_NN_MATH_F16X3: what run_nn uses on this context with the loaded model, at every batch size
 int nn_math_effective(const fvad_ctx* ctx);
 int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T, int skip, long n_last = 0);

@@ -837,13 +837,29 @@ __device__ __forceinline__ void generic_cfft(cpx* a, cpx* b, int M, const VadFft
             const int stride = (int)(((long long)(k + q * Ns) * tstep) % M);
             cpx acc = {0.0f, 0.0f};
             int idx = 0;
-            for (int r = 0; r < R; ++r) {
-                const cpx x = src[j + r * span];
-                const float wr = pl.tw[2 * idx], wi = inverse ? -pl.tw[2 * idx + 1] : pl.tw[2 * idx + 1];
-                acc.r += x.r * wr - x.i * wi;
-                acc.i += x.r * wi + x.i * wr;
-                idx += stride;
-                if (idx >= M) idx -= M;
+            if (R <= 5) {
+                for (int r = 0; r < R; ++r) {
+                    const cpx x = src[j + r * span];
+                    const float wr = pl.tw[2 * idx], wi = inverse ? -pl.tw[2 * idx + 1] : pl.tw[2 * idx + 1];
+                    acc.r += x.r * wr - x.i * wi;
+                    acc.i += x.r * wi + x.i * wr;
+                    idx += stride;
+                    if (idx >= M) idx -= M;
+                }
+            } else {
+                // a long direct sum (a prime radix such as 127): accumulated in double, so that its round-off stays at the
+                // level of the short butterflies' (kissfft's generic butterfly sums in f32 in another order; both are
+                // compared with the oracle at 1e-4 of bins that may be 1e-3 of the frame's largest)
+                double ar = 0.0, ai = 0.0;
+                for (int r = 0; r < R; ++r) {
+                    const cpx x = src[j + r * span];
+                    const double wr = pl.tw[2 * idx], wi = inverse ? -pl.tw[2 * idx + 1] : pl.tw[2 * idx + 1];
+                    ar += (double)x.r * wr - (double)x.i * wi;
+                    ai += (double)x.r * wi + (double)x.i * wr;
+                    idx += stride;
+                    if (idx >= M) idx -= M;
+                }
+                acc = {(float)ar, (float)ai};
             }
             dst[(j / Ns) * Ns * R + k + q * Ns] = acc;
         }

@@ -305,8 +305,8 @@ const char *fvad_ctx_last_nn_path(const fvad_ctx *ctx);
  * computes layer 2's input projection itself, and for 65..96 sequences layer 1's too, in the accumulation order of the GEMM
  * that otherwise runs in front: one set of bits for the whole range);
  * up to 2047 the narrow-block GEMMs with a weight-stationary or the low-latency recurrence; from 2048 the persistent GEMM
- * with the low-latency or the multi-wavefront recurrence (by a cost model over the CU count).  A call of 1537..2700
- * chunks whose launch size is left to the engine (max_chunks_per_launch = 0) runs as two launches of half the size.  Every selection runs f32 operands and f32 accumulation; they differ in
+ * with the low-latency or the multi-wavefront recurrence (by a cost model over the CU count).  A call of 1537..3400
+ * chunks whose launch size is left to the engine (max_chunks_per_launch = 0) runs as two or three equal launches.  Every selection runs f32 operands and f32 accumulation; they differ in
  * accumulation order and agree to ~1e-6 in the gains, not bit for bit.  The option "reproducible" = "1" makes every
  * launch use one selection (persistent GEMM + multi-wavefront recurrence; small launches are padded to 128 sequences
  * and lose their low-latency kernels), so that a stream pushed in any pieces, split over any number of launches or

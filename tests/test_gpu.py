@@ -1432,7 +1432,7 @@ def test_launch_size_does_not_change_the_arithmetic(fv, gpu_ctx, pkg):
         with gpu_ctx.options(nn_math=math, no_pipeline="1"):
             assert gpu_ctx.nn_math_effective() == math
             # (an explicit launch size: left to itself the f32 engine plans a 2304-chunk call as two launches of 1152, which
-            # stay on the pipelined small-batch recurrence -- engine.cpp planned_max_chunks)
+            # stay on the pipelined small-batch recurrence -- nn_dispatch.cpp planned_max_chunks)
             p1, whole = one(max_chunks_per_launch=49152)
             p2, split = one(max_chunks_per_launch=1024)
             two = pushes()
@@ -1510,7 +1510,8 @@ def test_new_entry_points_reject_bad_arguments(fv, gpu_ctx):
     L = fv.lib()
     st = gpu_ctx.lane_state()
     assert L.fvad_lane_state_seek(st, 24000 * 3 + 1, 0) == fv.FVAD_ERR_INVALID_ARGUMENT     # chunk boundaries only
-    assert L.fvad_lane_state_seek(st, 24000 * 3, 1024) == 0 and L.fvad_lane_state_seek(st, 0, 1000) == fv.FVAD_ERR_INVALID_ARGUMENT
+    assert L.fvad_lane_state_seek(st, 24000 * 3, 1024) == 0 and L.fvad_lane_state_seek(st, 0, 1001) == fv.FVAD_ERR_INVALID_ARGUMENT   # even sizes only
+    assert L.fvad_lane_state_seek(st, 0, 1000) == 0 and L.fvad_lane_state_seek(st, 0, 32768) == fv.FVAD_ERR_INVALID_ARGUMENT
     L.fvad_lane_state_destroy(st)
     d = gpu_ctx.device_alloc(24000 * 2 * 2 + 64)
     db = gpu_ctx.device_alloc(4096)
@@ -1603,7 +1604,19 @@ def test_pipeline_other_fft_sizes_match_oracle(fv, gpu_ctx, weights7, pkg, fft_s
     r1.push(lane[None])
     bins_ref = np.stack([r1.fft_bins(k) for k in range(o["n_fft_frames"])])
     assert o["fft_bins"].shape == bins_ref.shape == (72000 // fft_size, fft_size // 2 + 1)
-    assert_rel(o["fft_bins"], bins_ref, 1e-4, floor=1e-3 * bins_ref.max(), what="|X| tap")
+    # (a prime radix -- 254 = 2 x 127 -- is a 127-term f32 sum in kissfft's generic butterfly and in the oracle's restatement of
+    # it: its own round-off is ~1e-7 of the frame's largest bin, which is 1e-4 of a bin at 1e-3 of it: the floor is 1e-2 there)
+    floor = (1e-3 if max(orc_prime_factors(fft_size // 2)) <= 5 else 1e-2) * bins_ref.max()
+    assert_rel(o["fft_bins"], bins_ref, 1e-4, floor=floor, what="|X| tap")
+
+
+def orc_prime_factors(n):
+    out, p = [], 2
+    while n > 1:
+        while n % p == 0:
+            out.append(p); n //= p
+        p += 1
+    return out or [1]
 
 
 def test_weight_stationary_handoff_is_deterministic_under_load(fv, gpu_ctx, weights7):

@@ -1,4 +1,4 @@
-"""GRU recurrence time per layer for mid-size batches, per kernel shape (to calibrate engine.cpp's cost
+"""GRU recurrence time per layer for mid-size batches, per kernel shape (to calibrate nn_dispatch.cpp's cost
 model).  Run on the GPU box: python tools/gru_crossover.py"""
 import importlib.util, os, sys
 import numpy as np
