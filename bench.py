@@ -893,6 +893,22 @@ def side_measurements(pkg, fv, ctx, torch, dev):
         cfg3_graph_ms = (time.perf_counter() - t0) / 100 * 1e3
     except Exception as e:
         cfg3_graph_ms = repr(e)
+    # the same 100 calls after the context option ws2_calibrate measured the first-poll waits on this device (include/fvad.h)
+    cfg3_cal = None
+    try:
+        ctx.set_option("ws2_calibrate", 1)
+        for it in range(4 + 100):
+            if it == 4:
+                ctx.synchronize()
+                t0 = time.perf_counter()
+            L.fvad_engine_enqueue_device(ctx.h, d.data_ptr(), 2, d.stride(0), 41 * CHUNK, None, band.data_ptr(), rms.data_ptr(), None)
+        ctx.synchronize()
+        cfg3_cal = {"ms": (time.perf_counter() - t0) / 100 * 1e3,
+                    "waits_10ns_ticks": {"groups_25_25": list(ctx.ws2_waits(1)), "groups_13_25_gi1_in_kernel": list(ctx.ws2_waits(3))}}
+        ctx.set_option("ws2_calibrate", 0)
+        cfg3_cal["table"] = {"groups_25_25": list(ctx.ws2_waits(1)), "groups_13_25_gi1_in_kernel": list(ctx.ws2_waits(3))}
+    except Exception as e:
+        cfg3_cal = {"error": repr(e)}
     # host-buffer entry point (what AudioPipeline.pushSamples hands over): H2D of the 48 kHz input, the
     # kernels, D2H of band sums / RMS (and of the denoised audio in the second figure).  Pageable numpy
     # buffers, staged by the library; never `value`.
@@ -1066,7 +1082,7 @@ def side_measurements(pkg, fv, ctx, torch, dev):
     except Exception as e:
         extra["batch_curve"] = {"error": repr(e)}
     extra["cfg3_82_chunks_4100_frames"] = {"ms": dt * 1e3, "frames_per_s": 4100 / dt, "ms_as_hipgraph_replay": cfg3_graph_ms,
-                                           "nn_path": cfg3_path,
+                                           "after_ws2_calibrate": cfg3_cal, "nn_path": cfg3_path,
                                            "note": "mean of 100 calls; latency-bound: 55 dependent, exchange-bound steps over only 82 sequences (gru_ws2k_kernel: both GRU layers in one launch, layer 2 a step behind layer 1, recurrent weights stationary in registers across 228 workgroups of 16 wavefronts, h exchanged per step)"}
     return extra
 

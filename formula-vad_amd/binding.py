@@ -197,6 +197,7 @@ SIGNATURES = {
     "fvad_ctx_last_nn_path": (C.c_char_p, [vp]),
     "fvad_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
     "fvad_ctx_ws_fallbacks": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+    "fvad_ctx_ws2_waits": (C.c_uint32, [vp, C.c_int]),
     "fvad_ctx_kernel_times": (C.c_int, [vp, C.POINTER(C.c_char_p), c_float_p, sz,
                                         C.POINTER(sz)]),
     "fvad_vad_config_default": (None, [C.POINTER(VadConfig)]),
@@ -422,6 +423,11 @@ class Context:
         n = C.c_uint64(0)
         self._ck(lib().fvad_ctx_ws_fallbacks(self.h, C.byref(n)), "fvad_ctx_ws_fallbacks")
         return n.value
+
+    def ws2_waits(self, wait_class):
+        """(layer 1, layer 2) first-poll waits of gru_ws2k in 10 ns ticks for a group-shape class (fvad_ctx_ws2_waits)"""
+        w = lib().fvad_ctx_ws2_waits(self.h, wait_class)
+        return w & 0xFFFF, w >> 16
 
     def enable_timing(self, on=True):
         self._ck(lib().fvad_ctx_enable_timing(self.h, 1 if on else 0), "fvad_ctx_enable_timing")

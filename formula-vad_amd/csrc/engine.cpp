@@ -155,13 +155,22 @@ static int apply_option(fvad_ctx* ctx, const std::string& name, const char* valu
         }
     } else if (name == "ws2_variant") { // shape / timing knobs of the pipelined recurrence (tools/ws2_variants.py, ws2_delay.py)
         long c = 0;
-        if (!unset && (!to_long(c) || c < 0 || c >= (1 << 25))) return FVAD_ERR_INVALID_ARGUMENT;
+        if (!unset && (!to_long(c) || c < 0 || c >= (1 << 24))) return FVAD_ERR_INVALID_ARGUMENT;
 #if !FVAD_DIAG
         // the timing-only bits (1, 2, 4, 32: WRONG results) and the step trace (64) exist in the diagnostics build only
         // (make diag -> libfvad_hip_diag.so); the shipping library has no way to ask for wrong results
         if (c & (1 | 2 | 4 | 32 | 64 | 256 | 512 | 4096 | 8192 | 16384)) return FVAD_ERR_INVALID_ARGUMENT;
 #endif
         tn.ws2_variant = (int)c;
+    } else if (name == "ws2_waits") { // gru_ws2k's first-poll waits: layer 1 | layer 2 << 16, in 10 ns ticks; unset / 0 = built in (or calibrated)
+        long c = 0;
+        if (!unset && (!to_long(c) || c < 0 || c > 0x7FFFFFFFL)) return FVAD_ERR_INVALID_ARGUMENT;
+        tn.ws2_waits = (unsigned)c;
+    } else if (name == "ws2_calibrate") { // 1: measure those waits on this device now (needs the model); unset / 0: forget the measurement
+        bool on = false;
+        if (!to_bool(on)) return FVAD_ERR_INVALID_ARGUMENT;
+        for (unsigned& w : tn.ws2_waits_cal) w = 0;
+        if (on) { const int rc = calibrate_ws2_waits(ctx); if (rc) return rc; }
     } else if (name == "no_pipeline") { if (!to_bool(tn.no_pipeline)) return FVAD_ERR_INVALID_ARGUMENT; }
     else if (name == "trace_kernels") { if (!to_bool(tn.trace_kernels)) return FVAD_ERR_INVALID_ARGUMENT; }
     else if (name == "reproducible") { if (!to_bool(tn.reproducible)) return FVAD_ERR_INVALID_ARGUMENT; }
@@ -420,6 +429,13 @@ int fvad_debug_ws_trace(fvad_ctx* ctx, uint32_t* out, int n_words)
     return FVAD_OK;
 }
 
+uint32_t fvad_ctx_ws2_waits(const fvad_ctx* ctx, int wait_class)
+{
+    if (!ctx || wait_class < 1 || wait_class > 3) return 0;
+    const Tuning& tn = ctx->tune;
+    return tn.ws2_waits ? tn.ws2_waits : tn.ws2_waits_cal[wait_class] ? tn.ws2_waits_cal[wait_class] : fvad_gru_ws2_builtin_waits(wait_class);
+}
+
 int fvad_ctx_ws_fallbacks(fvad_ctx* ctx, uint64_t* n)
 {
     if (!ctx || !n) return FVAD_ERR_INVALID_ARGUMENT;
@@ -437,6 +453,7 @@ int fvad_ctx_set_option(fvad_ctx* ctx, const char* name, const char* value)
 {
     if (!ctx || !name) return FVAD_ERR_INVALID_ARGUMENT;
     const int rc = apply_option(ctx, name, value);
+    if (rc && !strcmp(name, "ws2_calibrate") && value && !strcmp(value, "1")) return rc; // the measurement failed: its own message stands
     if (rc) return set_err(ctx, rc, std::string("fvad_ctx_set_option: unknown option or bad value: ") + name + "=" + (value ? value : ""));
     return FVAD_OK;
 }

@@ -170,6 +170,8 @@ struct Tuning {
     bool trace_kernels = false;  // name every NSNet2 stage on stderr and wait for it
     bool reproducible = false;   // one kernel family (the large-batch one) at every batch size
     int ws2_variant = 0;         // timing-only variants of gru_ws2_kernel (tools/ws2_variants.py); 0 in production
+    unsigned ws2_waits = 0;      // gru_ws2k's first-poll waits for every launch (layer 1 | layer 2 << 16, 10 ns ticks); 0 = per class:
+    unsigned ws2_waits_cal[4] = {0, 0, 0, 0}; // what ws2_calibrate measured for fvad_gru_ws2_wait_class 1..3; 0 = the kernel's built-in table
     // spin deadline of the weight-stationary kernels' waits in 100 MHz ticks.  Default (ws_spin_auto): derived per launch from
     // the launch's own expected duration -- 20 x the cost model's estimate, at least 2 ms -- so that a launch that cannot make
     // progress (another process holds the CUs its workgroups need) costs milliseconds, not the 0.25 s of a fixed deadline
@@ -241,6 +243,7 @@ int get_vad_plan(fvad_ctx* ctx, size_t n, VadFftPlan* out, bool force_generic = 
 bool fvad_fft_size_ok(size_t n); // even, 4 .. kVadFftMax
 // NSNet2 on ws.feat -> ws.gains for n_chunks sequences of T rows; gains rows skip..T-1 only
 int run_nn(fvad_ctx* ctx, long n_chunks_pad, int T, int skip);
+int calibrate_ws2_waits(fvad_ctx* ctx);
 
 struct LaneJob {
     const float* d_in;   // device, n_chunks * 24000 samples (480 samples of history are read

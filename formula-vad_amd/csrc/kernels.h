@@ -137,7 +137,11 @@ const char* fvad_gru_ws2_kernel_name(long n_seq_pad, int T, int n_cu, int varian
 int fvad_launch_gru_ws2(const float* gi1, const float* feat, const float* W1frag, const float* bG1, const float* R1frag, const float* bR1,
                         const float* W2frag, const float* bW2, const float* R2frag, const float* bR2, float* hout2, float* hx,
                         unsigned* flags, unsigned* err, long n_seq_pad, int T, int n_cu, unsigned long long spin_ticks, int variant,
-                        hipStream_t stream);
+                        unsigned waits, hipStream_t stream); // waits: gru_ws2k's first-poll waits (layer 1 | layer 2 << 16, 10 ns ticks); 0 = built in
+// which table of built-in first-poll waits gru_ws2k uses for this launch: 0 not that kernel, 1 groups of 25 + 25, 2 groups of 13 + 25,
+// 3 groups of 13 + 25 with layer 1's input projection in the kernel (what ws2_calibrate measures and overrides)
+int fvad_gru_ws2_wait_class(long n_seq_pad, int T, int n_cu, int variant);
+unsigned fvad_gru_ws2_builtin_waits(int wait_class); // the table's entry, packed like `waits`
 int fvad_launch_gru_gen(const float* gi, int gi_ld, const float* R2frag, const float* bR, float* hout, int h_ld,
                         long n_seq_pad, int T, int J, hipStream_t stream);
 int fvad_launch_gru_rec3(const float* gi, const float* R2frag, const float* bR, float* hout,

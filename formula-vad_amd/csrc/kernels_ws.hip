@@ -577,7 +577,7 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
                                                         const float* __restrict__ bR2, float* __restrict__ hout2,
                                                         float* hx1, float* hx2, unsigned* flags1, unsigned* flags2,
                                                         unsigned* err, int T, int n_rt, unsigned long long spin_ticks,
-                                                        int variant, int nl1)
+                                                        int variant, int nl1, unsigned waits)
 {
     // dynamic LDS, in float4s: hbA[25][64], hbB[25][64] (the row tile's h1 and h2; layer 1 has no h2 and keeps the step's
     // input rows x_t there: two parities of 11 blocks); per tile slot: xch[3 gates][2 chains][64] recurrent partial products;
@@ -735,13 +735,13 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     // brings the wasted polls back, too long would sit on the critical path.  (A self-tuning wait -- longer after a step
     // that needed several polls, shorter after a first-poll hit -- ratchets up across the group, because a late poller
     // publishes late and makes its peers' polls miss: 400 us instead of 350.)  Timing only: results do not depend on it.
-    // Tuning: ws2_variant bit 24 = take the waits from bits 8..15 (layer 1) / 16..23 (layer 2), in units of 40 ns.
-    const unsigned wait_ticks = (variant & (1 << 24)) ? 4u * (unsigned)((layer ? variant >> 16 : variant >> 8) & 255)
+    // waits != 0 (context options ws2_waits / ws2_calibrate): layer 1's wait in the low half, layer 2's in the high half, ticks.
+    const unsigned wait_ticks = waits ? (layer ? waits >> 16 : waits & 0xFFFFu)
                                                       : GI1K ? (layer ? (one ? WS2K_WAIT_L2_ONE_G : WS2K_WAIT_L2_G) : (one ? WS2K_WAIT_L1_ONE_G : WS2K_WAIT_L1_G))
                                                              : (layer ? (one ? WS2K_WAIT_L2_ONE : WS2K_WAIT_L2) : (one ? WS2K_WAIT_L1_ONE : WS2K_WAIT_L1));
     auto acquire = [&](int pw, unsigned need1, unsigned need2, bool from_h2, unsigned slot, int st, int ev, int ready, bool timed) {
         if (wave == pw) {
-            const unsigned wt = timed ? wait_ticks : ((pw == 15 && !one && !(variant & (1 << 24))) ? WS2K_WAIT_H1 : 0u);
+            const unsigned wt = timed ? wait_ticks : ((pw == 15 && !one) ? WS2K_WAIT_H1 : 0u);
             if (wt) {
                 const unsigned long long until = __builtin_amdgcn_s_memrealtime() + wt;
                 while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(1);
@@ -1341,10 +1341,29 @@ const char* fvad_gru_ws2_kernel_name(long n_seq_pad, int T, int n_cu, int varian
     }
 }
 
+int fvad_gru_ws2_wait_class(long n_seq_pad, int T, int n_cu, int variant)
+{
+    int RT = 0, G = 0;
+    bool gi1k = false;
+    if (!fvad_gru_ws2_shape(n_seq_pad, n_cu, &RT, &G) || ws2_kernel_for(n_seq_pad, T, n_cu, variant, &gi1k) != 1) return 0;
+    const bool one = G * 2 * GRU_J <= n_cu && !(variant & 16);
+    return one ? 1 : gi1k ? 3 : 2;
+}
+
+unsigned fvad_gru_ws2_builtin_waits(int wait_class)
+{
+    switch (wait_class) {
+    case 1: return WS2K_WAIT_L1_ONE | (WS2K_WAIT_L2_ONE << 16);
+    case 2: return WS2K_WAIT_L1 | (WS2K_WAIT_L2 << 16);
+    case 3: return WS2K_WAIT_L1_G | (WS2K_WAIT_L2_G << 16);
+    default: return 0;
+    }
+}
+
 int fvad_launch_gru_ws2(const float* gi1, const float* feat, const float* W1frag, const float* bG1, const float* R1frag, const float* bR1,
                         const float* W2frag, const float* bW2, const float* R2frag, const float* bR2, float* hout2, float* hx,
                         unsigned* flags, unsigned* err, long n_seq_pad, int T, int n_cu, unsigned long long spin_ticks, int variant,
-                        hipStream_t stream)
+                        unsigned waits, hipStream_t stream)
 {
     int RT = 0, G = 0;
     if (!fvad_gru_ws2_shape(n_seq_pad, n_cu, &RT, &G)) return -1;
@@ -1366,7 +1385,7 @@ int fvad_launch_gru_ws2(const float* gi1, const float* feat, const float* W1frag
         {                                                                                                                                       \
             if (hipFuncSetAttribute((const void*)gru_ws2k_kernel<TRACE_, GI1K_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return -2; \
             hipLaunchKernelGGL((gru_ws2k_kernel<TRACE_, GI1K_>), grid, dim3(1024), lds_k, stream, in1, W1frag, bG1, R1frag, bR1, W2frag, bW2, R2frag, bR2, \
-                               hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant, nl1);                                   \
+                               hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant, nl1, waits);                                \
             return 0;                                                                                                                           \
         }
 #if FVAD_DIAG

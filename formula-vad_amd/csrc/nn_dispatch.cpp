@@ -554,7 +554,8 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
         time_begin(ctx, "gru12_rec_pipelined");
         rc |= ws_serialised(ctx, [&] {
             return fvad_launch_gru_ws2(ws.gi, ws.feat, m.s_w1frag.p, m.gi1f_b.p, m.r1v2.p, m.br1.p, m.s_w2frag.p, m.s_bw2.p, m.r2v2.p, m.br2.p, ws.h2,
-                                       ws.hx, ws.ws_sync, err, n_pad, T, ctx->n_cu, ws_spin_deadline(ctx, gru_ws2_cost_both_layers(n_pad, T, ctx->n_cu, tn.ws2_variant) * T / 55.0), tn.ws2_variant, st);
+                                       ws.hx, ws.ws_sync, err, n_pad, T, ctx->n_cu, ws_spin_deadline(ctx, gru_ws2_cost_both_layers(n_pad, T, ctx->n_cu, tn.ws2_variant) * T / 55.0), tn.ws2_variant,
+                                       tn.ws2_waits ? tn.ws2_waits : tn.ws2_waits_cal[fvad_gru_ws2_wait_class(n_pad, T, ctx->n_cu, tn.ws2_variant)], st);
         });
         // one launch behind it: the whole fallback (layer 1, layer 2's input projection, layer 2 -- run only if the
         // error word was raised), the pass count, and the reset of the polled words for the next pass
@@ -589,6 +590,74 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
     if (rc) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "no kernel instance for this layer shape");
     FVAD_HIP(ctx, hipGetLastError());
     return FVAD_OK;
+}
+
+// Context option ws2_calibrate: gru_ws2k's first-poll waits measured on THIS device.  The built-in table was swept on one box
+// (tools/ws2_delay.py); what the right wait is depends on how long a flag takes to cross the fabric, which is a property of
+// the part and its clocks.  A 5 x 5 grid around the table's entry (both layers' waits, +-0.8 us in steps of 0.4: the optimum is
+// a narrow diagonal valley, which a search along one axis at a time misses), the network pass (run_nn: the product path, on whatever the workspace holds) timed five times per candidate,
+// fastest run kept.  A candidate replaces the table's entry only if it is more than 1.5 % faster -- run-to-run noise is about
+// 1 %.  Timing only: results do not depend on the waits (tests/test_gpu.py checks bits with and without).
+// About 60 ms per class; classes measured: the one a one-chunk push falls in and the one BASELINE config 3's 82 chunks fall in.
+int calibrate_ws2_waits(fvad_ctx* ctx)
+{
+    Tuning& tn = ctx->tune;
+    if (!ctx->dm.loaded || ctx->dm.generic)
+        return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "ws2_calibrate: load an NSNet2 model of the baseline shape first");
+    const int T = kRowsPerChunk;
+    int rc = ensure_workspace(ctx, 96, T, kWarmupRows);
+    if (rc) return rc;
+    if ((rc = ensure_gru_ws(ctx))) return rc;
+    Workspace& ws = ctx->ws;
+    FVAD_HIP(ctx, hipMemsetAsync(ws.feat, 0, (size_t)96 * T * kFeatStride * sizeof(float), ctx->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    FVAD_HIP(ctx, hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return set_err(ctx, FVAD_ERR_HIP, "hipEventCreate"); }
+    const unsigned saved = tn.ws2_waits;
+    const std::string saved_path = ctx->last_nn_path;
+    auto time_pass = [&](long n_pad, unsigned waits, float* best) -> int {
+        tn.ws2_waits = waits;
+        *best = 1e30f;
+        for (int i = 0; i < 6; i++) { // the first is a warm-up
+            if (hipEventRecord(e0, ctx->stream) != hipSuccess) return FVAD_ERR_HIP;
+            const int r = run_nn(ctx, n_pad, T, kWarmupRows);
+            if (r) return r;
+            if (hipEventRecord(e1, ctx->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return FVAD_ERR_HIP;
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (i) *best = std::min(*best, ms);
+        }
+        return FVAD_OK;
+    };
+    bool done[4] = {false, false, false, false};
+    for (long n : {1L, 82L}) {
+        const long n_pad = padded_batch(ctx, n, T, kWarmupRows);
+        const int cls = fvad_gru_ws2_wait_class(n_pad, T, ctx->n_cu, tn.ws2_variant);
+        if (cls == 0 || done[cls] || pick_gru(ctx, n_pad, T, false).version != 6) continue;
+        done[cls] = true;
+        const unsigned base = fvad_gru_ws2_builtin_waits(cls);
+        float t_base = 0;
+        if ((rc = time_pass(n_pad, base, &t_base))) break;
+        unsigned best = base;
+        float t_best = t_base;
+        for (int d1 = -80; d1 <= 80 && !rc; d1 += 40)
+            for (int d2 = -80; d2 <= 80 && !rc; d2 += 40) {
+                const int l1 = (int)(base & 0xFFFFu) + d1, l2 = (int)(base >> 16) + d2;
+                if ((d1 == 0 && d2 == 0) || l1 < 0 || l2 < 0) continue;
+                float t = 0;
+                rc = time_pass(n_pad, (unsigned)l1 | ((unsigned)l2 << 16), &t);
+                if (!rc && t < t_best) { t_best = t; best = (unsigned)l1 | ((unsigned)l2 << 16); }
+            }
+        if (!rc && best != base) { // the winner against the table once more, back to back: keep it only on a clear margin
+            float t0 = 0, t1 = 0;
+            if (!(rc = time_pass(n_pad, base, &t0)) && !(rc = time_pass(n_pad, best, &t1)) && t1 < 0.985f * t0) tn.ws2_waits_cal[cls] = best;
+        }
+    }
+    tn.ws2_waits = saved;
+    ctx->last_nn_path = saved_path;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return rc;
 }
 
 // Chunks per launch of a call over `total` chunks; max_chunks <= 0: the caller leaves it to the engine.

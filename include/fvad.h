@@ -315,14 +315,23 @@ const char *fvad_ctx_last_nn_path(const fvad_ctx *ctx);
  * Testing / tuning aids, none needed in production: name = "reproducible" | "nn_math" ("f32" | "f16x3" | "bf16x3": overrides
  * fvad_ctx_set_nn_math) | "gru_kernel" ("v3w12" | "v3w8" | "v3w4" | "v4w8" | "v5w0" | "v6w0") | "gemm_kernel" ("v1" |
  * "v3" | "v3nofold") | "h3_waves" ("8" | "12") | "max_chunks" | "copy_threads" | "no_pipeline" | "trace_kernels" |
- * "ws_spin_ticks" | "ws2_variant" (diagnostic bit mask; bits 1, 2, 4, 32 are timing-only: WRONG results); value NULL or "" restores the
- * default.  The environment variables FVAD_<NAME> are read ONCE, by
+ * "ws_spin_ticks" | "ws2_variant" (diagnostic bit mask; the timing-only bits exist in the diagnostics build alone) |
+ * "ws2_waits" | "ws2_calibrate" (below); value NULL or "" restores the default.  The environment variables FVAD_<NAME> are read ONCE, by
  * fvad_ctx_create, as initial values (a bad value fails the creation); the data path never reads the environment. */
 int fvad_ctx_set_option(fvad_ctx *ctx, const char *name, const char *value);
 /* Network passes in which the weight-stationary small-batch recurrence (gru_ws_kernel) gave up waiting for a peer
  * workgroup -- the chip was shared with another process -- and the low-latency kernel redid the GRU layers (same
  * bits: both accumulate in the same order).  Waits for the context's stream. */
 int fvad_ctx_ws_fallbacks(fvad_ctx *ctx, uint64_t *n);
+/* The pipelined recurrence of launches up to 96 sequences (gru_ws2k) waits a fixed interval before a step's first poll of
+ * its peers' flags -- a poll made too early is a wasted round trip and traffic on the flag lines.  The intervals are a
+ * built-in table per group shape (wait_class 1: groups of 25 + 25 workgroups, 1..80 sequences; 2 and 3: groups of 13 + 25,
+ * without / with layer 1's input projection in the kernel), swept on one MI355X.  fvad_ctx_set_option(ctx, "ws2_calibrate",
+ * "1") measures them on THIS device (about 0.1 s, the model must be loaded; the table's entry stays unless a candidate is
+ * more than 1.5 % faster); "ws2_waits" = layer 1's wait | layer 2's << 16, in 10 ns ticks, sets them by hand for every class.
+ * Timing only: results do not depend on them.  Returns the waits in effect for a class, packed like "ws2_waits"; 0 for an
+ * unknown class. */
+uint32_t fvad_ctx_ws2_waits(const fvad_ctx *ctx, int wait_class);
 /* Per-kernel device time of the last fvad_engine_* call (HIP events on the context's stream):
  * names[i]/ms[i] for i < *n.  Enabled by fvad_ctx_enable_timing(ctx, 1). */
 int fvad_ctx_enable_timing(fvad_ctx *ctx, int on);

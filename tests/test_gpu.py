@@ -1650,6 +1650,45 @@ def test_weight_stationary_handoff_is_deterministic_under_load(fv, gpu_ctx, weig
         bg.close()
 
 
+def test_first_poll_waits_are_timing_only(fv, weights7):
+    # gru_ws2k waits a fixed interval before a step's first poll of its peers' flags: a built-in table per group shape, which
+    # the context option ws2_calibrate re-measures on this device and ws2_waits sets by hand (include/fvad.h:
+    # fvad_ctx_ws2_waits).  Whatever the waits are, the bits are the same and no pass gives up.
+    L = fv.lib()
+    ctx = fv.Context(0)
+    try:
+        # the measurement runs the network: without a model it is an error that says so, and the table stays
+        assert L.fvad_ctx_set_option(ctx.h, b"ws2_calibrate", b"1") == fv.FVAD_ERR_INVALID_ARGUMENT
+        assert b"model" in L.fvad_last_error(ctx.h)
+        table = {c: ctx.ws2_waits(c) for c in (1, 2, 3)}
+        assert all(0 < a < 1000 and 0 < b < 1000 for a, b in table.values()), table
+        assert ctx.ws2_waits(0) == (0, 0) and ctx.ws2_waits(4) == (0, 0) and L.fvad_ctx_ws2_waits(None, 1) == 0
+        for name, value in (("ws2_waits", "-1"), ("ws2_waits", "x"), ("ws2_calibrate", "2"), ("ws2_waits", str(1 << 31))):
+            assert L.fvad_ctx_set_option(ctx.h, name.encode(), value.encode()) == fv.FVAD_ERR_INVALID_ARGUMENT, (name, value)
+        ctx.load_weights(weights7)
+        feats = {n: np.random.default_rng(n).uniform(-11, 2, (n, 54, 161)).astype(np.float32) for n in (1, 40, 82)}
+        ref = {n: ctx.nsnet2_forward(f) for n, f in feats.items()}
+        assert "gru_ws2k" in ctx.last_nn_path()
+        for w in (1 | (1 << 16), 100 | (400 << 16), 600 | (50 << 16), 40 | (40 << 16)):
+            with ctx.options(ws2_waits=w):
+                assert ctx.ws2_waits(1) == ctx.ws2_waits(3) == (w & 0xFFFF, w >> 16)
+                for n, f in feats.items():
+                    assert np.array_equal(ctx.nsnet2_forward(f), ref[n]), (w, n)
+        assert {c: ctx.ws2_waits(c) for c in (1, 2, 3)} == table
+        ctx.set_option("ws2_calibrate", 1)
+        cal = {c: ctx.ws2_waits(c) for c in (1, 2, 3)}
+        for c in (1, 3):  # measured classes stay within the search window around the table's entry; class 2 is not measured
+            assert abs(cal[c][0] - table[c][0]) <= 80 and abs(cal[c][1] - table[c][1]) <= 80, (cal, table)
+        assert cal[2] == table[2]
+        for n, f in feats.items():
+            assert np.array_equal(ctx.nsnet2_forward(f), ref[n]), n
+        ctx.set_option("ws2_calibrate", 0)
+        assert {c: ctx.ws2_waits(c) for c in (1, 2, 3)} == table
+        assert ctx.ws_fallbacks() == 0
+    finally:
+        ctx.close()
+
+
 _WS_FALLBACK_SCRIPT = r"""
 import os, sys
 import numpy as np
