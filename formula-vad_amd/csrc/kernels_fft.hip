@@ -523,22 +523,27 @@ void fvad_launch_stft(const ChunkDesc* descs, int n_chunks, FftTables tb, float*
 }
 
 // ============================================================================ K3
-constexpr int K3_FR = kFramesPerChunk + 2; // frames -2..49
-
-// parts > 1 (launches of a few chunks): workgroup blockIdx.y produces the output hops [F0, F1) of the chunk's 50 from
-// the frames F0 - 2 .. F1 - 1 -- the same relation the whole chunk has to frames -2 .. 49, so a part is the same code
-// on a shorter range (two frames per seam are transformed twice, by the same instructions: the same bits).
+// One WAVEFRONT per run of output hops, no workgroup barrier in the frame loop.  A chunk's 50 hops are 25 pairs; the
+// 4 * parts wavefronts of its workgroups take contiguous runs of pairs [P0, P1).  A wavefront walks its run one frame pair
+// (2 pi, 2 pi + 1) at a time -- lanes 0..31 the first frame, lanes 32..63 the second, as in K1 -- and keeps everything
+// of a pair in its own 5 KB of LDS: gain * X pre-mixed into the complex sequence, the inverse transform read from and written
+// back over it (windowed), then the pair's two output hops formed where they are consumed:
+//     d[160 f + j] = y_{f-1}[160 + j] + y_f[j]   (NSNet2.zig:336),
+// the second half of the PREVIOUS pair's second frame being in the wavefront's other buffer (two buffers, alternating).
+// A run starts one pair early (frames 2 P0 - 2, 2 P0 - 1: nothing written, they leave y_{2 P0 - 1} and the sample before
+// the run's first); the chunk's very first pair takes both from the lane's carry instead.  Frames < 0 belong to the previous
+// chunk of the same lane (g - 1).  Every value is computed by the same instructions whatever the split: the same bits for
+// parts = 1, 2, 3, and the same bits as the round-3 kernel (one workgroup per chunk, 52 frames between two barriers per
+// 8 frames, 79 KB of LDS: two workgroups per CU, 46 % of its VALU-issue time busy) at 58 transformed frames instead of 52.
+// The spectrogram / gain operands of a pair are fetched one iteration ahead.
 __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict__ descs, FftTables tb,
                                                     const float* __restrict__ spec,
                                                     const float* __restrict__ gains,
                                                     int g_rows, int g_row0, int parts)
 {
-    __shared__ __attribute__((aligned(16))) float oa[K3_FR][kNHop]; // first halves y_f[0..160)
-    __shared__ __attribute__((aligned(16))) float ob[K3_FR][kNHop]; // second halves y_f[160..320)
-    __shared__ __attribute__((aligned(16))) float zb[4][2][2 * 160];
-    __shared__ float s_wn[kNFft];
-    __shared__ float s_st[2 * 80];
-    __shared__ float s_dm1;
+    __shared__ __attribute__((aligned(16))) float slab[4][2][2 * kNFft]; // [wavefront][buffer][frame of the pair][320]
+    __shared__ __attribute__((aligned(8))) float s_wn[kNFft];
+    __shared__ __attribute__((aligned(8))) float s_st[2 * 80];
 
     const int g = blockIdx.x;
     const ChunkDesc d = descs[g];
@@ -550,153 +555,147 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
 
     for (int i = tid; i < kNFft; i += 256) s_wn[i] = tb.win320n[i];
     for (int i = tid; i < 160; i += 256) s_st[i] = tb.st320[i];
-    __syncthreads();
+    __syncthreads(); // the only workgroup barrier: window and un-mixing table
 
     LaneTw<5, 32> tw;
     lane_tw_load<5, 32, true>(tw, tb.tw160, p);
     const int k2 = bitrev_lane<32>(p);
 
-    // frames fr = F0 - 2 .. F1 - 1 (the whole chunk: -2..49); fr < 0 belong to the previous chunk of the same lane (g - 1)
-    const int F0 = (kFramesPerChunk * (int)blockIdx.y) / parts, F1 = (kFramesPerChunk * ((int)blockIdx.y + 1)) / parts;
-    const int fr0 = F0 - 2; // frame in row 0 of oa / ob
-    const int fr_begin = (d.first && F0 == 0) ? 0 : fr0;
-    const int N_PAIRS = (F1 - fr0 + 1) / 2; // 26 for the whole chunk; an odd count leaves the last pair's second frame (F1) unused
-    // The spectrogram / gain operands of a frame pair are fetched one iteration ahead (3 items per
-    // lane: 12 spectrum floats + 6 gains), so each iteration's global-memory round trip overlaps the
-    // previous pair's FFT instead of heading the critical path.
+    constexpr int HOP_PAIRS = kFramesPerChunk / 2; // 25
+    const int n_runs = 4 * parts, run = 4 * (int)blockIdx.y + wave;
+    const int P0 = (HOP_PAIRS * run) / n_runs, P1 = (HOP_PAIRS * (run + 1)) / n_runs;
+    if (P0 >= P1) return;
+    const bool from_carry = d.first && P0 == 0;
+    float* buf0 = slab[wave][0];
+    float* buf1 = slab[wave][1];
+    float dm1 = 0.0f; // decimated output sample just before the pair at hand
+    if (from_carry) { // y_{-1}[160..320) and the sample before the chunk come from the lane's carry
+        for (int j = lane; j < kNHop; j += 64) buf1[kNFft + kNHop + j] = d.carry_in->ola_tail[j];
+        dm1 = d.carry_in->last_sample;
+    }
+
     struct Item { float sk_r, sk_i, snk_r, snk_i, gk, gnk; };
+    // bins k = p, p + 32, p + 64 (<= 80) and their mirrors 160 - k of this half-wavefront's frame of pair pi
     auto fetch = [&](int pi, Item (&itm)[3]) {
+        const int fr = 2 * pi + half;
+        const int gg = fr < 0 ? g - 1 : g;
+        const int f = fr < 0 ? fr + kFramesPerChunk : fr;
+        const float* srow = spec + ((size_t)gg * kFramesPerChunk + f) * kNBins * 2;
+        const float* grow = gains + ((size_t)gg * g_rows + g_row0 + f) * kFeatStride;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            const int item = lane + 64 * u;
-            const int hh = item / 81;
-            const int k = item - hh * 81;
-            const int fr = 2 * pi + hh + fr0;
-            itm[u] = Item{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (item < 2 * 81 && pi < N_PAIRS && fr >= fr_begin && fr < F1) {
-                const int gg = fr < 0 ? g - 1 : g;
-                const int f = fr < 0 ? fr + kFramesPerChunk : fr;
-                const float* srow = spec + ((size_t)gg * kFramesPerChunk + f) * kNBins * 2;
-                const float* grow = gains + ((size_t)gg * g_rows + g_row0 + f) * kFeatStride;
-                const int kn = 160 - k;
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                const f32x2 a = *reinterpret_cast<const f32x2*>(srow + 2 * k);
-                const f32x2 b = *reinterpret_cast<const f32x2*>(srow + 2 * kn);
-                itm[u].sk_r = a.x; itm[u].sk_i = a.y;
-                itm[u].snk_r = b.x; itm[u].snk_i = b.y;
-                itm[u].gk = grow[k]; itm[u].gnk = grow[kn];
-            }
+            int k = p + 32 * u;
+            k = k <= 80 ? k : 80; // lanes past bin 80 repeat it: loads stay unconditional, the values are not used
+            const int kn = 160 - k;
+            const f32x2 a = *reinterpret_cast<const f32x2*>(srow + 2 * k);
+            const f32x2 b = *reinterpret_cast<const f32x2*>(srow + 2 * kn);
+            itm[u] = Item{a.x, a.y, b.x, b.y, grow[k], grow[kn]};
         }
     };
-    Item cur[3];
-    fetch(wave, cur);
-    for (int it = 0; it < (N_PAIRS + 3) / 4; ++it) {
-        const int pi = it * 4 + wave;
-        Item nxt[3];
-        fetch(pi + 4, nxt);
-        // pre-mix gain * X into the length-160 complex sequence
+    const int pi_begin = from_carry ? 0 : P0 - 1;
+    Item cur[3], nxt[3];
+    fetch(pi_begin, cur);
+    f32x4* out4 = reinterpret_cast<f32x4*>(d.den);
+    const float frac1 = 1.0f / 3.0f, frac2 = 2.0f / 3.0f;
+    for (int pi = pi_begin; pi < P1; ++pi) {
+        float* cb = ((pi - pi_begin) & 1) ? buf1 : buf0;   // this pair's buffer
+        float* pb = ((pi - pi_begin) & 1) ? buf0 : buf1;   // the previous pair's (from_carry: the carry's tail)
+        if (pi + 1 < P1) fetch(pi + 1, nxt);
+        __builtin_amdgcn_wave_barrier();
+        {   // pre-mix gain * X into the length-160 complex sequence
+            float* z = cb + half * kNFft;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int item = lane + 64 * u;
-            const int hh = item / 81;
-            const int k = item - hh * 81;
-            const int fr = 2 * pi + hh + fr0;
-            if (item < 2 * 81 && pi < N_PAIRS && fr >= fr_begin && fr < F1) {
-                const int kn = 160 - k;
-                float gk = cur[u].gk, gnk = cur[u].gnk;
-                gk = gk < -80.0f ? -80.0f : (gk > 1.0f ? 1.0f : gk);   // NSNet2.zig:295-305
-                gnk = gnk < -80.0f ? -80.0f : (gnk > 1.0f ? 1.0f : gnk);
-                const cpx yk = {cur[u].sk_r * gk, cur[u].sk_i * gk};
-                const cpx ynk = {cur[u].snk_r * gnk, cur[u].snk_i * gnk};
-                float* z = zb[wave][hh];
-                if (k == 0) {
-                    z[0] = yk.r + ynk.r;
-                    z[1] = yk.r - ynk.r;
-                } else {
-                    cpx tk, tnk;
-                    const cpx st_inv = {s_st[2 * (k - 1)], -s_st[2 * (k - 1) + 1]};
-                    premix_inv(yk, ynk, st_inv, tk, tnk);
-                    z[2 * k] = tk.r; z[2 * k + 1] = tk.i;
-                    z[2 * kn] = tnk.r; z[2 * kn + 1] = tnk.i; // k == 80: second write wins
+            for (int u = 0; u < 3; ++u) {
+                const int k = p + 32 * u;
+                if (u < 2 || k <= 80) {
+                    const int kn = 160 - k;
+                    float gk = cur[u].gk, gnk = cur[u].gnk;
+                    gk = gk < -80.0f ? -80.0f : (gk > 1.0f ? 1.0f : gk);   // NSNet2.zig:295-305
+                    gnk = gnk < -80.0f ? -80.0f : (gnk > 1.0f ? 1.0f : gnk);
+                    const cpx yk = {cur[u].sk_r * gk, cur[u].sk_i * gk};
+                    const cpx ynk = {cur[u].snk_r * gnk, cur[u].snk_i * gnk};
+                    if (u == 0 && k == 0) {
+                        *reinterpret_cast<float2*>(z) = make_float2(yk.r + ynk.r, yk.r - ynk.r);
+                    } else {
+                        cpx tk, tnk;
+                        const float2 st = *reinterpret_cast<const float2*>(s_st + 2 * (k - 1));
+                        premix_inv(yk, ynk, {st.x, -st.y}, tk, tnk);
+                        *reinterpret_cast<float2*>(z + 2 * k) = make_float2(tk.r, tk.i);
+                        *reinterpret_cast<float2*>(z + 2 * kn) = make_float2(tnk.r, tnk.i); // k == 80: second write wins
+                    }
                 }
             }
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            float* z = cb + half * kNFft;
+            cpx v[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float2 zv = *reinterpret_cast<const float2*>(z + 2 * (p + 32 * j));
+                v[j] = {zv.x, zv.y};
+            }
+            wave_fft<5, 32, true>(v, tw, p);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k1 = 0; k1 < 5; ++k1) {
+                const int n = 2 * (k1 + 5 * k2);
+                // inv_fft_buffer[i] *= window[i] * (1/320), NSNet2.zig:335 -- over the pair's own z, which is in registers by now
+                const float2 wv = *reinterpret_cast<const float2*>(s_wn + n);
+                *reinterpret_cast<float2*>(z + n) = make_float2(v[k1].r * wv.x, v[k1].i * wv.y);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the pair's 320 decimated samples d[m] = (second half of the earlier frame) + (first half of the later one):
+        //   m < 160: y_{2 pi - 1}[160 + m] (other buffer) + y_{2 pi}[m];   m >= 160: y_{2 pi}[m] + y_{2 pi + 1}[m - 160]
+        auto dec4 = [&](int m0) -> f32x4 { // 160 % 4 == 0: a float4 never straddles the two hops
+            const float* a = m0 < kNHop ? pb + kNFft + kNHop + m0 : cb + m0;
+            const float* b = m0 < kNHop ? cb + m0 : cb + kNHop + m0;
+            return *reinterpret_cast<const f32x4*>(a) + *reinterpret_cast<const f32x4*>(b);
+        };
+        auto dec1 = [&](int m) -> float {
+            return m < kNHop ? pb[kNFft + kNHop + m] + cb[m] : cb[m] + cb[kNHop + m];
+        };
+        if (pi >= P0) {
+            // x3 upsample (resample.zig:32-79): out[3m+2] = d[m]; out[3m+j] = lerp(d[m-1], d[m], (j+1)/3).
+            // Each lane turns 4 decimated samples into 12 outputs = three float4 stores (d.den is 16-byte
+            // aligned: chunk regions are 64-float aligned and 24000 % 4 == 0): 80 such items per pair.
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int w = lane + 64 * pass;
+                if (pass == 0 || w < 2 * kNHop / 4) {
+                    const int m0 = 4 * w;
+                    const f32x4 c = dec4(m0);
+                    const float pv = w > 0 ? dec1(m0 - 1) : dm1;
+                    // std.math.lerp = mulAdd: (b - a) * t + a, fused
+                    const f32x4 o0 = {__builtin_fmaf(c.x - pv, frac1, pv), __builtin_fmaf(c.x - pv, frac2, pv), c.x,
+                                      __builtin_fmaf(c.y - c.x, frac1, c.x)};
+                    const f32x4 o1 = {__builtin_fmaf(c.y - c.x, frac2, c.x), c.y, __builtin_fmaf(c.z - c.y, frac1, c.y),
+                                      __builtin_fmaf(c.z - c.y, frac2, c.y)};
+                    const f32x4 o2 = {c.z, __builtin_fmaf(c.w - c.z, frac1, c.z), __builtin_fmaf(c.w - c.z, frac2, c.z), c.w};
+                    const int wo = (2 * kNHop / 4) * pi + w; // float4-triple index within the chunk
+                    out4[3 * wo] = o0;
+                    out4[3 * wo + 1] = o1;
+                    out4[3 * wo + 2] = o2;
+                    if (d.den16) { // PCM16 copy of the same 12 samples: three 8-byte stores
+                        typedef short s16x4 __attribute__((ext_vector_type(4)));
+                        auto q = [](float y) { return (short)__builtin_rintf(fminf(fmaxf(y * 32768.0f, -32768.0f), 32767.0f)); };
+                        s16x4* o16 = reinterpret_cast<s16x4*>(d.den16) + 3 * wo;
+                        o16[0] = (s16x4){q(o0.x), q(o0.y), q(o0.z), q(o0.w)};
+                        o16[1] = (s16x4){q(o1.x), q(o1.y), q(o1.z), q(o1.w)};
+                        o16[2] = (s16x4){q(o2.x), q(o2.y), q(o2.z), q(o2.w)};
+                    }
+                }
+            }
+        }
+        dm1 = dec1(2 * kNHop - 1);
+        if (d.last && pi == HOP_PAIRS - 1) { // the lane's carry: y_49[160..320) and the chunk's last decimated sample
+            for (int j = lane; j < kNHop; j += 64) d.carry_out->ola_tail[j] = cb[kNFft + kNHop + j];
+            if (lane == 0) d.carry_out->last_sample = dm1;
         }
 #pragma unroll
         for (int u = 0; u < 3; ++u) cur[u] = nxt[u];
-        __syncthreads();
-        {
-            const int fr = 2 * pi + half + fr0;
-            if (pi < N_PAIRS && fr >= fr_begin && fr < F1) {
-                const float* z = zb[wave][half];
-                cpx v[5];
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    const int n = p + 32 * j;
-                    v[j] = {z[2 * n], z[2 * n + 1]};
-                }
-                wave_fft<5, 32, true>(v, tw, p);
-#pragma unroll
-                for (int k1 = 0; k1 < 5; ++k1) {
-                    const int n = 2 * (k1 + 5 * k2);
-                    // inv_fft_buffer[i] *= window[i] * (1/320), NSNet2.zig:335
-                    const float y0 = v[k1].r * s_wn[n];
-                    const float y1 = v[k1].i * s_wn[n + 1];
-                    if (n < kNHop) { oa[fr - fr0][n] = y0; oa[fr - fr0][n + 1] = y1; }
-                    else { ob[fr - fr0][n - kNHop] = y0; ob[fr - fr0][n - kNHop + 1] = y1; }
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    // previous-chunk state of the first chunk of a call comes from the carry
-    if (d.first && F0 == 0) {
-        for (int j = tid; j < kNHop; j += 256) ob[1][j] = d.carry_in->ola_tail[j];
-        if (tid == 0) s_dm1 = d.carry_in->last_sample;
-    } else if (tid == 0) {
-        s_dm1 = ob[0][kNHop - 1] + oa[1][kNHop - 1]; // decimated output sample 8000c + 160 F0 - 1
-    }
-    __syncthreads();
-
-    // overlap-add (NSNet2.zig:336), d[160 f + j] = y_{f-1}[160 + j] + y_f[j], is folded into the
-    // upsampling loop below (each value is formed once, as ob + oa, where it is consumed)
-    auto ola = [&](int mdec) { // decimated output sample mdec of this chunk, 160 F0 <= mdec < 160 F1
-        const int f = mdec / kNHop, j = mdec - f * kNHop;
-        return ob[f - F0 + 1][j] + oa[f - F0 + 2][j];
-    };
-    if (d.last && F1 == kFramesPerChunk) {
-        for (int j = tid; j < kNHop; j += 256) d.carry_out->ola_tail[j] = ob[kFramesPerChunk - F0 + 1][j];
-        if (tid == 0) d.carry_out->last_sample = ola(kFramesPerChunk * kNHop - 1);
-    }
-
-    // x3 upsample (resample.zig:32-79): out[3m+2] = d[m]; out[3m+j] = lerp(d[m-1], d[m], (j+1)/3).
-    // Each thread turns 4 decimated samples into 12 outputs = three float4 stores (d.den is 16-byte
-    // aligned: chunk regions are 64-float aligned and 24000 % 4 == 0).
-    const float frac1 = 1.0f / 3.0f, frac2 = 2.0f / 3.0f;
-    f32x4* out4 = reinterpret_cast<f32x4*>(d.den);
-    const float dm1 = s_dm1;
-    for (int w = F0 * (kNHop / 4) + tid; w < F1 * (kNHop / 4); w += 256) {
-        const int m0 = 4 * w;
-        const int f = m0 / kNHop, j = m0 - f * kNHop; // 160 % 4 == 0: a float4 never straddles two frames
-        const f32x4 c = *reinterpret_cast<const f32x4*>(&ob[f - F0 + 1][j]) + *reinterpret_cast<const f32x4*>(&oa[f - F0 + 2][j]);
-        const float pv = m0 > F0 * kNHop ? ola(m0 - 1) : dm1;
-        // std.math.lerp = mulAdd: (b - a) * t + a, fused
-        const f32x4 o0 = {__builtin_fmaf(c.x - pv, frac1, pv), __builtin_fmaf(c.x - pv, frac2, pv), c.x,
-                          __builtin_fmaf(c.y - c.x, frac1, c.x)};
-        const f32x4 o1 = {__builtin_fmaf(c.y - c.x, frac2, c.x), c.y, __builtin_fmaf(c.z - c.y, frac1, c.y),
-                          __builtin_fmaf(c.z - c.y, frac2, c.y)};
-        const f32x4 o2 = {c.z, __builtin_fmaf(c.w - c.z, frac1, c.z), __builtin_fmaf(c.w - c.z, frac2, c.z), c.w};
-        out4[3 * w] = o0;
-        out4[3 * w + 1] = o1;
-        out4[3 * w + 2] = o2;
-        if (d.den16) { // PCM16 copy of the same 12 samples: three 8-byte stores
-            typedef short s16x4 __attribute__((ext_vector_type(4)));
-            auto q = [](float y) { return (short)__builtin_rintf(fminf(fmaxf(y * 32768.0f, -32768.0f), 32767.0f)); };
-            s16x4* o16 = reinterpret_cast<s16x4*>(d.den16) + 3 * w;
-            o16[0] = (s16x4){q(o0.x), q(o0.y), q(o0.z), q(o0.w)};
-            o16[1] = (s16x4){q(o1.x), q(o1.y), q(o1.z), q(o1.w)};
-            o16[2] = (s16x4){q(o2.x), q(o2.y), q(o2.z), q(o2.w)};
-        }
     }
 }
 
@@ -705,7 +704,7 @@ void fvad_launch_istft(const ChunkDesc* descs, int n_chunks, FftTables tb, const
                        const float* gains, int gains_rows_per_chunk, int gains_row0,
                        hipStream_t stream, int parts)
 {
-    if (parts < 1 || parts > 3) parts = 1;
+    if (parts < 1 || parts > 3) parts = 1; // 4 * parts wavefronts per chunk, each with its own run of hop pairs
     hipLaunchKernelGGL(istft_kernel, dim3(n_chunks, parts), dim3(256), 0, stream, descs, tb, spec, gains,
                        gains_rows_per_chunk, gains_row0, parts);
 }
