@@ -701,7 +701,7 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
             ws.jobs_mirror.assign(h_jobs, h_jobs + n_lanes);
         }
         time_begin(ctx, "fft1024_bandsum");
-        fvad_launch_vadfft_jobs(d_jobs, (int)n_lanes, (long)n_frames, plan, opts.min_bin, opts.max_bin, st);
+        fvad_launch_vadfft_jobs(d_jobs, (int)n_lanes, (long)n_frames, plan, opts.min_bin, opts.max_bin, st, 0, ctx->n_cu);
         time_end(ctx);
         return FVAD_OK;
     };

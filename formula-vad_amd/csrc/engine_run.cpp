@@ -403,7 +403,9 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
         }
         if (mf) {
             time_begin(ctx, "fft1024_bandsum");
-            fvad_launch_vadfft_jobs(ws.fft_jobs + l0, (int)(l1 - l0), mf, plan, opts.min_bin, opts.max_bin, st);
+            int any_bins = 0;
+            for (size_t l = l0; l < l1; ++l) any_bins |= lanes[l].fft_bins != nullptr;
+            fvad_launch_vadfft_jobs(ws.fft_jobs + l0, (int)(l1 - l0), mf, plan, opts.min_bin, opts.max_bin, st, any_bins, ctx->n_cu);
             time_end(ctx);
         }
         for (size_t l = l0; l < l1; ++l) {

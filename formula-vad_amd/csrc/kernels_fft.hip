@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "kernels.h"
+#include "device_math.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -325,8 +326,8 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
 {
     __shared__ __attribute__((aligned(16))) float dec[K1_DEC];
     __shared__ __attribute__((aligned(16))) float zb[4][2][2 * 160];
-    __shared__ float s_win[kNFft];
-    __shared__ float s_st[2 * 80];
+    __shared__ __attribute__((aligned(8))) float s_win[kNFft];
+    __shared__ __attribute__((aligned(8))) float s_sth[2 * 81]; // un-mixing table / 2, entry k for bin k (unmix_fwd_h)
     __shared__ float s_red[4];
 
     const int g = blockIdx.x;
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
     const int pb = parts == 1 ? N_PAIRS : (do_fft ? (N_PAIRS * (part + 1)) / parts : 0);
 
     for (int i = tid; i < kNFft; i += K1_THREADS) s_win[i] = tb.win320[i];
-    for (int i = tid; i < 160; i += K1_THREADS) s_st[i] = tb.st320[i];
+    for (int i = tid; i < 162; i += K1_THREADS) s_sth[i] = i >= 2 ? tb.st320[i - 2] * 0.5f : (i == 0 ? 0.0f : -0.5f);
 
     // ---- load + decimate + sum of squares
     float ss = 0.0f;
@@ -357,10 +358,21 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
         // [320 pa, 320 pb + 160), i.e. raw samples [960 pa, 960 pb + 480)
         const int i4_lo = do_rms ? 0 : 240 * pa, i4_hi = do_rms ? (hist + kChunk48) / 4 : 240 * pb + 120;
         const int i4_begin = (d.first && hist / 4 > i4_lo) ? hist / 4 : i4_lo;
-        auto take = [&](unsigned s, float x) { // sample s of [history | chunk]
-            const unsigned s3 = s / 3u;
-            if (s3 * 3u == s) dec[s3] = x;
-            if ((int)s >= hist) ss += x * x;
+        // float4 i4 of [history | chunk] holds samples 4 i4 .. 4 i4 + 3; the decimated ones are those at multiples of 3:
+        // sample 3 q with q = ceil(4 i4 / 3), i.e. element r = 3 q - 4 i4 (0, 1 or 2), and element 3 too when r == 0.
+        // (one division per float4 instead of one per sample; the order of the RMS sum is untouched)
+        auto take4 = [&](int i4, const f32x4& v) {
+            const unsigned x = 4u * (unsigned)i4;
+            const unsigned q = (x + 2u) / 3u;
+            const unsigned r = 3u * q - x;
+            dec[q] = r == 0 ? v.x : (r == 1 ? v.y : v.z);
+            if (r == 0) dec[q + 1] = v.w;
+            if (i4 >= hist / 4) {
+                ss += v.x * v.x;
+                ss += v.y * v.y;
+                ss += v.z * v.z;
+                ss += v.w * v.w;
+            }
         };
         // batches of 9 independent loads per thread are issued before any is consumed, so the chunk's
         // 96-105 KB stream in with ~37 KB per workgroup in flight instead of one L2/HBM round trip per loop
@@ -396,10 +408,7 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
 #pragma unroll
             for (int b = 0; b < LD_BATCH; ++b) {
                 const int i4 = base + b * K1_THREADS + tid;
-                if (i4 < n4 && i4 >= i4_begin) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) take(4u * i4 + e, v[b][e]);
-                }
+                if (i4 < n4 && i4 >= i4_begin) take4(i4, v[b]);
             }
         }
         if (d.last && do_rms) {
@@ -438,78 +447,70 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
     const int p = lane & 31;
     LaneTw<5, 32> tw;
     lane_tw_load<5, 32, false>(tw, tb.tw160, p);
-    float wre[5], wim[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        wre[j] = s_win[2 * (p + 32 * j)];
-        wim[j] = s_win[2 * (p + 32 * j) + 1];
-    }
     const int k2 = bitrev_lane<32>(p);
     const float p_min = 1.0f / 1e12f; // std.math.pow(f32, 10, -12), NSNet2.zig:275
     float* spec_g = spec + (size_t)g * kFramesPerChunk * kNBins * 2;
     const int fl_begin = d.first ? kWarmupRows : 0;
 
-    for (int it = 0; it < (pb - pa + 3) / 4; ++it) {
-        const int pi = pa + it * 4 + wave;
+    // Every wavefront runs its own frame pairs pa + wave, pa + wave + 4, ... -- lanes 0..31 the pair's first frame, lanes
+    // 32..63 the second -- with no workgroup barrier: the complex transform goes through the wavefront's own LDS slab
+    // (LDS accesses of one wavefront execute in program order), and wavefronts drift apart and cover each other's waits.
+    for (int pi = pa + wave; pi < pb; pi += 4) {
+        if (2 * pi < fl_begin) continue; // warm-up rows of a call's first chunk come from the carry (fl_begin is even: whole pairs)
         const int fl = 2 * pi + half;
-        const bool active = (pi < pb) && (fl >= fl_begin);
-        if (active) {
+        float* z = zb[wave][half];
+        {
             cpx v[5];
             const float* x = dec + kNHop * fl;
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
                 const int n = 2 * (p + 32 * j);
-                v[j] = {x[n] * wre[j], x[n + 1] * wim[j]}; // loadSamplesFwd, FFT.zig:183-199
+                const float2 xv = *reinterpret_cast<const float2*>(x + n);
+                const float2 wv = *reinterpret_cast<const float2*>(s_win + n);
+                v[j] = {xv.x * wv.x, xv.y * wv.y}; // loadSamplesFwd, FFT.zig:183-199
             }
             wave_fft<5, 32, false>(v, tw, p);
-            float* z = zb[wave][half];
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k1 = 0; k1 < 5; ++k1) {
                 const int k = k1 + 5 * k2;
-                z[2 * k] = v[k1].r;
-                z[2 * k + 1] = v[k1].i;
+                *reinterpret_cast<float2*>(z + 2 * k) = make_float2(v[k1].r, v[k1].i);
             }
         }
-        __syncthreads();
-        // un-mix: 2 frames x 81 k's per wavefront
-        for (int item = lane; item < 2 * 81; item += 64) {
-            const int hh = item / 81;
-            const int k = item - hh * 81;
-            const int fl2 = 2 * pi + hh;
-            if (pi < pb && fl2 >= fl_begin) {
-                const float* z = zb[wave][hh];
+        __builtin_amdgcn_wave_barrier();
+        // un-mix: bins k = p, p + 32, p + 64 (<= 80) and their mirrors 160 - k.  Bin 80 is its own mirror: only the
+        // X[ncfft - k] form is kept, the one kissfft writes last.
+        float* frow = feat_g + fl * kFeatStride;
+        float* srow = spec_g + (size_t)(fl - kWarmupRows) * kNBins * 2; // used for fl >= kWarmupRows only
+        float* ftail = d.carry_out->feat_tail + (fl - kFramesPerChunk) * kNBins; // used for the lane's last chunk, fl >= 50
+        const bool to_spec = fl >= kWarmupRows, to_tail = d.last && fl >= kFramesPerChunk;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int k = p + 32 * u;
+            if (u < 2 || k <= 80) {
+                const int kn = 160 - k;
+                const bool dc = u == 0 && k == 0;
+                const int ksrc = dc ? 0 : kn; // z[160] does not exist: k = 0 pairs with itself (table entry 0 = (0, -1/2))
+                const float2 zk = *reinterpret_cast<const float2*>(z + 2 * k);
+                const float2 zn = *reinterpret_cast<const float2*>(z + 2 * ksrc);
+                const float2 st = *reinterpret_cast<const float2*>(s_sth + 2 * k);
                 cpx xk, xnk;
-                int kn;
-                if (k == 0) {
-                    const cpx tdc = {z[0], z[1]};
-                    xk = {tdc.r + tdc.i, 0.0f};
-                    xnk = {tdc.r - tdc.i, 0.0f};
-                    kn = 160;
-                } else {
-                    kn = 160 - k;
-                    unmix_fwd({z[2 * k], z[2 * k + 1]}, {z[2 * kn], z[2 * kn + 1]},
-                              {s_st[2 * (k - 1)], s_st[2 * (k - 1) + 1]}, xk, xnk);
-                }
-                float* frow = feat_g + fl2 * kFeatStride;
-                const float fk = log10f(fmaxf(xk.r * xk.r + xk.i * xk.i, p_min));
-                const float fnk = log10f(fmaxf(xnk.r * xnk.r + xnk.i * xnk.i, p_min));
-                if (k != 80) frow[k] = fk; // k == 80: X[160-k] is written last in the reference
+                unmix_fwd_h({zk.x, zk.y}, {zn.x, zn.y}, {st.x, st.y}, xk, xnk);
+                if (dc) { xk.i = 0.0f; xnk.i = 0.0f; } // kissfft's DC / Nyquist bins are real: +0, not the formula's -0
+                const float fk = log10_pos(fmaxf(xk.r * xk.r + xk.i * xk.i, p_min));
+                const float fnk = log10_pos(fmaxf(xnk.r * xnk.r + xnk.i * xnk.i, p_min));
+                if (k != 80) frow[k] = fk;
                 frow[kn] = fnk;
-                if (fl2 >= kWarmupRows) {
-                    float* srow = spec_g + (size_t)(fl2 - kWarmupRows) * kNBins * 2;
-                    // one 8-byte store per bin (rows start 8-byte aligned: 161 * 2 floats per row)
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    if (k != 80) *reinterpret_cast<f32x2*>(srow + 2 * k) = (f32x2){xk.r, xk.i};
-                    *reinterpret_cast<f32x2*>(srow + 2 * kn) = (f32x2){xnk.r, xnk.i};
+                if (to_spec) { // one 8-byte store per bin (rows start 8-byte aligned: 161 * 2 floats per row)
+                    if (k != 80) *reinterpret_cast<float2*>(srow + 2 * k) = make_float2(xk.r, xk.i);
+                    *reinterpret_cast<float2*>(srow + 2 * kn) = make_float2(xnk.r, xnk.i);
                 }
-                if (d.last && fl2 >= kFramesPerChunk) {
-                    float* ft = d.carry_out->feat_tail + (fl2 - kFramesPerChunk) * kNBins;
-                    if (k != 80) ft[k] = fk;
-                    ft[kn] = fnk;
+                if (to_tail) {
+                    if (k != 80) ftail[k] = fk;
+                    ftail[kn] = fnk;
                 }
             }
         }
-        __syncthreads();
     }
 }
 
@@ -813,6 +814,240 @@ __global__ __launch_bounds__(256) void vadfft_jobs_kernel(const VadFftJob* __res
     vadfft_body<R>(j.den, j.n_frames, frame, pl, min_bin, max_bin, j.band_sum, j.bins, zl, mag);
 }
 
+// ============================================================================ K4 at 1024 points, band sum only: four frames per wavefront
+// The kernel above gives a frame to a whole wavefront (8 points per lane, six exchange stages across 64 lanes, all 513 bins)
+// and a wavefront to one frame: its twiddles are fetched again for every frame.  The VAD consumes the band min_bin..max_bin
+// only (bins 11..43 at the reference's 500-2000 Hz, VADMachine.zig:146-151).  Here a frame is SIXTEEN lanes with 32 complex
+// points each, z[32 a + n2] in lane a, four frames per wavefront, wavefronts persistent over their job's frames:
+//   Z[k1 + 16 k2] = sum_n2 W512^{n2 k1} W32^{n2 k2} ( sum_a z[32 a + n2] W16^{a k1} )
+//   * the inner 16-point transforms run across the lanes (four exchange stages instead of six, none crossing a row of 16:
+//     no v_permlane swaps), leaving k1 = bitrev(a) in lane a; one twiddle multiply (31 per lane, loaded once);
+//   * the outer 32-point transform is in registers and PRUNED: bins 1..47 and their un-mixing partners 465..511 have
+//     k2 in {0, 1, 2} and {29, 30, 31} -- six outputs of 32 (eight 4-point transforms, then six 8-term sums);
+//   * kissfft's un-mixing pairs Z[k] with Z[512 - k], which sits in the lane holding 16 - k1: one ds_bpermute per scalar;
+//     every lane un-mixes its three bins k1, k1 + 16, k1 + 32, the 48 magnitudes go to LDS and one lane per frame adds the
+//     band in index order (BufferedFFT.zig:192-199).
+// A lane's 32 points are 256 contiguous bytes, so the four frames are staged through LDS: rows of 64 floats padded to 68 (a
+// 16-lane ds_read_b128 then covers all 64 banks).  The staging is LDS-DMA (16 bytes per lane, global address per lane, LDS
+// address lane * 16: 17 instructions per four frames, the padding units fetch a neighbour) issued as soon as the previous
+// group's points are in registers, so a group's memory time lies under the previous group's arithmetic; a job whose frames
+// are not 16-byte aligned takes plain 8-byte loads instead -- the same arithmetic, the same bits.
+// ~330 VALU instructions per frame instead of ~650.  The full-spectrum kernel above stays for the magnitude tap, for
+// 512 / 2048 points and for bands outside 1..47.
+constexpr int V4_ROW = 68; // floats per padded row of 64
+
+// forward twiddle exp(-2 pi i m / 32); constants rounded from double
+__device__ __forceinline__ cpx w32(int m)
+{
+    const float C[9] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
+                        0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f, 0.0f};
+    m &= 31;
+    const int quad = m >> 3, r = m & 7;
+    float c, sn;
+    switch (quad) {
+    case 0: c = C[r]; sn = C[8 - r]; break;
+    case 1: c = -C[8 - r]; sn = C[r]; break;
+    case 2: c = -C[r]; sn = -C[8 - r]; break;
+    default: c = C[8 - r]; sn = -C[r]; break;
+    }
+    return {c, -sn};
+}
+__device__ __forceinline__ cpx mul_w32(cpx a, int m) // a * W32^m; the quarter turns are exact
+{
+    m &= 31;
+    if (m == 0) return a;
+    if (m == 8) return mul_mi<false>(a);
+    if (m == 16) return {-a.r, -a.i};
+    if (m == 24) return mul_mi<true>(a);
+    return cmul_fma(a, w32(m));
+}
+// u[n2], n2 < 32, in; y = Y[0], Y[1], Y[2], Y[29], Y[30], Y[31] of the 32-point transform out (u is overwritten).
+// n2 = 8 m + s: Y[k2] = sum_s W32^{s k2} T_s[k2 mod 4], T_s[c] = sum_m u[8 m + s] W4^{m c}
+__device__ __forceinline__ void dft32_band(cpx (&u)[32], cpx (&y)[6])
+{
+#pragma unroll
+    for (int s = 0; s < 8; ++s) dft4<false>(u[s], u[8 + s], u[16 + s], u[24 + s]); // T_s[c] is now u[8 c + s]
+    constexpr int K2[6] = {0, 1, 2, 29, 30, 31};
+#pragma unroll
+    for (int o = 0; o < 6; ++o) {
+        const int k2 = K2[o], c = k2 & 3;
+        cpx acc = u[8 * c];
+#pragma unroll
+        for (int s = 1; s < 8; ++s) acc = cadd(acc, mul_w32(u[8 * c + s], s * k2));
+        y[o] = acc;
+    }
+}
+
+// x = x(lane ^ h) * sgn + x for h = 8, 2, 1 inside a row of 16 lanes as ONE instruction: v_fmac_f32 with the exchange as its
+// DPP operand (row_ror:8, quad_perm) -- no LDS round trip, no separate move (the compiler keeps v_mov_b32_dpp + v_fmac apart
+// when given the builtin).  s_nop 1: a DPP read of a VGPR needs two wait states after the VALU write of it.
+__device__ __forceinline__ void dpp_butterfly(float& x, float sgn, int h) // h is a constant after unrolling
+{
+    switch (h) {
+    case 8: asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(sgn)); break;
+    case 2: asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(sgn)); break;
+    default: asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(sgn)); break;
+    }
+}
+
+__global__ __launch_bounds__(256) void vadfft1024_band_kernel(const VadFftJob* __restrict__ jobs, VadFftPlan pl, int min_bin, int max_bin)
+{
+    // dynamic LDS (77 KB: over the static limit; two workgroups per CU): per wavefront a slab of 4 frames x 16 rows of 64 (+4)
+    // floats; the window in the same padded rows; 48 magnitudes per frame
+    extern __shared__ __attribute__((aligned(16))) float v4_smem[];
+    float* s_win = v4_smem + 4 * 64 * V4_ROW;
+    float* s_mag = s_win + 16 * V4_ROW;
+    const VadFftJob job = jobs[blockIdx.y];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4; // frame of the group
+    const int a = lane & 15; // row of the frame: points 32 a .. 32 a + 31
+    for (int i = tid; i < 1024; i += 256) s_win[(i >> 6) * V4_ROW + (i & 63)] = pl.win[i];
+    __syncthreads(); // the only workgroup barrier
+    const long n_groups = (job.n_frames + 3) / 4;
+    long grp = (long)blockIdx.x * 4 + wave;
+    const long stride = (long)gridDim.x * 4;
+    if (grp >= n_groups) return;
+
+    // ---- per-lane constants
+    const int k1 = (int)(__brev((unsigned)a) >> 28);
+    cpx twl[31]; // W512^{n2 k1}
+#pragma unroll
+    for (int n2 = 1; n2 < 32; ++n2) {
+        const cpx t = ld_tw(pl.tw, n2 * k1);
+        twl[n2 - 1] = (a & 1) ? cpx{-t.r, -t.i} : t; // the last exchange stage leaves minus the value on odd lanes
+    }
+    cpx tws[3]; // exchange-stage twiddles (strides 8, 4, 2): 1 on the lower lane, MINUS the twiddle on the upper (mine - other)
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+        const int h = 8 >> st;
+        cpx t = {1.0f, 0.0f};
+        if (a & h) {
+            t = ld_tw(pl.tw, (a & (h - 1)) * (256 / h)); // W_{2h}^{a mod h} = W512^{(a mod h) 256 / h}
+            t = {-t.r, -t.i};
+        }
+        tws[st] = t;
+    }
+    cpx stl[3]; // un-mixing factors of this lane's bins k1 + 16 j (bin 0 is never in the band)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int k = k1 + 16 * j;
+        stl[j] = k > 0 ? ld_tw(pl.st, k - 1) : cpx{0.0f, 0.0f};
+    }
+    const int partner = 4 * (16 * q + (int)(__brev((unsigned)((16 - k1) & 15)) >> 28)); // byte address for ds_bpermute
+    const float norm = pl.norm;
+
+    // ---- staging
+    float* sl = v4_smem + wave * (64 * V4_ROW);
+    const bool dma = (reinterpret_cast<uintptr_t>(job.den) & 15) == 0;
+    unsigned voff[17]; // 16-byte unit U = 64 jj + lane of the padded slab: row U / 17, unit U % 17 (16 = padding: re-fetches unit 15)
+#pragma unroll
+    for (int jj = 0; jj < 17; ++jj) {
+        const unsigned U = 64u * jj + (unsigned)lane, row = U / 17u, c = U - 17u * row;
+        voff[jj] = row * 256u + (c < 16u ? c : 15u) * 16u;
+    }
+    auto stage = [&](long g0) { // frames 4 g0 .. 4 g0 + 3 -> slab (frames past the job's end read as zeros)
+        const long left = job.n_frames - 4 * g0; // > 0
+        const unsigned bytes = (unsigned)(left < 4 ? left : 4) * 4096u;
+        const float* src = job.den + g0 * 4096;
+        if (dma) {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)bytes, 0x00020000);
+            auto lds3 = (__attribute__((address_space(3))) char*)sl;
+#pragma unroll
+            for (int jj = 0; jj < 17; ++jj)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds3 + jj * 1024), 16, voff[jj], 0, 0, 0);
+        } else {
+#pragma unroll 4
+            for (int t = 0; t < 32; ++t) {
+                const unsigned f = 2u * ((unsigned)lane + 64u * t);
+                const float2 v = f * 4u < bytes ? *reinterpret_cast<const float2*>(src + f) : make_float2(0.0f, 0.0f);
+                *reinterpret_cast<float2*>(sl + (f >> 6) * V4_ROW + (f & 63u)) = v;
+            }
+        }
+    };
+    stage(grp);
+    for (; grp < n_groups; grp += stride) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        cpx u[32];
+        {
+            const f32x4* xr = reinterpret_cast<const f32x4*>(sl + (16 * q + a) * V4_ROW);
+            const f32x4* wr = reinterpret_cast<const f32x4*>(s_win + a * V4_ROW);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const f32x4 x = xr[t], w = wr[t];
+                u[2 * t] = {x.x * w.x, x.y * w.y};
+                u[2 * t + 1] = {x.z * w.z, x.w * w.w};
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (grp + stride < n_groups) stage(grp + stride); // the slab is in registers: refill it under this group's arithmetic
+
+        // 16-point transforms across the frame's lanes (decimation in frequency, as wave_fft).  Every stage is
+        // t = other * sgn + mine with sgn = -1 on the upper lane (there: mine - other, and the stage twiddle is stored
+        // negated); the exchange is a DPP operand of that fma for strides 8 (row_ror:8), 2 and 1 (quad_perm) -- no LDS
+        // round trip -- and a swizzle for stride 4.  The last stage has no twiddle: its upper lane holds MINUS the result,
+        // which the twiddle multiply that follows absorbs (twl is negated there; u[0] has none and is negated by hand).
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int h = 8 >> st;
+            const float sgn = (a & h) ? -1.0f : 1.0f;
+#pragma unroll
+            for (int n2 = 0; n2 < 32; ++n2) {
+                cpx t = u[n2];
+                if (h == 4) {
+                    const cpx other = {lane_xor<4>(t.r, lane), lane_xor<4>(t.i, lane)};
+                    t = {__builtin_fmaf(other.r, sgn, t.r), __builtin_fmaf(other.i, sgn, t.i)};
+                } else {
+                    dpp_butterfly(t.r, sgn, h);
+                    dpp_butterfly(t.i, sgn, h);
+                }
+                u[n2] = h > 1 ? cmul_fma(t, tws[st]) : t;
+            }
+        }
+        if (a & 1) u[0] = {-u[0].r, -u[0].i};
+#pragma unroll
+        for (int n2 = 1; n2 < 32; ++n2) u[n2] = cmul_fma(u[n2], twl[n2 - 1]);
+        cpx y[6];
+        dft32_band(u, y); // Z[k1 + 16 k2], k2 = 0, 1, 2, 29, 30, 31
+
+        // Z[512 - k] for k = k1 + 16 j: lane of 16 - k1, k2 = 31 - j; for k1 = 0 this lane itself, k2 = 32 - j
+        cpx pz[3]; // partner's k2 = 29, 30, 31
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            pz[o].r = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(y[3 + o].r)));
+            pz[o].i = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(y[3 + o].i)));
+        }
+        const bool self = k1 == 0;
+        const cpx zn[3] = {pz[2], self ? pz[2] : pz[1], self ? pz[1] : pz[0]};
+        float* mg = s_mag + (4 * wave + q) * 48;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            cpx xk, xnk;
+            unmix_fwd(y[j], zn[j], stl[j], xk, xnk);
+            mg[k1 + 16 * j] = sqrtf(xk.r * xk.r + xk.i * xk.i) * norm; // FFT.zig:16-18 (bin 0's entry is never read)
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (a == 0) {
+            const f32x4* m4 = reinterpret_cast<const f32x4*>(mg);
+            float m[48];
+#pragma unroll
+            for (int t = 0; t < 12; ++t) {
+                const f32x4 v = m4[t];
+                m[4 * t] = v.x; m[4 * t + 1] = v.y; m[4 * t + 2] = v.z; m[4 * t + 3] = v.w;
+            }
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 1; k < 48; ++k) acc = (k >= min_bin && k <= max_bin) ? acc + m[k] : acc; // index order, BufferedFFT.zig:192-199
+            const long frame = 4 * grp + q;
+            if (frame < job.n_frames) job.band_sum[frame] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ============================================================================ any even size: generic mixed radix
 // FFT.init takes any even n_fft that kissfft factors (FFT.zig:35-60), VADPipeline.Config.fft_size with it.  The sizes the
 // pipeline runs at have wavefront kernels above; every other even size up to kVadFftMax runs here: one workgroup per frame,
@@ -1006,15 +1241,31 @@ void fvad_launch_vadfft(const float* den, long n_frames, VadFftPlan pl, int min_
 }
 
 void fvad_launch_vadfft_jobs(const VadFftJob* jobs, int n_jobs, long max_frames, VadFftPlan pl,
-                             int min_bin, int max_bin, hipStream_t stream)
+                             int min_bin, int max_bin, hipStream_t stream, int any_bins, int n_cu)
 {
     if (n_jobs <= 0 || max_frames <= 0) return;
     if (pl.generic) {
         launch_rfft_generic(nullptr, 0, nullptr, pl, nullptr, nullptr, jobs, n_jobs, max_frames, min_bin, max_bin, stream);
         return;
     }
-    VADFFT_DISPATCH(pl.n, hipLaunchKernelGGL(vadfft_jobs_kernel<R>, dim3((unsigned)((max_frames + 3) / 4), (unsigned)n_jobs), dim3(256), 0,
-                                              stream, jobs, pl, min_bin, max_bin))
+    // 1024 points and a band inside bins 1..47 (the reference's 500-2000 Hz is 11..43): the four-frames-per-wavefront
+    // kernel writes the band sums; the full-spectrum kernel runs (first) only when some job wants the magnitude tap, so
+    // that a call's band sums have the same bits with and without the tap
+    const bool band = pl.n == 1024 && min_bin >= 1 && max_bin <= 47 && min_bin <= max_bin;
+    if (!band || any_bins)
+        VADFFT_DISPATCH(pl.n, hipLaunchKernelGGL(vadfft_jobs_kernel<R>, dim3((unsigned)((max_frames + 3) / 4), (unsigned)n_jobs), dim3(256), 0,
+                                                  stream, jobs, pl, min_bin, max_bin))
+    if (band) {
+        // persistent wavefronts: two workgroups per CU (77 KB of LDS each) over all jobs -- one resident round, no tail --,
+        // each wavefront walking its job's groups of four frames with the next group's staging in flight
+        const long groups = (max_frames + 3) / 4, wg_all = (groups + 3) / 4;
+        long per_job = (2L * (n_cu > 0 ? n_cu : 256)) / n_jobs;
+        if (per_job < 1) per_job = 1;
+        if (per_job > wg_all) per_job = wg_all;
+        constexpr size_t lds = (size_t)(4 * 64 * V4_ROW + 16 * V4_ROW + 16 * 48) * sizeof(float);
+        if (hipFuncSetAttribute((const void*)vadfft1024_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return;
+        hipLaunchKernelGGL(vadfft1024_band_kernel, dim3((unsigned)per_job, (unsigned)n_jobs), dim3(256), lds, stream, jobs, pl, min_bin, max_bin);
+    }
 }
 
 // ============================================================================ batched FFT.fft
