@@ -28,6 +28,9 @@
 #include "device_math.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct cpx { float r, i; };
 
@@ -313,19 +316,20 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 // ============================================================================ K1
-constexpr int K1_THREADS = 256;
+constexpr int K1_THREADS = 256; // the threads that load, decimate and sum (the sample -> thread assignment fixes the RMS bits)
+constexpr int K1_BLOCK = 512;   // eight wavefronts share the decimated chunk in LDS for the frame loop
 constexpr int K1_DEC = (kRowsPerChunk + 1) * kNHop; // 8800 decimated samples: frames -4..49
 
 // parts == 1: one workgroup per chunk does everything.  parts > 1 (launches of a few chunks, where a chunk's 27 frame
 // pairs on one workgroup are a latency chain): blockIdx.y < parts transforms its share of the frame pairs from its share
 // of the samples; blockIdx.y == parts streams the whole chunk for the RMS (the sample -> thread assignment and the order
 // of that sum do not change) and writes the carries.  Every value is computed by the same instructions either way.
-__global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __restrict__ descs,
+__global__ __launch_bounds__(K1_BLOCK) void stft_kernel(const ChunkDesc* __restrict__ descs,
                                                           FftTables tb, float* __restrict__ feat,
                                                           float* __restrict__ spec, int parts)
 {
     __shared__ __attribute__((aligned(16))) float dec[K1_DEC];
-    __shared__ __attribute__((aligned(16))) float zb[4][2][2 * 160];
+    __shared__ __attribute__((aligned(16))) float zb[K1_BLOCK / 64][2][2 * 160];
     __shared__ __attribute__((aligned(8))) float s_win[kNFft];
     __shared__ __attribute__((aligned(8))) float s_sth[2 * 81]; // un-mixing table / 2, entry k for bin k (unmix_fwd_h)
     __shared__ float s_red[4];
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
     const ChunkDesc d = descs[g];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int N_PAIRS = kRowsPerChunk / 2; // 27
     const int part = blockIdx.y;
     const bool do_fft = parts == 1 || part < parts;
@@ -342,12 +346,14 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
     const int pa = parts == 1 ? 0 : (do_fft ? (N_PAIRS * part) / parts : 0);          // this workgroup's frame pairs
     const int pb = parts == 1 ? N_PAIRS : (do_fft ? (N_PAIRS * (part + 1)) / parts : 0);
 
-    for (int i = tid; i < kNFft; i += K1_THREADS) s_win[i] = tb.win320[i];
-    for (int i = tid; i < 162; i += K1_THREADS) s_sth[i] = i >= 2 ? tb.st320[i - 2] * 0.5f : (i == 0 ? 0.0f : -0.5f);
+    for (int i = tid; i < kNFft; i += K1_BLOCK) s_win[i] = tb.win320[i];
+    for (int i = tid; i < 162; i += K1_BLOCK) s_sth[i] = i >= 2 ? tb.st320[i - 2] * 0.5f : (i == 0 ? 0.0f : -0.5f);
 
-    // ---- load + decimate + sum of squares
+    // ---- load + decimate + sum of squares: wavefronts 0..3 (the other four wait at the barrier below; with two workgroups
+    // per CU their SIMD slots go to the other workgroup's frame loop meanwhile)
+    const bool loader = wave < K1_THREADS / 64;
     float ss = 0.0f;
-    {
+    if (loader) {
         // [2400 raw samples of history | chunk]: the history of the first chunk of a launch is not in memory (its
         // decimated tail comes from the carry below), so its float4s are skipped -- but the sample -> thread
         // assignment is the SAME for every chunk, first or not: the order of the RMS sum, and with it the RMS bits,
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
         }
     }
     ss = wave_sum(ss);
-    if (lane == 0) s_red[wave] = ss;
+    if (loader && lane == 0) s_red[wave] = ss;
     __syncthreads();
     if (tid == 0 && do_rms) {
         const float sum = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
     // ---- warm-up feature rows of the first chunk of a call come from the carry (zeros at t=0:
     // NSNet2.zig:77-79)
     float* feat_g = feat + (size_t)g * kRowsPerChunk * kFeatStride;
-    if (d.first && do_rms) {
+    if (d.first && do_rms && loader) {
         const float* ft = d.carry_in->feat_tail;
         for (int i = tid; i < kWarmupRows * kNBins; i += K1_THREADS) {
             const int r = i / kNBins, k = i - r * kNBins;
@@ -451,11 +457,24 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
     const float p_min = 1.0f / 1e12f; // std.math.pow(f32, 10, -12), NSNet2.zig:275
     float* spec_g = spec + (size_t)g * kFramesPerChunk * kNBins * 2;
     const int fl_begin = d.first ? kWarmupRows : 0;
+    // stores of the frame loop as buffer stores: the chunk's rows in the resource, the pair's first row in the scalar offset,
+    // a lane's bins at constant 32-bit offsets (its half-wavefront's row included) -- no 64-bit address arithmetic per store
+    const auto rs_f = __builtin_amdgcn_make_buffer_rsrc(feat_g, 0, kRowsPerChunk * kFeatStride * 4, 0x00020000);
+    const auto rs_sp = __builtin_amdgcn_make_buffer_rsrc(spec_g, 0, kFramesPerChunk * kNBins * 2 * 4, 0x00020000);
+    unsigned vo_f[3], vo_fn[3], vo_s[3], vo_sn[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int k = p + 32 * u;
+        vo_f[u] = (unsigned)(half * kFeatStride + k) * 4u;
+        vo_fn[u] = (unsigned)(half * kFeatStride + 160 - k) * 4u;
+        vo_s[u] = (unsigned)(half * kNBins * 2 + 2 * k) * 4u;
+        vo_sn[u] = (unsigned)(half * kNBins * 2 + 2 * (160 - k)) * 4u;
+    }
 
-    // Every wavefront runs its own frame pairs pa + wave, pa + wave + 4, ... -- lanes 0..31 the pair's first frame, lanes
+    // Every wavefront runs its own frame pairs pa + wave, pa + wave + 8, ... -- lanes 0..31 the pair's first frame, lanes
     // 32..63 the second -- with no workgroup barrier: the complex transform goes through the wavefront's own LDS slab
     // (LDS accesses of one wavefront execute in program order), and wavefronts drift apart and cover each other's waits.
-    for (int pi = pa + wave; pi < pb; pi += 4) {
+    for (int pi = pa + wave; pi < pb; pi += K1_BLOCK / 64) {
         if (2 * pi < fl_begin) continue; // warm-up rows of a call's first chunk come from the carry (fl_begin is even: whole pairs)
         const int fl = 2 * pi + half;
         float* z = zb[wave][half];
@@ -480,8 +499,8 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
         __builtin_amdgcn_wave_barrier();
         // un-mix: bins k = p, p + 32, p + 64 (<= 80) and their mirrors 160 - k.  Bin 80 is its own mirror: only the
         // X[ncfft - k] form is kept, the one kissfft writes last.
-        float* frow = feat_g + fl * kFeatStride;
-        float* srow = spec_g + (size_t)(fl - kWarmupRows) * kNBins * 2; // used for fl >= kWarmupRows only
+        const unsigned so_f = (unsigned)(2 * pi) * (kFeatStride * 4);
+        const unsigned so_s = (unsigned)(2 * pi - kWarmupRows) * (kNBins * 2 * 4); // used for fl >= kWarmupRows only (whole pairs)
         float* ftail = d.carry_out->feat_tail + (fl - kFramesPerChunk) * kNBins; // used for the lane's last chunk, fl >= 50
         const bool to_spec = fl >= kWarmupRows, to_tail = d.last && fl >= kFramesPerChunk;
 #pragma unroll
@@ -499,11 +518,11 @@ __global__ __launch_bounds__(K1_THREADS) void stft_kernel(const ChunkDesc* __res
                 if (dc) { xk.i = 0.0f; xnk.i = 0.0f; } // kissfft's DC / Nyquist bins are real: +0, not the formula's -0
                 const float fk = log10_pos(fmaxf(xk.r * xk.r + xk.i * xk.i, p_min));
                 const float fnk = log10_pos(fmaxf(xnk.r * xnk.r + xnk.i * xnk.i, p_min));
-                if (k != 80) frow[k] = fk;
-                frow[kn] = fnk;
+                if (k != 80) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fk), rs_f, vo_f[u], so_f, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fnk), rs_f, vo_fn[u], so_f, 0);
                 if (to_spec) { // one 8-byte store per bin (rows start 8-byte aligned: 161 * 2 floats per row)
-                    if (k != 80) *reinterpret_cast<float2*>(srow + 2 * k) = make_float2(xk.r, xk.i);
-                    *reinterpret_cast<float2*>(srow + 2 * kn) = make_float2(xnk.r, xnk.i);
+                    if (k != 80) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2v){xk.r, xk.i}), rs_sp, vo_s[u], so_s, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2v){xnk.r, xnk.i}), rs_sp, vo_sn[u], so_s, 0);
                 }
                 if (to_tail) {
                     if (k != 80) ftail[k] = fk;
@@ -519,7 +538,7 @@ void fvad_launch_stft(const ChunkDesc* descs, int n_chunks, FftTables tb, float*
                       hipStream_t stream, int parts)
 {
     if (parts < 1 || parts > 3) parts = 1;
-    hipLaunchKernelGGL(stft_kernel, dim3(n_chunks, parts == 1 ? 1 : parts + 1), dim3(K1_THREADS), 0, stream, descs, tb, feat,
+    hipLaunchKernelGGL(stft_kernel, dim3(n_chunks, parts == 1 ? 1 : parts + 1), dim3(K1_BLOCK), 0, stream, descs, tb, feat,
                        spec, parts);
 }
 
@@ -536,7 +555,7 @@ void fvad_launch_stft(const ChunkDesc* descs, int n_chunks, FftTables tb, float*
 // chunk of the same lane (g - 1).  Every value is computed by the same instructions whatever the split: the same bits for
 // parts = 1, 2, 3, and the same bits as the round-3 kernel (one workgroup per chunk, 52 frames between two barriers per
 // 8 frames, 79 KB of LDS: two workgroups per CU, 46 % of its VALU-issue time busy) at 58 transformed frames instead of 52.
-// The spectrogram / gain operands of a pair are fetched one iteration ahead.
+// The spectrogram / gain operands of the next pair are fetched as soon as the pre-mix has consumed this pair's.
 __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict__ descs, FftTables tb,
                                                     const float* __restrict__ spec,
                                                     const float* __restrict__ gains,
@@ -550,7 +569,7 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
     const ChunkDesc d = descs[g];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
     const int p = lane & 31;
 
@@ -576,33 +595,45 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
     }
 
     struct Item { float sk_r, sk_i, snk_r, snk_i, gk, gnk; };
-    // bins k = p, p + 32, p + 64 (<= 80) and their mirrors 160 - k of this half-wavefront's frame of pair pi
+    // bins k = p, p + 32, p + 64 (<= 80) and their mirrors 160 - k of this half-wavefront's frame of pair pi.  Buffer loads: a
+    // pair's two frames are consecutive rows of ONE chunk, so the chunk's base goes into the resource (scalar), the pair's row
+    // into the scalar offset, and a lane's share is six constant 32-bit offsets -- no 64-bit address arithmetic per load
+    unsigned vo_s[3], vo_sn[3], vo_g[3], vo_gn[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        int k = p + 32 * u;
+        k = k <= 80 ? k : 80; // lanes past bin 80 repeat it: loads stay unconditional, the values are not used
+        vo_s[u] = (unsigned)(half * kNBins * 2 + 2 * k) * 4u;
+        vo_sn[u] = (unsigned)(half * kNBins * 2 + 2 * (160 - k)) * 4u;
+        vo_g[u] = (unsigned)(half * kFeatStride + k) * 4u;
+        vo_gn[u] = (unsigned)(half * kFeatStride + 160 - k) * 4u;
+    }
     auto fetch = [&](int pi, Item (&itm)[3]) {
-        const int fr = 2 * pi + half;
-        const int gg = fr < 0 ? g - 1 : g;
-        const int f = fr < 0 ? fr + kFramesPerChunk : fr;
-        const float* srow = spec + ((size_t)gg * kFramesPerChunk + f) * kNBins * 2;
-        const float* grow = gains + ((size_t)gg * g_rows + g_row0 + f) * kFeatStride;
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const int gg = pi < 0 ? g - 1 : g;                          // pi = -1: the previous chunk's last two frames
+        const int f0 = pi < 0 ? 2 * pi + kFramesPerChunk : 2 * pi;  // the pair's first frame within that chunk
+        const auto rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(spec) + (size_t)gg * kFramesPerChunk * kNBins * 2, 0,
+                                                            kFramesPerChunk * kNBins * 2 * 4, 0x00020000);
+        const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gains) + (size_t)gg * g_rows * kFeatStride, 0,
+                                                            g_rows * kFeatStride * 4, 0x00020000);
+        const unsigned so_s = (unsigned)f0 * (kNBins * 2 * 4), so_g = (unsigned)(g_row0 + f0) * (kFeatStride * 4);
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            int k = p + 32 * u;
-            k = k <= 80 ? k : 80; // lanes past bin 80 repeat it: loads stay unconditional, the values are not used
-            const int kn = 160 - k;
-            const f32x2 a = *reinterpret_cast<const f32x2*>(srow + 2 * k);
-            const f32x2 b = *reinterpret_cast<const f32x2*>(srow + 2 * kn);
-            itm[u] = Item{a.x, a.y, b.x, b.y, grow[k], grow[kn]};
+            const f32x2v a = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(rs_s, vo_s[u], so_s, 0));
+            const f32x2v b = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(rs_s, vo_sn[u], so_s, 0));
+            const float gk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, vo_g[u], so_g, 0));
+            const float gnk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, vo_gn[u], so_g, 0));
+            itm[u] = Item{a.x, a.y, b.x, b.y, gk, gnk};
         }
     };
     const int pi_begin = from_carry ? 0 : P0 - 1;
-    Item cur[3], nxt[3];
+    Item cur[3];
     fetch(pi_begin, cur);
-    f32x4* out4 = reinterpret_cast<f32x4*>(d.den);
+    // output: a pair's 960 samples start at a scalar offset of the chunk; a lane's three float4s at constant offsets
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(d.den, 0, kChunk48 * 4, 0x00020000);
     const float frac1 = 1.0f / 3.0f, frac2 = 2.0f / 3.0f;
     for (int pi = pi_begin; pi < P1; ++pi) {
         float* cb = ((pi - pi_begin) & 1) ? buf1 : buf0;   // this pair's buffer
         float* pb = ((pi - pi_begin) & 1) ? buf0 : buf1;   // the previous pair's (from_carry: the carry's tail)
-        if (pi + 1 < P1) fetch(pi + 1, nxt);
         __builtin_amdgcn_wave_barrier();
         {   // pre-mix gain * X into the length-160 complex sequence
             float* z = cb + half * kNFft;
@@ -628,6 +659,8 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
                 }
             }
         }
+        // the next pair's operands, into the registers the pre-mix has just consumed: in flight during this pair's transform and output
+        if (pi + 1 < P1) fetch(pi + 1, cur);
         __builtin_amdgcn_wave_barrier();
         {
             float* z = cb + half * kNFft;
@@ -676,9 +709,10 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
                                       __builtin_fmaf(c.z - c.y, frac2, c.y)};
                     const f32x4 o2 = {c.z, __builtin_fmaf(c.w - c.z, frac1, c.z), __builtin_fmaf(c.w - c.z, frac2, c.z), c.w};
                     const int wo = (2 * kNHop / 4) * pi + w; // float4-triple index within the chunk
-                    out4[3 * wo] = o0;
-                    out4[3 * wo + 1] = o1;
-                    out4[3 * wo + 2] = o2;
+                    const unsigned so_o = (unsigned)pi * (2 * kNHop * kDown * 4);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rs_o, (unsigned)w * 48u, so_o, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rs_o, (unsigned)w * 48u + 16u, so_o, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o2), rs_o, (unsigned)w * 48u + 32u, so_o, 0);
                     if (d.den16) { // PCM16 copy of the same 12 samples: three 8-byte stores
                         typedef short s16x4 __attribute__((ext_vector_type(4)));
                         auto q = [](float y) { return (short)__builtin_rintf(fminf(fmaxf(y * 32768.0f, -32768.0f), 32767.0f)); };
@@ -695,8 +729,6 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
             for (int j = lane; j < kNHop; j += 64) d.carry_out->ola_tail[j] = cb[kNFft + kNHop + j];
             if (lane == 0) d.carry_out->last_sample = dm1;
         }
-#pragma unroll
-        for (int u = 0; u < 3; ++u) cur[u] = nxt[u];
     }
 }
 
@@ -878,13 +910,16 @@ __device__ __forceinline__ void dft32_band(cpx (&u)[32], cpx (&y)[6])
     }
 }
 
-// x = x(lane ^ h) * sgn + x for h = 8, 2, 1 inside a row of 16 lanes as ONE instruction: v_fmac_f32 with the exchange as its
-// DPP operand (row_ror:8, quad_perm) -- no LDS round trip, no separate move (the compiler keeps v_mov_b32_dpp + v_fmac apart
-// when given the builtin).  s_nop 1: a DPP read of a VGPR needs two wait states after the VALU write of it.
+// x = x(partner) * sgn + x inside a row of 16 lanes as ONE instruction: v_fmac_f32 with the exchange as its DPP operand -- no
+// LDS round trip, no separate move (the compiler keeps v_mov_b32_dpp + v_fmac apart when given the builtin).  Partners:
+// lane ^ 8 (row_ror:8), lane ^ 7 (row_half_mirror), lane ^ 2 and lane ^ 1 (quad_perm).  There is no single DPP pattern for
+// lane ^ 4, so the kernel numbers a frame's rows such that index bit 2 flips with lane bits 0..2 together (see `a` there).
+// s_nop 1: a DPP read of a VGPR needs two wait states after the VALU write of it.
 __device__ __forceinline__ void dpp_butterfly(float& x, float sgn, int h) // h is a constant after unrolling
 {
     switch (h) {
     case 8: asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(sgn)); break;
+    case 4: asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(sgn)); break; // lane ^ 7
     case 2: asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(sgn)); break;
     default: asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(sgn)); break;
     }
@@ -902,7 +937,9 @@ __global__ __launch_bounds__(256) void vadfft1024_band_kernel(const VadFftJob* _
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4; // frame of the group
-    const int a = lane & 15; // row of the frame: points 32 a .. 32 a + 31
+    // row of the frame (points 32 a .. 32 a + 31) held by this lane: bits (l3, l2, l1 ^ l2, l0 ^ l2) of the lane index, so that
+    // flipping bit 2 of `a` is lane ^ 7 -- a DPP pattern -- and flipping bits 0, 1, 3 stays lane ^ 1, ^ 2, ^ 8
+    const int a = (lane & 12) | (((lane & 3) ^ ((lane & 4) ? 3 : 0)));
     for (int i = tid; i < 1024; i += 256) s_win[(i >> 6) * V4_ROW + (i & 63)] = pl.win[i];
     __syncthreads(); // the only workgroup barrier
     const long n_groups = (job.n_frames + 3) / 4;
@@ -935,7 +972,8 @@ __global__ __launch_bounds__(256) void vadfft1024_band_kernel(const VadFftJob* _
         const int k = k1 + 16 * j;
         stl[j] = k > 0 ? ld_tw(pl.st, k - 1) : cpx{0.0f, 0.0f};
     }
-    const int partner = 4 * (16 * q + (int)(__brev((unsigned)((16 - k1) & 15)) >> 28)); // byte address for ds_bpermute
+    const int a_p = (int)(__brev((unsigned)((16 - k1) & 15)) >> 28); // row whose lane holds 16 - k1
+    const int partner = 4 * (16 * q + ((a_p & 12) | ((a_p & 3) ^ ((a_p & 4) ? 3 : 0)))); // its lane, as a byte address for ds_bpermute
     const float norm = pl.norm;
 
     // ---- staging
@@ -987,8 +1025,7 @@ __global__ __launch_bounds__(256) void vadfft1024_band_kernel(const VadFftJob* _
 
         // 16-point transforms across the frame's lanes (decimation in frequency, as wave_fft).  Every stage is
         // t = other * sgn + mine with sgn = -1 on the upper lane (there: mine - other, and the stage twiddle is stored
-        // negated); the exchange is a DPP operand of that fma for strides 8 (row_ror:8), 2 and 1 (quad_perm) -- no LDS
-        // round trip -- and a swizzle for stride 4.  The last stage has no twiddle: its upper lane holds MINUS the result,
+        // negated), the exchange being the DPP operand of that fma (dpp_butterfly).  The last stage has no twiddle: its upper lane holds MINUS the result,
         // which the twiddle multiply that follows absorbs (twl is negated there; u[0] has none and is negated by hand).
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
@@ -997,13 +1034,8 @@ __global__ __launch_bounds__(256) void vadfft1024_band_kernel(const VadFftJob* _
 #pragma unroll
             for (int n2 = 0; n2 < 32; ++n2) {
                 cpx t = u[n2];
-                if (h == 4) {
-                    const cpx other = {lane_xor<4>(t.r, lane), lane_xor<4>(t.i, lane)};
-                    t = {__builtin_fmaf(other.r, sgn, t.r), __builtin_fmaf(other.i, sgn, t.i)};
-                } else {
-                    dpp_butterfly(t.r, sgn, h);
-                    dpp_butterfly(t.i, sgn, h);
-                }
+                dpp_butterfly(t.r, sgn, h);
+                dpp_butterfly(t.i, sgn, h);
                 u[n2] = h > 1 ? cmul_fma(t, tws[st]) : t;
             }
         }
