@@ -940,12 +940,44 @@ __global__ __launch_bounds__(256) void vadfft1024_band_kernel(const VadFftJob* _
     // row of the frame (points 32 a .. 32 a + 31) held by this lane: bits (l3, l2, l1 ^ l2, l0 ^ l2) of the lane index, so that
     // flipping bit 2 of `a` is lane ^ 7 -- a DPP pattern -- and flipping bits 0, 1, 3 stays lane ^ 1, ^ 2, ^ 8
     const int a = (lane & 12) | (((lane & 3) ^ ((lane & 4) ? 3 : 0)));
-    for (int i = tid; i < 1024; i += 256) s_win[(i >> 6) * V4_ROW + (i & 63)] = pl.win[i];
-    __syncthreads(); // the only workgroup barrier
     const long n_groups = (job.n_frames + 3) / 4;
     long grp = (long)blockIdx.x * 4 + wave;
     const long stride = (long)gridDim.x * 4;
-    if (grp >= n_groups) return;
+    const bool has_work = grp < n_groups;
+
+    // ---- staging
+    float* sl = v4_smem + wave * (64 * V4_ROW);
+    const bool dma = (reinterpret_cast<uintptr_t>(job.den) & 15) == 0;
+    unsigned voff[17]; // 16-byte unit U = 64 jj + lane of the padded slab: row U / 17, unit U % 17 (16 = padding: re-fetches unit 15)
+#pragma unroll
+    for (int jj = 0; jj < 17; ++jj) {
+        const unsigned U = 64u * jj + (unsigned)lane, row = U / 17u, c = U - 17u * row;
+        voff[jj] = row * 256u + (c < 16u ? c : 15u) * 16u;
+    }
+    auto stage = [&](long g0) { // frames 4 g0 .. 4 g0 + 3 -> slab (frames past the job's end read as zeros)
+        const long left = job.n_frames - 4 * g0; // > 0
+        const unsigned bytes = (unsigned)(left < 4 ? left : 4) * 4096u;
+        const float* src = job.den + g0 * 4096;
+        if (dma) {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)bytes, 0x00020000);
+            auto lds3 = (__attribute__((address_space(3))) char*)sl;
+#pragma unroll
+            for (int jj = 0; jj < 17; ++jj)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds3 + jj * 1024), 16, voff[jj], 0, 0, 0);
+        } else {
+#pragma unroll 4
+            for (int t = 0; t < 32; ++t) {
+                const unsigned f = 2u * ((unsigned)lane + 64u * t);
+                const float2 v = f * 4u < bytes ? *reinterpret_cast<const float2*>(src + f) : make_float2(0.0f, 0.0f);
+                *reinterpret_cast<float2*>(sl + (f >> 6) * V4_ROW + (f & 63u)) = v;
+            }
+        }
+    };
+    // the first group's staging goes out before anything else: its memory time lies under the window copy and the twiddle loads
+    if (has_work) stage(grp);
+    for (int i = tid; i < 1024; i += 256) s_win[(i >> 6) * V4_ROW + (i & 63)] = pl.win[i];
+    __syncthreads(); // the only workgroup barrier
+    if (!has_work) return;
 
     // ---- per-lane constants
     const int k1 = (int)(__brev((unsigned)a) >> 28);
@@ -976,35 +1008,6 @@ __global__ __launch_bounds__(256) void vadfft1024_band_kernel(const VadFftJob* _
     const int partner = 4 * (16 * q + ((a_p & 12) | ((a_p & 3) ^ ((a_p & 4) ? 3 : 0)))); // its lane, as a byte address for ds_bpermute
     const float norm = pl.norm;
 
-    // ---- staging
-    float* sl = v4_smem + wave * (64 * V4_ROW);
-    const bool dma = (reinterpret_cast<uintptr_t>(job.den) & 15) == 0;
-    unsigned voff[17]; // 16-byte unit U = 64 jj + lane of the padded slab: row U / 17, unit U % 17 (16 = padding: re-fetches unit 15)
-#pragma unroll
-    for (int jj = 0; jj < 17; ++jj) {
-        const unsigned U = 64u * jj + (unsigned)lane, row = U / 17u, c = U - 17u * row;
-        voff[jj] = row * 256u + (c < 16u ? c : 15u) * 16u;
-    }
-    auto stage = [&](long g0) { // frames 4 g0 .. 4 g0 + 3 -> slab (frames past the job's end read as zeros)
-        const long left = job.n_frames - 4 * g0; // > 0
-        const unsigned bytes = (unsigned)(left < 4 ? left : 4) * 4096u;
-        const float* src = job.den + g0 * 4096;
-        if (dma) {
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)bytes, 0x00020000);
-            auto lds3 = (__attribute__((address_space(3))) char*)sl;
-#pragma unroll
-            for (int jj = 0; jj < 17; ++jj)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds3 + jj * 1024), 16, voff[jj], 0, 0, 0);
-        } else {
-#pragma unroll 4
-            for (int t = 0; t < 32; ++t) {
-                const unsigned f = 2u * ((unsigned)lane + 64u * t);
-                const float2 v = f * 4u < bytes ? *reinterpret_cast<const float2*>(src + f) : make_float2(0.0f, 0.0f);
-                *reinterpret_cast<float2*>(sl + (f >> 6) * V4_ROW + (f & 63u)) = v;
-            }
-        }
-    };
-    stage(grp);
     for (; grp < n_groups; grp += stride) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
