@@ -171,7 +171,8 @@ static int apply_option(fvad_ctx* ctx, const std::string& name, const char* valu
         if (!to_bool(on)) return FVAD_ERR_INVALID_ARGUMENT;
         for (unsigned& w : tn.ws2_waits_cal) w = 0;
         if (on) { const int rc = calibrate_ws2_waits(ctx); if (rc) return rc; }
-    } else if (name == "no_pipeline") { if (!to_bool(tn.no_pipeline)) return FVAD_ERR_INVALID_ARGUMENT; }
+    } else if (name == "k4_plain_loads") { if (!to_bool(tn.k4_plain_loads)) return FVAD_ERR_INVALID_ARGUMENT; }
+    else if (name == "no_pipeline") { if (!to_bool(tn.no_pipeline)) return FVAD_ERR_INVALID_ARGUMENT; }
     else if (name == "trace_kernels") { if (!to_bool(tn.trace_kernels)) return FVAD_ERR_INVALID_ARGUMENT; }
     else if (name == "reproducible") { if (!to_bool(tn.reproducible)) return FVAD_ERR_INVALID_ARGUMENT; }
     else return FVAD_ERR_INVALID_ARGUMENT;
@@ -701,7 +702,7 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
             ws.jobs_mirror.assign(h_jobs, h_jobs + n_lanes);
         }
         time_begin(ctx, "fft1024_bandsum");
-        fvad_launch_vadfft_jobs(d_jobs, (int)n_lanes, (long)n_frames, plan, opts.min_bin, opts.max_bin, st, 0, ctx->n_cu);
+        fvad_launch_vadfft_jobs(d_jobs, (int)n_lanes, (long)n_frames, plan, opts.min_bin, opts.max_bin, st, 0, ctx->n_cu, ctx->tune.k4_plain_loads ? 1 : 0);
         time_end(ctx);
         return FVAD_OK;
     };

@@ -165,9 +165,10 @@ void fvad_launch_istft(const ChunkDesc* descs, int n_chunks, FftTables tb, const
 void fvad_launch_vadfft(const float* den, long n_frames, VadFftPlan pl, int min_bin, int max_bin,
                         float* band_sum, float* bins_or_null, hipStream_t stream);
 // all lanes in one launch: jobs is a device array of n_jobs entries, max_frames = max n_frames
-// any_bins: some job has a `bins` tap (the full-spectrum kernel must run; band sums come from the band kernel either way)
+// any_bins: some job has a `bins` tap (the full-spectrum kernel must run; band sums come from the band kernel either way);
+// plain_loads: the band kernel stages its frames with plain 8-byte loads, the path of unaligned jobs (context option k4_plain_loads)
 void fvad_launch_vadfft_jobs(const VadFftJob* jobs, int n_jobs, long max_frames, VadFftPlan pl,
-                             int min_bin, int max_bin, hipStream_t stream, int any_bins, int n_cu);
+                             int min_bin, int max_bin, hipStream_t stream, int any_bins, int n_cu, int plain_loads = 0);
 // batched FFT.fft for B3 / BASELINE config 2: n_fft in {320, 512, 1024, 2048} (pl is used for n_fft != 320)
 void fvad_launch_rfft_batch(const float* frames, long n_frames, int n_fft, const float* window,
                             FftTables tb, VadFftPlan pl, float* bins_or_null, float* mag_or_null,

@@ -934,7 +934,7 @@ __device__ __forceinline__ void dpp_butterfly(float& x, float sgn, int h) // h i
 // MINB / MAXB: the band as compile-time constants (the reference's 11..43: the index-order sum is then 33 adds), or 0, 0: the
 // band is the run-time pair (a select per bin)
 template <int MINB, int MAXB>
-__global__ __launch_bounds__(256) void vadfft1024_band_kernel(const VadFftJob* __restrict__ jobs, VadFftPlan pl, int min_bin, int max_bin)
+__global__ __launch_bounds__(256) void vadfft1024_band_kernel(const VadFftJob* __restrict__ jobs, VadFftPlan pl, int min_bin, int max_bin, int plain_loads)
 {
     // dynamic LDS (77 KB: over the static limit; two workgroups per CU): per wavefront a slab of 4 frames x 16 rows of 64 (+4)
     // floats; the window in the same padded rows; 48 magnitudes per frame
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(256) void vadfft1024_band_kernel(const VadFftJob* _
 
     // ---- staging
     float* sl = v4_smem + wave * (64 * V4_ROW);
-    const bool dma = (reinterpret_cast<uintptr_t>(job.den) & 15) == 0;
+    const bool dma = (reinterpret_cast<uintptr_t>(job.den) & 15) == 0 && !plain_loads;
     unsigned voff[17]; // 16-byte unit U = 64 jj + lane of the padded slab: row U / 17, unit U % 17 (16 = padding: re-fetches unit 15)
 #pragma unroll
     for (int jj = 0; jj < 17; ++jj) {
@@ -1290,7 +1290,7 @@ void fvad_launch_vadfft(const float* den, long n_frames, VadFftPlan pl, int min_
 }
 
 void fvad_launch_vadfft_jobs(const VadFftJob* jobs, int n_jobs, long max_frames, VadFftPlan pl,
-                             int min_bin, int max_bin, hipStream_t stream, int any_bins, int n_cu)
+                             int min_bin, int max_bin, hipStream_t stream, int any_bins, int n_cu, int plain)
 {
     if (n_jobs <= 0 || max_frames <= 0) return;
     if (pl.generic) {
@@ -1314,10 +1314,10 @@ void fvad_launch_vadfft_jobs(const VadFftJob* jobs, int n_jobs, long max_frames,
         constexpr size_t lds = (size_t)(4 * 64 * V4_ROW + 16 * V4_ROW + 16 * 48) * sizeof(float);
         if (min_bin == 11 && max_bin == 43) { // VADMachine.zig:146-151 at 48 kHz / 1024 points
             if (hipFuncSetAttribute((const void*)vadfft1024_band_kernel<11, 43>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return;
-            hipLaunchKernelGGL((vadfft1024_band_kernel<11, 43>), dim3((unsigned)per_job, (unsigned)n_jobs), dim3(256), lds, stream, jobs, pl, min_bin, max_bin);
+            hipLaunchKernelGGL((vadfft1024_band_kernel<11, 43>), dim3((unsigned)per_job, (unsigned)n_jobs), dim3(256), lds, stream, jobs, pl, min_bin, max_bin, plain);
         } else {
             if (hipFuncSetAttribute((const void*)vadfft1024_band_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return;
-            hipLaunchKernelGGL((vadfft1024_band_kernel<0, 0>), dim3((unsigned)per_job, (unsigned)n_jobs), dim3(256), lds, stream, jobs, pl, min_bin, max_bin);
+            hipLaunchKernelGGL((vadfft1024_band_kernel<0, 0>), dim3((unsigned)per_job, (unsigned)n_jobs), dim3(256), lds, stream, jobs, pl, min_bin, max_bin, plain);
         }
     }
 }

@@ -604,6 +604,43 @@ def test_engine_streaming_state_equals_one_shot(fv, gpu_ctx, pkg):
     assert np.array_equal(np.concatenate([p["chunk_rms"] for p in parts]), whole["chunk_rms"])
 
 
+def test_band_fft_kernel_paths_agree(fv, gpu_ctx, weights7, pkg):
+    # K4 at 1024 points with a band inside bins 1..47 runs vadfft1024_band_kernel (four frames per wavefront, pruned to the
+    # band): LDS-DMA staging or -- for a job that is not 16-byte aligned, forced here by the context option k4_plain_loads --
+    # plain loads, the same arithmetic; the reference's band 11..43 as compile-time constants or any other band at run time;
+    # the magnitude tap comes from the full-spectrum kernel and must not change the band sums; a band outside 1..47 falls
+    # back to the full-spectrum kernel.  Ragged lanes: a lane's last group of four frames is partial.
+    lanes = []
+    for i, n_ch in enumerate((7, 3, 1)):
+        pcm, _ = pkg.synth.make_stream(n_ch * 0.5 + 0.1, seed=60 + i)
+        lanes.append(pcm[0][: n_ch * 24000].copy())
+    base = gpu_ctx.engine_run(lanes)
+    with gpu_ctx.options(k4_plain_loads=1):
+        plain = gpu_ctx.engine_run(lanes)
+    taps = gpu_ctx.engine_run(lanes, want_bins=True)
+    for x, a, b, t in zip(lanes, base, plain, taps):
+        assert a["n_fft_frames"] == len(x) // 1024
+        assert np.array_equal(a["band_sum"], b["band_sum"])
+        assert np.array_equal(a["band_sum"], t["band_sum"])
+        ref = _oracle_lane(weights7, x)
+        assert_rel(a["band_sum"], ref["band"], 1e-4, what="band 11..43")
+        # the tap's magnitudes, summed in index order, are the other kernel's band sums: the same quantity to rounding
+        tap_sum = np.zeros(len(a["band_sum"]), np.float32)
+        for k in range(11, 44):
+            tap_sum = tap_sum + t["fft_bins"][:, k]
+        assert_rel(a["band_sum"], tap_sum, 2e-5, what="band kernel against the tap")
+    for lo, hi in ((1, 47), (20, 20), (5, 30), (11, 44), (0, 43), (11, 48), (40, 200)):
+        got = gpu_ctx.engine_run(lanes, want_bins=True, min_bin=lo, max_bin=hi)
+        with gpu_ctx.options(k4_plain_loads=1):
+            got_plain = gpu_ctx.engine_run(lanes, min_bin=lo, max_bin=hi)
+        for a, b in zip(got, got_plain):
+            assert np.array_equal(a["band_sum"], b["band_sum"]), (lo, hi)
+            tap_sum = np.zeros(len(a["band_sum"]), np.float32)
+            for k in range(lo, hi + 1):
+                tap_sum = tap_sum + a["fft_bins"][:, k]
+            assert_rel(a["band_sum"], tap_sum, 2e-5, floor=1e-6 * float(tap_sum.max()), what=f"band {lo}..{hi}")
+
+
 def test_config3_full_pipeline_82_chunks(fv, gpu_ctx, weights7, pkg):
     # BASELINE config 3: "batch = 4096 frames" -> 82 chunks = 4100 frames (chunks are 50 frames),
     # synthetic weights seed 7, as 2 lanes of 41 chunks
