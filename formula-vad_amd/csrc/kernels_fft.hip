@@ -343,8 +343,13 @@ __global__ __launch_bounds__(K1_BLOCK) void stft_kernel(const ChunkDesc* __restr
     const int part = blockIdx.y;
     const bool do_fft = parts == 1 || part < parts;
     const bool do_rms = parts == 1 || part == parts;
-    const int pa = parts == 1 ? 0 : (do_fft ? (N_PAIRS * part) / parts : 0);          // this workgroup's frame pairs
-    const int pb = parts == 1 ? N_PAIRS : (do_fft ? (N_PAIRS * (part + 1)) / parts : 0);
+    // Frame pairs 0 and 1 are the chunk's four warm-up rows = the last four frames of the PREVIOUS chunk of the lane.  They are
+    // not transformed again here: the workgroup of the previous chunk writes its frames 50..53 into this chunk's rows 0..3 as
+    // well (below), and a lane's first chunk of a launch takes them from the carry -- 50 transforms per chunk, not 54, and
+    // 480 history samples instead of 2400.  The same values either way (they were the same instructions on the same samples).
+    constexpr int P_LO = kWarmupRows / 2, P_OWN = N_PAIRS - P_LO; // 2, 25
+    const int pa = parts == 1 ? P_LO : (do_fft ? P_LO + (P_OWN * part) / parts : P_LO);          // this workgroup's frame pairs
+    const int pb = parts == 1 ? N_PAIRS : (do_fft ? P_LO + (P_OWN * (part + 1)) / parts : P_LO);
 
     for (int i = tid; i < kNFft; i += K1_BLOCK) s_win[i] = tb.win320[i];
     for (int i = tid; i < 162; i += K1_BLOCK) s_sth[i] = i >= 2 ? tb.st320[i - 2] * 0.5f : (i == 0 ? 0.0f : -0.5f);
@@ -362,7 +367,8 @@ __global__ __launch_bounds__(K1_BLOCK) void stft_kernel(const ChunkDesc* __restr
         const int dec0 = (kWarmupRows + 1) * kNHop;             // 800: where the chunk's own decimated samples start
         // float4s this workgroup needs: all of them for the RMS; for frame pairs [pa, pb) the decimated samples
         // [320 pa, 320 pb + 160), i.e. raw samples [960 pa, 960 pb + 480)
-        const int i4_lo = do_rms ? 0 : 240 * pa, i4_hi = do_rms ? (hist + kChunk48) / 4 : 240 * pb + 120;
+        // (the RMS workgroup starts at the 480 history samples frame 4 reaches back to: float4 480 = 240 P_LO)
+        const int i4_lo = 240 * (do_rms ? P_LO : pa), i4_hi = do_rms ? (hist + kChunk48) / 4 : 240 * pb + 120;
         const int i4_begin = (d.first && hist / 4 > i4_lo) ? hist / 4 : i4_lo;
         // float4 i4 of [history | chunk] holds samples 4 i4 .. 4 i4 + 3; the decimated ones are those at multiples of 3:
         // sample 3 q with q = ceil(4 i4 / 3), i.e. element r = 3 q - 4 i4 (0, 1 or 2), and element 3 too when r == 0.
@@ -456,11 +462,11 @@ __global__ __launch_bounds__(K1_BLOCK) void stft_kernel(const ChunkDesc* __restr
     const int k2 = bitrev_lane<32>(p);
     const float p_min = 1.0f / 1e12f; // std.math.pow(f32, 10, -12), NSNet2.zig:275
     float* spec_g = spec + (size_t)g * kFramesPerChunk * kNBins * 2;
-    const int fl_begin = d.first ? kWarmupRows : 0;
     // stores of the frame loop as buffer stores: the chunk's rows in the resource, the pair's first row in the scalar offset,
     // a lane's bins at constant 32-bit offsets (its half-wavefront's row included) -- no 64-bit address arithmetic per store
     const auto rs_f = __builtin_amdgcn_make_buffer_rsrc(feat_g, 0, kRowsPerChunk * kFeatStride * 4, 0x00020000);
     const auto rs_sp = __builtin_amdgcn_make_buffer_rsrc(spec_g, 0, kFramesPerChunk * kNBins * 2 * 4, 0x00020000);
+    const auto rs_fn = __builtin_amdgcn_make_buffer_rsrc(feat_g + kRowsPerChunk * kFeatStride, 0, kWarmupRows * kFeatStride * 4, 0x00020000);
     unsigned vo_f[3], vo_fn[3], vo_s[3], vo_sn[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
@@ -475,7 +481,6 @@ __global__ __launch_bounds__(K1_BLOCK) void stft_kernel(const ChunkDesc* __restr
     // 32..63 the second -- with no workgroup barrier: the complex transform goes through the wavefront's own LDS slab
     // (LDS accesses of one wavefront execute in program order), and wavefronts drift apart and cover each other's waits.
     for (int pi = pa + wave; pi < pb; pi += K1_BLOCK / 64) {
-        if (2 * pi < fl_begin) continue; // warm-up rows of a call's first chunk come from the carry (fl_begin is even: whole pairs)
         const int fl = 2 * pi + half;
         float* z = zb[wave][half];
         {
@@ -503,6 +508,8 @@ __global__ __launch_bounds__(K1_BLOCK) void stft_kernel(const ChunkDesc* __restr
         const unsigned so_s = (unsigned)(2 * pi - kWarmupRows) * (kNBins * 2 * 4); // used for fl >= kWarmupRows only (whole pairs)
         float* ftail = d.carry_out->feat_tail + (fl - kFramesPerChunk) * kNBins; // used for the lane's last chunk, fl >= 50
         const bool to_spec = fl >= kWarmupRows, to_tail = d.last && fl >= kFramesPerChunk;
+        const bool to_next = !d.last && fl >= kFramesPerChunk; // rows 0..3 of the lane's next chunk (chunk g + 1 of the launch)
+        const unsigned so_n = (unsigned)(2 * pi - kFramesPerChunk) * (kFeatStride * 4);
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int k = p + 32 * u;
@@ -527,6 +534,10 @@ __global__ __launch_bounds__(K1_BLOCK) void stft_kernel(const ChunkDesc* __restr
                 if (to_tail) {
                     if (k != 80) ftail[k] = fk;
                     ftail[kn] = fnk;
+                }
+                if (to_next) {
+                    if (k != 80) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fk), rs_fn, vo_f[u], so_n, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fnk), rs_fn, vo_fn[u], so_n, 0);
                 }
             }
         }
@@ -564,6 +575,13 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
     __shared__ __attribute__((aligned(16))) float slab[4][2][2 * kNFft]; // [wavefront][buffer][frame of the pair][320]
     __shared__ __attribute__((aligned(8))) float s_wn[kNFft];
     __shared__ __attribute__((aligned(8))) float s_st[2 * 80];
+    // a run's first pair (frames 2 P0 - 2, 2 P0 - 1: its seam) is the LAST pair of the run before it.  Wavefronts 1..3 of a
+    // workgroup hold the runs that follow wavefronts 0..2 (4 | n_runs), so they transform their seam pair into a shared buffer
+    // and raise a flag, and the wavefront before them takes its last pair from there instead of transforming it again:
+    // 55 instead of 58 transformed frames per chunk (parts = 1), three of four seam pairs fetched once instead of twice.
+    // A taker only ever waits for a wavefront of its own workgroup that waits for nobody.
+    __shared__ __attribute__((aligned(16))) float seam[4][2 * kNFft];
+    __shared__ int seam_flag[4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -578,7 +596,8 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
 
     for (int i = tid; i < kNFft; i += 256) s_wn[i] = tb.win320n[i];
     for (int i = tid; i < 160; i += 256) s_st[i] = tb.st320[i];
-    __syncthreads(); // the only workgroup barrier: window and un-mixing table
+    if (tid < 4) seam_flag[tid] = 0;
+    __syncthreads(); // the only workgroup barrier: window and un-mixing table, the seam flags
 
     LaneTw<5, 32> tw;
     lane_tw_load<5, 32, true>(tw, tb.tw160, p);
@@ -628,15 +647,25 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
         }
     };
     const int pi_begin = from_carry ? 0 : P0 - 1;
+    const bool give = wave > 0;  // (run > 0 then: never from_carry) this run's seam pair goes to seam[wave] for the wavefront before
+    const bool take = wave < 3;  // this run's last pair comes from seam[wave + 1] (the next wavefront: same chunk, next run)
+    const int P1c = take ? P1 - 1 : P1; // pairs this wavefront transforms: pi_begin .. P1c - 1
     Item cur[3];
     fetch(pi_begin, cur);
     // output: a pair's 960 samples start at a scalar offset of the chunk; a lane's three float4s at constant offsets
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(d.den, 0, kChunk48 * 4, 0x00020000);
     const float frac1 = 1.0f / 3.0f, frac2 = 2.0f / 3.0f;
+    float* prev = from_carry ? buf1 : nullptr; // the previous pair's buffer (from_carry: the carry's tail)
     for (int pi = pi_begin; pi < P1; ++pi) {
-        float* cb = ((pi - pi_begin) & 1) ? buf1 : buf0;   // this pair's buffer
-        float* pb = ((pi - pi_begin) & 1) ? buf0 : buf1;   // the previous pair's (from_carry: the carry's tail)
+        const bool taken = pi >= P1c, given = give && pi == pi_begin;
+        float* cb = given ? seam[wave] : (taken ? seam[wave + 1] : (prev == buf0 ? buf1 : buf0)); // this pair's buffer
+        float* pb = prev;
+        prev = cb;
         __builtin_amdgcn_wave_barrier();
+        if (taken) { // transformed by the next wavefront as its first pair, long ago
+            volatile int* fl = seam_flag;
+            while (fl[wave + 1] == 0) __builtin_amdgcn_s_sleep(1);
+        } else {
         {   // pre-mix gain * X into the length-160 complex sequence
             float* z = cb + half * kNFft;
 #pragma unroll
@@ -662,7 +691,7 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
             }
         }
         // the next pair's operands, into the registers the pre-mix has just consumed: in flight during this pair's transform and output
-        if (pi + 1 < P1) fetch(pi + 1, cur);
+        if (pi + 1 < P1c) fetch(pi + 1, cur);
         __builtin_amdgcn_wave_barrier();
         {
             float* z = cb + half * kNFft;
@@ -681,6 +710,11 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
                 const float2 wv = *reinterpret_cast<const float2*>(s_wn + n);
                 *reinterpret_cast<float2*>(z + n) = make_float2(v[k1].r * wv.x, v[k1].i * wv.y);
             }
+        }
+        if (given) { // LDS operations of a wavefront execute in order: the flag lands behind the pair
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) *(volatile int*)&seam_flag[wave] = 1;
+        }
         }
         __builtin_amdgcn_wave_barrier();
         // the pair's 320 decimated samples d[m] = (second half of the earlier frame) + (first half of the later one):
