@@ -183,6 +183,38 @@ def test_config2_fft_isolation_1024_frames(fv, gpu_ctx):
     assert_bins_close(b, np.stack([orc.rfft(x * wp) for x in fr2]), "rfft1024 batch")
 
 
+def test_fft_large_batch_kernel_matches_oracle_and_small_batch_kernel(fv, gpu_ctx):
+    # From 16384 frames on the 320-point batch runs rfft320_batch8_kernel (eight frames per wavefront, a 20-point register
+    # transform and three DPP exchange stages); below, the four-frame kernel.  Both against the oracle; against each other to
+    # rounding; a frame's result does not depend on where it sits in a large batch or on the batch's raggedness; bins only,
+    # magnitudes only and both give the same values.
+    rng = np.random.default_rng(11)
+    n = 16384 + 13
+    frames = rng.uniform(-1, 1, (n, 320)).astype(np.float32)
+    frames[5] = 0.0                      # a silent frame
+    frames[6] = 1.0                      # DC only
+    frames[7, ::2] = 1.0; frames[7, 1::2] = -1.0   # Nyquist only
+    win = orc.nsnet2_window()
+    f = fv.FFT(gpu_ctx, 320, 16000)
+    bins, mag = f.fft_batch(frames, win)
+    pick = [0, 1, 5, 6, 7, 8, 4095, 8191, 16383, 16384, n - 1]
+    ref = np.stack([orc.rfft(frames[i] * win) for i in pick])
+    assert_bins_close(bins[pick], ref, "large-batch bins")
+    assert_rel(mag[pick], np.abs(ref.astype(np.complex128)), 1e-4, floor=1e-3 * np.abs(ref).max(), what="large-batch |X|")
+    b_only, _ = f.fft_batch(frames, win, want_mag=False)
+    assert np.array_equal(b_only, bins)
+    small_b, small_m = f.fft_batch(frames[:1024], win)        # the four-frame kernel on the same frames
+    scale = np.abs(small_b).max()
+    assert np.abs(small_b - bins[:1024]).max() <= 2e-6 * scale
+    assert np.abs(small_m - mag[:1024]).max() <= 2e-6 * scale
+    # position and raggedness: the same frames shifted by 3 in a batch of another size
+    b2, m2 = f.fft_batch(frames[3:3 + 16384 + 1], win)
+    assert np.array_equal(b2, bins[3:3 + 16384 + 1]) and np.array_equal(m2, mag[3:3 + 16384 + 1])
+    # magnitudes of a magnitudes-only call (they leave through another path of the kernel) are the same values
+    _, m_only = f.fft_batch(frames, win, want_bins=False)
+    assert np.array_equal(m_only, mag)
+
+
 def test_fft_linearity_at_scale(fv, gpu_ctx):
     # size-independent property at 2^17 frames: FFT(a + b) == FFT(a) + FFT(b) within round-off,
     # and every frame of a replicated batch is bit-identical
