@@ -647,8 +647,10 @@ __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict_
         }
     };
     const int pi_begin = from_carry ? 0 : P0 - 1;
-    const bool give = wave > 0;  // (run > 0 then: never from_carry) this run's seam pair goes to seam[wave] for the wavefront before
-    const bool take = wave < 3;  // this run's last pair comes from seam[wave + 1] (the next wavefront: same chunk, next run)
+    // (only while a workgroup's four wavefronts are four consecutive runs of ONE chunk: 4 | n_runs, which fvad_launch_istft guarantees)
+    const bool share = (n_runs & 3) == 0;
+    const bool give = share && wave > 0;  // (run > 0 then: never from_carry) this run's seam pair goes to seam[wave] for the wavefront before
+    const bool take = share && wave < 3;  // this run's last pair comes from seam[wave + 1] (the next wavefront: same chunk, next run)
     const int P1c = take ? P1 - 1 : P1; // pairs this wavefront transforms: pi_begin .. P1c - 1
     Item cur[3];
     fetch(pi_begin, cur);
