@@ -67,6 +67,7 @@ pub extern "c" fn fvad_ctx_nn_math_effective(ctx: *const Ctx) c_int;
 pub extern "c" fn fvad_ctx_last_nn_path(ctx: *const Ctx) [*:0]const u8;
 pub extern "c" fn fvad_ctx_set_option(ctx: *Ctx, name: [*:0]const u8, value: ?[*:0]const u8) c_int; // e.g. "reproducible", "1"
 pub extern "c" fn fvad_ctx_ws_fallbacks(ctx: *Ctx, n: *u64) c_int;
+pub extern "c" fn fvad_ctx_ws2_waits(ctx: *const Ctx, wait_class: c_int) u32; // layer 1 | layer 2 << 16, 10 ns ticks
 
 pub extern "c" fn fvad_pipeline_create(ctx: *Ctx, cfg: *const PipelineConfig, callbacks: ?*const anyopaque, out: *?*Pipeline) c_int;
 pub extern "c" fn fvad_pipeline_destroy(p: ?*Pipeline) void;
