@@ -318,7 +318,8 @@ __device__ __forceinline__ float wave_sum(float v)
 // ============================================================================ K1
 constexpr int K1_THREADS = 256; // the threads that load, decimate and sum (the sample -> thread assignment fixes the RMS bits)
 constexpr int K1_BLOCK = 512;   // eight wavefronts share the decimated chunk in LDS for the frame loop
-constexpr int K1_DEC = (kRowsPerChunk + 1) * kNHop; // 8800 decimated samples: frames -4..49
+constexpr int K1_DEC = (kRowsPerChunk + 1) * kNHop; // 8800 decimated samples: frames -4..49 (indexed from frame -4; since the
+                                                     // warm-up frames are no longer transformed here only [640, 8800) is used)
 
 // parts == 1: one workgroup per chunk does everything.  parts > 1 (launches of a few chunks, where a chunk's 27 frame
 // pairs on one workgroup are a latency chain): blockIdx.y < parts transforms its share of the frame pairs from its share
@@ -565,7 +566,8 @@ void fvad_launch_stft(const ChunkDesc* descs, int n_chunks, FftTables tb, float*
 // the run's first); the chunk's very first pair takes both from the lane's carry instead.  Frames < 0 belong to the previous
 // chunk of the same lane (g - 1).  Every value is computed by the same instructions whatever the split: the same bits for
 // parts = 1, 2, 3, and the same bits as the round-3 kernel (one workgroup per chunk, 52 frames between two barriers per
-// 8 frames, 79 KB of LDS: two workgroups per CU, 46 % of its VALU-issue time busy) at 58 transformed frames instead of 52.
+// 8 frames, 79 KB of LDS: two workgroups per CU, 46 % of its VALU-issue time busy) at 55 transformed frames instead of 52 (58 without the
+// seam sharing below).
 // The spectrogram / gain operands of the next pair are fetched as soon as the pre-mix has consumed this pair's.
 __global__ __launch_bounds__(256) void istft_kernel(const ChunkDesc* __restrict__ descs, FftTables tb,
                                                     const float* __restrict__ spec,
