@@ -843,43 +843,58 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec3_kernel(const float* __res
 //     barrier per step.
 // gi holds Wx + Wb; Rb is added here.
 // (the body is a device function: gru_lat_kernel runs it for one layer, gru_ws2_fallback_kernel for both)
-template <int WAVES>
+// RT: row tiles (16 sequences each) per workgroup.  RT = 1: h_{t-1} of the step is copied into 100 registers up front.
+// RT = 2 (gru_lat2_kernel, launches of more 16-sequence tiles than CUs): what paces this kernel is the 1.92 MB of R every
+// workgroup re-streams from L2 per step, so two row tiles share ONE stream -- every fragment feeds both tiles' chains -- and
+// h_{t-1} is read from LDS where a super-step uses it (the registers hold two sets of accumulators instead).  An output is
+// the same chain of fmas either way: the same bits.
+template <int WAVES, int RT = 1>
 __device__ __forceinline__ void gru_lat_body(const float* gi, const float* __restrict__ R2frag, const float* __restrict__ bR,
-                                             float* hout, int T, int gi_js, int gi_gs, float (*hs)[GRU_J * 256])
+                                             float* hout, int T, int gi_js, int gi_gs, float* hs /* [2][RT][GRU_J * 256] */)
 {
     // gi_js / gi_gs: floats between unit tiles / between gates in a gi row (16, 400: gate-major rows of the
     // small-batch GEMM; 48, 16: the tile-major rows of the large-batch GEMM)
     typedef const __attribute__((address_space(1))) f32x4* gptr4;
     constexpr int D = 5;
+    constexpr bool HREG = RT == 1;
+    constexpr int HB = GRU_J * 256; // floats of one row tile's h in operand layout
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15;
     const int q = lane >> 4;
-    const size_t seq = (size_t)blockIdx.x * 16 + m;
-    const float* gi_seq = gi + seq * T * (3 * GRU_H) + 4 * q;
-    float* h_seq = hout + seq * T * GRU_H + 4 * q;
+    const float* gi_seq[RT];
+    float* h_seq[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const size_t seq = ((size_t)blockIdx.x * RT + rt) * 16 + m;
+        gi_seq[rt] = gi + seq * T * (3 * GRU_H) + 4 * q;
+        h_seq[rt] = hout + seq * T * GRU_H + 4 * q;
+    }
     const float* bR_q = bR + 4 * q;
 
     // ---- t = 0: h_{-1} = 0, so R h + Rb = Rb
     for (int J = wave; J < GRU_J; J += WAVES) {
-        const f32x4 giz = *reinterpret_cast<const f32x4*>(gi_seq + gi_js * J);
-        const f32x4 gir = *reinterpret_cast<const f32x4*>(gi_seq + gi_gs + gi_js * J);
-        const f32x4 gin = *reinterpret_cast<const f32x4*>(gi_seq + 2 * gi_gs + gi_js * J);
         const f32x4 bz = *reinterpret_cast<const f32x4*>(bR_q + 16 * J);
         const f32x4 br = *reinterpret_cast<const f32x4*>(bR_q + GRU_H + 16 * J);
         const f32x4 bn = *reinterpret_cast<const f32x4*>(bR_q + 2 * GRU_H + 16 * J);
-        f32x4 h;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float z = fast_sigmoid(giz[r] + bz[r]);
-            const float rr = fast_sigmoid(gir[r] + br[r]);
-            const float n = fast_tanh(gin[r] + rr * bn[r]);
-            h[r] = (1.0f - z) * n + z * 0.0f;
+        for (int rt = 0; rt < RT; ++rt) {
+            const f32x4 giz = *reinterpret_cast<const f32x4*>(gi_seq[rt] + gi_js * J);
+            const f32x4 gir = *reinterpret_cast<const f32x4*>(gi_seq[rt] + gi_gs + gi_js * J);
+            const f32x4 gin = *reinterpret_cast<const f32x4*>(gi_seq[rt] + 2 * gi_gs + gi_js * J);
+            f32x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = fast_sigmoid(giz[r] + bz[r]);
+                const float rr = fast_sigmoid(gir[r] + br[r]);
+                const float n = fast_tanh(gin[r] + rr * bn[r]);
+                h[r] = (1.0f - z) * n + z * 0.0f;
+            }
+            *reinterpret_cast<f32x4*>(h_seq[rt] + 16 * J) = h;
+            reinterpret_cast<f32x4*>(hs + rt * HB)[J * 64 + lane] = h;
         }
-        *reinterpret_cast<f32x4*>(h_seq + 16 * J) = h;
-        reinterpret_cast<f32x4*>(hs[0])[J * 64 + lane] = h;
     }
     __syncthreads();
     int cur = 0;
@@ -900,39 +915,54 @@ __device__ __forceinline__ void gru_lat_body(const float* gi, const float* __res
         wn[S] = *frag(wave, 2, S);
     }
     for (int t = 1; t < T; ++t) {
-        const float* gi_t = gi_seq + (size_t)t * (3 * GRU_H);
-        float* h_out = h_seq + (size_t)t * GRU_H;
-        const f32x4* hcur = reinterpret_cast<const f32x4*>(hs[cur]) + lane;
-        f32x4* hnxt = reinterpret_cast<f32x4*>(hs[cur ^ 1]) + lane;
+        const f32x4* hcur = reinterpret_cast<const f32x4*>(hs + cur * (RT * HB)) + lane;
+        f32x4* hnxt = reinterpret_cast<f32x4*>(hs + (cur ^ 1) * (RT * HB)) + lane;
 
-        f32x4 hreg[GRU_J];
+        f32x4 hreg[HREG ? GRU_J : 1];
+        if (HREG) {
 #pragma unroll
-        for (int S = 0; S < GRU_J; ++S) hreg[S] = hcur[S * 64];
+            for (int S = 0; S < GRU_J; ++S) hreg[S] = hcur[S * 64];
+        }
 
         for (int J = wave; J < GRU_J; J += WAVES) {
             const int Jn = (J + WAVES < GRU_J) ? J + WAVES : wave; // this wave's next tile; after the last one, its first tile of the next step
             // two accumulation chains per gate (even / odd super-steps), summed at the end: the order of
             // gru_ws_kernel, whose fallback this kernel is -- both give the same bits
-            f32x4 az[2], ar[2], an[2];
-            az[0] = az[1] = ar[0] = ar[1] = an[0] = an[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            f32x4 giz, gir, gin, hp, bz, br, bn;
+            f32x4 az[RT][2], ar[RT][2], an[RT][2];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) az[rt][0] = az[rt][1] = ar[rt][0] = ar[rt][1] = an[rt][0] = an[rt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 giz[RT], gir[RT], gin[RT], hp[RT], bz, br, bn;
 #pragma unroll
             for (int S = 0; S < GRU_J; ++S) {
                 const int k = S % D;
                 const int c = S & 1;
-                const f32x4 hv = hreg[S];
-                az[c] = MFMA16(wz[k].x, hv.x, az[c]);
-                ar[c] = MFMA16(wr[k].x, hv.x, ar[c]);
-                an[c] = MFMA16(wn[k].x, hv.x, an[c]);
-                az[c] = MFMA16(wz[k].y, hv.y, az[c]);
-                ar[c] = MFMA16(wr[k].y, hv.y, ar[c]);
-                an[c] = MFMA16(wn[k].y, hv.y, an[c]);
-                az[c] = MFMA16(wz[k].z, hv.z, az[c]);
-                ar[c] = MFMA16(wr[k].z, hv.z, ar[c]);
-                an[c] = MFMA16(wn[k].z, hv.z, an[c]);
-                az[c] = MFMA16(wz[k].w, hv.w, az[c]);
-                ar[c] = MFMA16(wr[k].w, hv.w, ar[c]);
-                an[c] = MFMA16(wn[k].w, hv.w, an[c]);
+                f32x4 hv[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) hv[rt] = HREG ? hreg[HREG ? S : 0] : hcur[(rt * GRU_J + S) * 64];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    az[rt][c] = MFMA16(wz[k].x, hv[rt].x, az[rt][c]);
+                    ar[rt][c] = MFMA16(wr[k].x, hv[rt].x, ar[rt][c]);
+                    an[rt][c] = MFMA16(wn[k].x, hv[rt].x, an[rt][c]);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    az[rt][c] = MFMA16(wz[k].y, hv[rt].y, az[rt][c]);
+                    ar[rt][c] = MFMA16(wr[k].y, hv[rt].y, ar[rt][c]);
+                    an[rt][c] = MFMA16(wn[k].y, hv[rt].y, an[rt][c]);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    az[rt][c] = MFMA16(wz[k].z, hv[rt].z, az[rt][c]);
+                    ar[rt][c] = MFMA16(wr[k].z, hv[rt].z, ar[rt][c]);
+                    an[rt][c] = MFMA16(wn[k].z, hv[rt].z, an[rt][c]);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    az[rt][c] = MFMA16(wz[k].w, hv[rt].w, az[rt][c]);
+                    ar[rt][c] = MFMA16(wr[k].w, hv[rt].w, ar[rt][c]);
+                    an[rt][c] = MFMA16(wn[k].w, hv[rt].w, an[rt][c]);
+                }
                 // refill the slot with the super-step D ahead; past the end of this tile that is the
                 // next tile's super-step S + D - 25
                 if (S + D < GRU_J) {
@@ -945,28 +975,35 @@ __device__ __forceinline__ void gru_lat_body(const float* gi, const float* __res
                     wn[k] = *frag(Jn, 2, S + D - GRU_J);
                 }
                 if (S == 15) {
-                    giz = *reinterpret_cast<const f32x4*>(gi_t + gi_js * J);
-                    gir = *reinterpret_cast<const f32x4*>(gi_t + gi_gs + gi_js * J);
-                    gin = *reinterpret_cast<const f32x4*>(gi_t + 2 * gi_gs + gi_js * J);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const float* gi_t = gi_seq[rt] + (size_t)t * (3 * GRU_H);
+                        giz[rt] = *reinterpret_cast<const f32x4*>(gi_t + gi_js * J);
+                        gir[rt] = *reinterpret_cast<const f32x4*>(gi_t + gi_gs + gi_js * J);
+                        gin[rt] = *reinterpret_cast<const f32x4*>(gi_t + 2 * gi_gs + gi_js * J);
+                        hp[rt] = hcur[(rt * GRU_J + J) * 64];
+                    }
                     bz = *reinterpret_cast<const f32x4*>(bR_q + 16 * J);
                     br = *reinterpret_cast<const f32x4*>(bR_q + GRU_H + 16 * J);
                     bn = *reinterpret_cast<const f32x4*>(bR_q + 2 * GRU_H + 16 * J);
-                    hp = hcur[J * 64];
                 }
             }
-            const f32x4 sz = az[0] + az[1], sr = ar[0] + ar[1], sn = an[0] + an[1];
-            f32x4 h;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float z = fast_sigmoid(giz[r] + (sz[r] + bz[r]));
-                const float rr = fast_sigmoid(gir[r] + (sr[r] + br[r]));
-                const float n = fast_tanh(gin[r] + rr * (sn[r] + bn[r]));
-                h[r] = (1.0f - z) * n + z * hp[r];
+            for (int rt = 0; rt < RT; ++rt) {
+                const f32x4 sz = az[rt][0] + az[rt][1], sr = ar[rt][0] + ar[rt][1], sn = an[rt][0] + an[rt][1];
+                f32x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z = fast_sigmoid(giz[rt][r] + (sz[r] + bz[r]));
+                    const float rr = fast_sigmoid(gir[rt][r] + (sr[r] + br[r]));
+                    const float n = fast_tanh(gin[rt][r] + rr * (sn[r] + bn[r]));
+                    h[r] = (1.0f - z) * n + z * hp[rt][r];
+                }
+                *reinterpret_cast<f32x4*>(h_seq[rt] + (size_t)t * GRU_H + 16 * J) = h;
+                hnxt[(rt * GRU_J + J) * 64] = h;
             }
-            *reinterpret_cast<f32x4*>(h_out + 16 * J) = h;
-            hnxt[J * 64] = h;
         }
-        __syncthreads(); // h_t complete in hs[cur ^ 1]; everyone has read hs[cur]
+        __syncthreads(); // h_t complete in the other buffer; everyone has read this one
         cur ^= 1;
     }
 }
@@ -981,7 +1018,15 @@ __global__ __launch_bounds__(WAVES * 64) void gru_lat_kernel(const float* __rest
     __shared__ __attribute__((aligned(16))) float hs[2][GRU_J * 256];
     // launched behind gru_ws_kernel as its fallback: runs only if that kernel raised *guard (kernels_ws.hip)
     if (guard && *guard == 0) return;
-    gru_lat_body<WAVES>(gi, R2frag, bR, hout, T, gi_js, gi_gs, hs);
+    gru_lat_body<WAVES>(gi, R2frag, bR, hout, T, gi_js, gi_gs, &hs[0][0]);
+}
+
+// two row tiles per workgroup, one stream of R for both (gru_lat_body<8, 2>): 102 KB of dynamic LDS
+__global__ __launch_bounds__(512) void gru_lat2_kernel(const float* __restrict__ gi, const float* __restrict__ R2frag,
+                                                       const float* __restrict__ bR, float* hout, int T, int gi_js, int gi_gs)
+{
+    extern __shared__ __attribute__((aligned(16))) float lat2_hs[];
+    gru_lat_body<8, 2>(gi, R2frag, bR, hout, T, gi_js, gi_gs, lat2_hs);
 }
 
 // The whole fallback of the pipelined two-layer recurrence (kernels_ws.hip: gru_ws2_kernel / gru_ws2k_kernel) in ONE
@@ -1032,7 +1077,7 @@ __global__ __launch_bounds__(512) void gru_ws2_fallback_kernel(float* gi, const 
             __threadfence();
             __syncthreads();
         }
-        gru_lat_body<8>(gi, R1frag, bR1, h1, T, 48, 16, hs);
+        gru_lat_body<8>(gi, R1frag, bR1, h1, T, 48, 16, &hs[0][0]);
         __threadfence(); // h1 rows written by the other wavefronts of this workgroup
         __syncthreads();
         for (int t = 0; t < T; ++t) {
@@ -1055,7 +1100,7 @@ __global__ __launch_bounds__(512) void gru_ws2_fallback_kernel(float* gi, const 
         }
         __threadfence(); // gi rows rewritten: this CU's L1 may still hold layer 1's gi in those lines
         __syncthreads();
-        gru_lat_body<8>(gi, R2frag, bR2, h2, T, 48, 16, hs);
+        gru_lat_body<8>(gi, R2frag, bR2, h2, T, 48, 16, &hs[0][0]);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1080,9 +1125,16 @@ int fvad_launch_gru_ws2_fallback(float* gi, const float* feat, const float* W1fr
 }
 
 int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, float* hout,
-                        long n_seq_pad, int T, const unsigned* guard, int tile_major, hipStream_t stream)
+                        long n_seq_pad, int T, const unsigned* guard, int tile_major, hipStream_t stream, int two_row_tiles)
 {
     if (n_seq_pad % 16) return -1;
+    if (two_row_tiles && !guard && n_seq_pad % 32 == 0) { // same bits; for launches of more 16-sequence tiles than CUs
+        constexpr size_t lds = (size_t)2 * 2 * GRU_J * 256 * sizeof(float);
+        if (hipFuncSetAttribute((const void*)gru_lat2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+        hipLaunchKernelGGL(gru_lat2_kernel, dim3((unsigned)(n_seq_pad / 32)), dim3(512), lds, stream, gi, R2frag, bR, hout, T,
+                           tile_major ? 48 : 16, tile_major ? 16 : GRU_H);
+        return 0;
+    }
     hipLaunchKernelGGL((gru_lat_kernel<8>), dim3((unsigned)(n_seq_pad / 16)), dim3(512), 0, stream, gi, R2frag, bR, hout, T, guard,
                        tile_major ? 48 : 16, tile_major ? 16 : GRU_H);
     return 0;

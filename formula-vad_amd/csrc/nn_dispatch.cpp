@@ -319,7 +319,12 @@ template <class F> static int ws_serialised(fvad_ctx* ctx, F&& launch)
 static int launch_gru(fvad_ctx* ctx, GruChoice c, const float* gi, const DevBuf& r_v2, const float* bR,
                       float* hout, long n_pad, int T, int layer, int tile_major)
 {
-    if (c.version == 4) return fvad_launch_gru_lat(gi, r_v2.p, bR, hout, n_pad, T, nullptr, tile_major, ctx->stream);
+    if (c.version == 4) {
+        // more 16-sequence tiles than CUs, but no more 32-sequence pairs: two row tiles per workgroup share one stream of R in ONE
+        // round instead of two (same bits; 8192 sequences: 4.03 against 4.43 ms per layer)
+        const int two = ctx->tune.gru_lat2 > 0 || (ctx->tune.gru_lat2 < 0 && n_pad / 16 > ctx->n_cu && n_pad / 32 <= ctx->n_cu);
+        return fvad_launch_gru_lat(gi, r_v2.p, bR, hout, n_pad, T, nullptr, tile_major, ctx->stream, two);
+    }
     if (c.version == 5) {
         Workspace& ws = ctx->ws;
         unsigned* err = ws.ws_sync + 512;

@@ -1719,6 +1719,28 @@ def test_weight_stationary_handoff_is_deterministic_under_load(fv, gpu_ctx, weig
         bg.close()
 
 
+def test_low_latency_recurrence_with_two_row_tiles_gives_the_same_bits(fv, gpu_ctx, weights7):
+    # 4097..8192 sequences: more 16-sequence tiles than CUs, so gru_lat runs as gru_lat2_kernel -- two row tiles per workgroup on
+    # one stream of R, one round instead of two.  Same chains per output: the option gru_lat2 (0 never, 1 always, unset: by launch
+    # size) must not change a bit; a few sequences against the oracle.
+    rng = np.random.default_rng(41)
+    f = rng.uniform(-11, 2, (4200, 54, 161)).astype(np.float32)
+    auto = gpu_ctx.nsnet2_forward(f)
+    assert "gru_lat" in gpu_ctx.last_nn_path()
+    with gpu_ctx.options(gru_lat2=0):
+        one = gpu_ctx.nsnet2_forward(f)
+    with gpu_ctx.options(gru_lat2=1):
+        two = gpu_ctx.nsnet2_forward(f)
+        small = gpu_ctx.nsnet2_forward(f[:3000])          # one round of 16-sequence workgroups would do: forced all the same
+    assert np.array_equal(auto, one) and np.array_equal(auto, two)
+    assert np.array_equal(small, auto[:3000])
+    for i in (0, 17, 4199):
+        assert_rel(auto[i], orc.nsnet2_forward(weights7, f[i]), 1e-4, floor=1e-2, what=f"gains of sequence {i}")
+    L = fv.lib()
+    for bad in ("2", "-2", "x"):
+        assert L.fvad_ctx_set_option(gpu_ctx.h, b"gru_lat2", bad.encode()) == fv.FVAD_ERR_INVALID_ARGUMENT
+
+
 def test_first_poll_waits_are_timing_only(fv, weights7):
     # gru_ws2k waits a fixed interval before a step's first poll of its peers' flags: a built-in table per group shape, which
     # the context option ws2_calibrate re-measures on this device and ws2_waits sets by hand (include/fvad.h:
