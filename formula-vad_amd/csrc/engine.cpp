@@ -171,10 +171,10 @@ static int apply_option(fvad_ctx* ctx, const std::string& name, const char* valu
         if (!to_bool(on)) return FVAD_ERR_INVALID_ARGUMENT;
         for (unsigned& w : tn.ws2_waits_cal) w = 0;
         if (on) { const int rc = calibrate_ws2_waits(ctx); if (rc) return rc; }
-    } else if (name == "gru_lat2") { // same bits either way
-        long c = -1;
-        if (!unset && (!to_long(c) || c < -1 || c > 1)) return FVAD_ERR_INVALID_ARGUMENT;
-        tn.gru_lat2 = (int)c;
+    } else if (name == "gru_lat_tiles") { // same bits whatever the value
+        long c = 0;
+        if (!unset && (!to_long(c) || c < 1 || c > 3)) return FVAD_ERR_INVALID_ARGUMENT;
+        tn.gru_lat_tiles = (int)c;
     } else if (name == "k4_plain_loads") { if (!to_bool(tn.k4_plain_loads)) return FVAD_ERR_INVALID_ARGUMENT; }
     else if (name == "no_pipeline") { if (!to_bool(tn.no_pipeline)) return FVAD_ERR_INVALID_ARGUMENT; }
     else if (name == "trace_kernels") { if (!to_bool(tn.trace_kernels)) return FVAD_ERR_INVALID_ARGUMENT; }

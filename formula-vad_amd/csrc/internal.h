@@ -166,7 +166,7 @@ struct Tuning {
     int h3_waves = 0;            // 0 / 8 / 12
     long max_chunks = 49152;     // chunks per launch when the caller passes 0
     bool no_pipeline = false;    // host-buffer path: single lane group
-    int gru_lat2 = -1;           // gru_lat with two row tiles per workgroup (gru_lat2_kernel: same bits): -1 by launch size, 0 never, 1 always
+    int gru_lat_tiles = 0;       // row tiles per workgroup of gru_lat (1, 2, 3: the same bits); 0 = by launch size (the cost model)
     bool k4_plain_loads = false; // vadfft1024_band_kernel: stage frames with plain 8-byte loads even when they are 16-byte aligned (the path
                                  // an unaligned job takes; same arithmetic, same bits: tests)
     int copy_threads = 8;        // memcpy threads of the pinned staging rings

@@ -106,7 +106,7 @@ int fvad_launch_gru_ws2_fallback(float* gi, const float* feat, const float* W1fr
                                  const float* W2frag_nt2, const float* bW2, const float* R2frag, const float* bR2, float* h1, float* h2,
                                  long n_seq_pad, int T, unsigned* sync, unsigned long long* fallbacks, hipStream_t stream);
 int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, float* hout,
-                        long n_seq_pad, int T, const unsigned* guard, int tile_major, hipStream_t stream, int two_row_tiles = 0);
+                        long n_seq_pad, int T, const unsigned* guard, int tile_major, hipStream_t stream, int row_tiles = 1);
 // small batches: recurrent weights stationary in registers across 25 x G workgroups, h exchanged per step
 // (kernels_ws.hip).  hx: fvad_gru_ws_exchange_floats(n_seq_pad) floats; flags: 256 zeroed words per launch;
 // err: one zeroed word shared by the launches of a network pass.  Returns -1 when the batch is too large.

@@ -844,9 +844,9 @@ __global__ __launch_bounds__(WAVES * 64) void gru_rec3_kernel(const float* __res
 // gi holds Wx + Wb; Rb is added here.
 // (the body is a device function: gru_lat_kernel runs it for one layer, gru_ws2_fallback_kernel for both)
 // RT: row tiles (16 sequences each) per workgroup.  RT = 1: h_{t-1} of the step is copied into 100 registers up front.
-// RT = 2 (gru_lat2_kernel, launches of more 16-sequence tiles than CUs): what paces this kernel is the 1.92 MB of R every
-// workgroup re-streams from L2 per step, so two row tiles share ONE stream -- every fragment feeds both tiles' chains -- and
-// h_{t-1} is read from LDS where a super-step uses it (the registers hold two sets of accumulators instead).  An output is
+// RT = 2, 3 (gru_lat2_kernel, gru_lat3_kernel: launches of more 16-sequence tiles than CUs): what paces this kernel is the 1.92 MB of R every
+// workgroup re-streams from L2 per step, so the row tiles share ONE stream -- every fragment feeds all their chains -- and
+// h_{t-1} is read from LDS where a super-step uses it (the registers hold RT sets of accumulators instead).  An output is
 // the same chain of fmas either way: the same bits.
 template <int WAVES, int RT = 1>
 __device__ __forceinline__ void gru_lat_body(const float* gi, const float* __restrict__ R2frag, const float* __restrict__ bR,
@@ -1028,6 +1028,13 @@ __global__ __launch_bounds__(512) void gru_lat2_kernel(const float* __restrict__
     extern __shared__ __attribute__((aligned(16))) float lat2_hs[];
     gru_lat_body<8, 2>(gi, R2frag, bR, hout, T, gi_js, gi_gs, lat2_hs);
 }
+// three row tiles (154 KB of LDS, 190 VGPRs): 8193..12288 sequences in one round
+__global__ __launch_bounds__(512) void gru_lat3_kernel(const float* __restrict__ gi, const float* __restrict__ R2frag,
+                                                       const float* __restrict__ bR, float* hout, int T, int gi_js, int gi_gs)
+{
+    extern __shared__ __attribute__((aligned(16))) float lat3_hs[];
+    gru_lat_body<8, 3>(gi, R2frag, bR, hout, T, gi_js, gi_gs, lat3_hs);
+}
 
 // The whole fallback of the pipelined two-layer recurrence (kernels_ws.hip: gru_ws2_kernel / gru_ws2k_kernel) in ONE
 // launch behind it -- it used to be three guarded launches (gru_lat, layer 2's input projection, gru_lat) and a fourth
@@ -1125,10 +1132,17 @@ int fvad_launch_gru_ws2_fallback(float* gi, const float* feat, const float* W1fr
 }
 
 int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, float* hout,
-                        long n_seq_pad, int T, const unsigned* guard, int tile_major, hipStream_t stream, int two_row_tiles)
+                        long n_seq_pad, int T, const unsigned* guard, int tile_major, hipStream_t stream, int row_tiles)
 {
     if (n_seq_pad % 16) return -1;
-    if (two_row_tiles && !guard && n_seq_pad % 32 == 0) { // same bits; for launches of more 16-sequence tiles than CUs
+    if (row_tiles == 3 && !guard && n_seq_pad % 48 == 0) {
+        constexpr size_t lds3 = (size_t)2 * 3 * GRU_J * 256 * sizeof(float);
+        if (hipFuncSetAttribute((const void*)gru_lat3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess) return -2;
+        hipLaunchKernelGGL(gru_lat3_kernel, dim3((unsigned)(n_seq_pad / 48)), dim3(512), lds3, stream, gi, R2frag, bR, hout, T,
+                           tile_major ? 48 : 16, tile_major ? 16 : GRU_H);
+        return 0;
+    }
+    if (row_tiles == 2 && !guard && n_seq_pad % 32 == 0) { // same bits; for launches of more 16-sequence tiles than CUs
         constexpr size_t lds = (size_t)2 * 2 * GRU_J * 256 * sizeof(float);
         if (hipFuncSetAttribute((const void*)gru_lat2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
         hipLaunchKernelGGL(gru_lat2_kernel, dim3((unsigned)(n_seq_pad / 32)), dim3(512), lds, stream, gi, R2frag, bR, hout, T,

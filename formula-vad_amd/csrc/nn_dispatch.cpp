@@ -137,10 +137,28 @@ static double gru_ws2_cost_both_layers(long n_pad, int T, int n_cu, int variant)
     return RT == 1 ? 55.0 * 13e3 : 55.0 * (7e3 + 5.9e3 * RT); // measured: tools/ws2_ab.py, tools/ws2m_ab.py
 }
 
+// gru_lat with 1, 2 or 3 row tiles per workgroup on one stream of R (gru_lat_kernel, gru_lat2_kernel, gru_lat3_kernel: the same
+// bits): measured 41 / 73.6 / 103 us per step, on the scale of this model 120k / 215k / 301k clocks per round of workgroups
+static double gru_lat_cost(long n_pad, int n_cu, int* rt_out)
+{
+    static const double per_step[4] = {0, 120e3, 215e3, 301e3};
+    double best = 1e30;
+    int best_rt = 1;
+    for (int rt = 1; rt <= 3; ++rt) {
+        if (n_pad % (16 * rt)) continue;
+        const long wgs = n_pad / (16 * rt);
+        const double c = (double)((wgs + n_cu - 1) / n_cu) * per_step[rt];
+        if (c < best) { best = c; best_rt = rt; }
+    }
+    if (rt_out) *rt_out = best_rt;
+    return best;
+}
+
 static double gru_cost(long n_pad, int waves, int n_cu)
 {
-    const double per_step = waves == 12 ? 25 * 32.3e3 : waves == 8 ? 25 * 23.4e3 : waves == 4 ? 25 * 13.0e3 : 120e3;
-    const long wgs = n_pad / (waves ? 16 * waves : 16);
+    if (waves == 0) return gru_lat_cost(n_pad, n_cu, nullptr);
+    const double per_step = waves == 12 ? 25 * 32.3e3 : waves == 8 ? 25 * 23.4e3 : 25 * 13.0e3;
+    const long wgs = n_pad / (16 * waves);
     return (double)((wgs + n_cu - 1) / n_cu) * per_step;
 }
 
@@ -320,10 +338,12 @@ static int launch_gru(fvad_ctx* ctx, GruChoice c, const float* gi, const DevBuf&
                       float* hout, long n_pad, int T, int layer, int tile_major)
 {
     if (c.version == 4) {
-        // more 16-sequence tiles than CUs, but no more 32-sequence pairs: two row tiles per workgroup share one stream of R in ONE
-        // round instead of two (same bits; 8192 sequences: 4.03 against 4.43 ms per layer)
-        const int two = ctx->tune.gru_lat2 > 0 || (ctx->tune.gru_lat2 < 0 && n_pad / 16 > ctx->n_cu && n_pad / 32 <= ctx->n_cu);
-        return fvad_launch_gru_lat(gi, r_v2.p, bR, hout, n_pad, T, nullptr, tile_major, ctx->stream, two);
+        // more 16-sequence tiles than CUs: two or three row tiles per workgroup share one stream of R in fewer rounds of
+        // workgroups (same bits; 8192 sequences: 4.03 against 4.43 ms per layer, 12288: 5.6 against gru_rec3<4>'s 6.7)
+        int rt = 1;
+        (void)gru_lat_cost(n_pad, ctx->n_cu, &rt);
+        if (ctx->tune.gru_lat_tiles > 0) rt = (n_pad % (16 * ctx->tune.gru_lat_tiles) == 0) ? ctx->tune.gru_lat_tiles : 1;
+        return fvad_launch_gru_lat(gi, r_v2.p, bR, hout, n_pad, T, nullptr, tile_major, ctx->stream, rt);
     }
     if (c.version == 5) {
         Workspace& ws = ctx->ws;

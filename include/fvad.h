@@ -316,8 +316,8 @@ const char *fvad_ctx_last_nn_path(const fvad_ctx *ctx);
  * fvad_ctx_set_nn_math) | "gru_kernel" ("v3w12" | "v3w8" | "v3w4" | "v4w8" | "v5w0" | "v6w0") | "gemm_kernel" ("v1" |
  * "v3" | "v3nofold") | "h3_waves" ("8" | "12") | "max_chunks" | "copy_threads" | "no_pipeline" | "trace_kernels" |
  * "ws_spin_ticks" | "ws2_variant" (diagnostic bit mask; the timing-only bits exist in the diagnostics build alone) |
- * "ws2_waits" | "ws2_calibrate" (below) | "k4_plain_loads" (the band FFT's staging path of unaligned frames) | "gru_lat2" ("0" | "1": the low-latency recurrence
- * with two row tiles per workgroup never / always instead of by launch size; same bits); value NULL or ""
+ * "ws2_waits" | "ws2_calibrate" (below) | "k4_plain_loads" (the band FFT's staging path of unaligned frames) | "gru_lat_tiles" ("1" | "2" | "3": row tiles per
+ * workgroup of the low-latency recurrence instead of the cost model's choice; same bits); value NULL or ""
  * restores the default.  The environment variables FVAD_<NAME> are read ONCE, by
  * fvad_ctx_create, as initial values (a bad value fails the creation); the data path never reads the environment. */
 int fvad_ctx_set_option(fvad_ctx *ctx, const char *name, const char *value);

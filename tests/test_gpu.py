@@ -1719,26 +1719,31 @@ def test_weight_stationary_handoff_is_deterministic_under_load(fv, gpu_ctx, weig
         bg.close()
 
 
-def test_low_latency_recurrence_with_two_row_tiles_gives_the_same_bits(fv, gpu_ctx, weights7):
-    # 4097..8192 sequences: more 16-sequence tiles than CUs, so gru_lat runs as gru_lat2_kernel -- two row tiles per workgroup on
-    # one stream of R, one round instead of two.  Same chains per output: the option gru_lat2 (0 never, 1 always, unset: by launch
-    # size) must not change a bit; a few sequences against the oracle.
+def test_low_latency_recurrence_with_several_row_tiles_gives_the_same_bits(fv, gpu_ctx, weights7):
+    # More 16-sequence tiles than CUs: gru_lat runs with two or three row tiles per workgroup on one stream of R
+    # (gru_lat2_kernel, gru_lat3_kernel) -- one round of workgroups instead of two or three.  Same chains per output: the option
+    # gru_lat_tiles (1, 2, 3; unset: the cost model) must not change a bit; a few sequences against the oracle.
     rng = np.random.default_rng(41)
-    f = rng.uniform(-11, 2, (4200, 54, 161)).astype(np.float32)
+    f = rng.uniform(-11, 2, (4200, 54, 161)).astype(np.float32)       # padded to 4224 = 88 x 48 sequences
     auto = gpu_ctx.nsnet2_forward(f)
     assert "gru_lat" in gpu_ctx.last_nn_path()
-    with gpu_ctx.options(gru_lat2=0):
-        one = gpu_ctx.nsnet2_forward(f)
-    with gpu_ctx.options(gru_lat2=1):
-        two = gpu_ctx.nsnet2_forward(f)
-        small = gpu_ctx.nsnet2_forward(f[:3000])          # one round of 16-sequence workgroups would do: forced all the same
-    assert np.array_equal(auto, one) and np.array_equal(auto, two)
-    assert np.array_equal(small, auto[:3000])
+    for tiles in (1, 2, 3):
+        with gpu_ctx.options(gru_lat_tiles=tiles):
+            assert np.array_equal(gpu_ctx.nsnet2_forward(f), auto), tiles
+            if tiles == 3:
+                assert np.array_equal(gpu_ctx.nsnet2_forward(f[:3000]), auto[:3000])   # a launch that one round of single tiles would serve
     for i in (0, 17, 4199):
         assert_rel(auto[i], orc.nsnet2_forward(weights7, f[i]), 1e-4, floor=1e-2, what=f"gains of sequence {i}")
+    # 8193..12288 sequences: three row tiles per workgroup beat gru_rec3<4> in the cost model
+    big = rng.uniform(-11, 2, (9216, 54, 161)).astype(np.float32)
+    g = gpu_ctx.nsnet2_forward(big)
+    assert "gru_lat" in gpu_ctx.last_nn_path(), gpu_ctx.last_nn_path()
+    with gpu_ctx.options(gru_lat_tiles=1):
+        assert np.array_equal(gpu_ctx.nsnet2_forward(big), g)
+    assert_rel(g[9215], orc.nsnet2_forward(weights7, big[9215]), 1e-4, floor=1e-2, what="gains of the last sequence of 9216")
     L = fv.lib()
-    for bad in ("2", "-2", "x"):
-        assert L.fvad_ctx_set_option(gpu_ctx.h, b"gru_lat2", bad.encode()) == fv.FVAD_ERR_INVALID_ARGUMENT
+    for bad in ("0", "4", "-1", "x"):
+        assert L.fvad_ctx_set_option(gpu_ctx.h, b"gru_lat_tiles", bad.encode()) == fv.FVAD_ERR_INVALID_ARGUMENT
 
 
 def test_first_poll_waits_are_timing_only(fv, weights7):
