@@ -560,8 +560,9 @@ __global__ __launch_bounds__(512) void gru_ws2_kernel(const float* __restrict__ 
 constexpr unsigned WS2K_WAIT_L1 = 150, WS2K_WAIT_L2 = 270, WS2K_WAIT_L1_ONE = 220, WS2K_WAIT_L2_ONE = 220;
 // the same with layer 1's input projection in the kernel (GI1K): the projection's MFMAs run in the hand-off's shadow and move
 // the moment the peers' flags become visible; swept again with tools/ws2_delay.py (82 sequences: 370 us at the waits above,
-// 324 us at these; one chunk: 287 -> 280 us)
-constexpr unsigned WS2K_WAIT_L1_G = 240, WS2K_WAIT_L2_G = 320, WS2K_WAIT_L1_ONE_G = 240, WS2K_WAIT_L2_ONE_G = 240;
+// 324 us at these; one chunk: 287 -> 280 us); layer 2's wait 3.2 -> 2.8 us after the context option ws2_calibrate had picked
+// (240, 280) on every box it ran on (three in a row: 328 -> 322 us)
+constexpr unsigned WS2K_WAIT_L1_G = 240, WS2K_WAIT_L2_G = 280, WS2K_WAIT_L1_ONE_G = 240, WS2K_WAIT_L2_ONE_G = 240;
 // layer 2's fetch of the next h1 (wavefront 15) in groups of 13 + 25: 0.505 -> 0.491 ms at 82 chunks (0.55 ms at twice this
 // wait: it is on the critical path then); none in groups of 25 + 25, where it costs a one-chunk push 10-25 us
 constexpr unsigned WS2K_WAIT_H1 = 120;
