@@ -620,10 +620,10 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
 // Context option ws2_calibrate: gru_ws2k's first-poll waits measured on THIS device.  The built-in table was swept on one box
 // (tools/ws2_delay.py); what the right wait is depends on how long a flag takes to cross the fabric, which is a property of
 // the part and its clocks.  A 5 x 5 grid around the table's entry (both layers' waits, +-0.8 us in steps of 0.4: the optimum is
-// a narrow diagonal valley, which a search along one axis at a time misses), the network pass (run_nn: the product path, on whatever the workspace holds) timed five times per candidate,
+// a narrow diagonal valley, which a search along one axis at a time misses), then 3 x 3 in steps of 0.2 around its best; the network pass (run_nn: the product path, on whatever the workspace holds) timed five times per candidate,
 // fastest run kept.  A candidate replaces the table's entry only if it is more than 1.5 % faster -- run-to-run noise is about
 // 1 %.  Timing only: results do not depend on the waits (tests/test_gpu.py checks bits with and without).
-// About 60 ms per class; classes measured: the one a one-chunk push falls in and the one BASELINE config 3's 82 chunks fall in.
+// About 80 ms per class; classes measured: the one a one-chunk push falls in and the one BASELINE config 3's 82 chunks fall in.
 int calibrate_ws2_waits(fvad_ctx* ctx)
 {
     Tuning& tn = ctx->tune;
@@ -673,6 +673,17 @@ int calibrate_ws2_waits(fvad_ctx* ctx)
                 rc = time_pass(n_pad, (unsigned)l1 | ((unsigned)l2 << 16), &t);
                 if (!rc && t < t_best) { t_best = t; best = (unsigned)l1 | ((unsigned)l2 << 16); }
             }
+        {   // a finer 3 x 3 (+-0.2 us) around the coarse grid's best
+            const unsigned centre = best;
+            for (int d1 = -20; d1 <= 20 && !rc; d1 += 20)
+                for (int d2 = -20; d2 <= 20 && !rc; d2 += 20) {
+                    const int l1 = (int)(centre & 0xFFFFu) + d1, l2 = (int)(centre >> 16) + d2;
+                    if ((d1 == 0 && d2 == 0) || l1 < 0 || l2 < 0) continue;
+                    float t = 0;
+                    rc = time_pass(n_pad, (unsigned)l1 | ((unsigned)l2 << 16), &t);
+                    if (!rc && t < t_best) { t_best = t; best = (unsigned)l1 | ((unsigned)l2 << 16); }
+                }
+        }
         if (!rc && best != base) { // the winner against the table once more, back to back: keep it only on a clear margin
             float t0 = 0, t1 = 0;
             if (!(rc = time_pass(n_pad, base, &t0)) && !(rc = time_pass(n_pad, best, &t1)) && t1 < 0.985f * t0) tn.ws2_waits_cal[cls] = best;

@@ -329,7 +329,7 @@ int fvad_ctx_ws_fallbacks(fvad_ctx *ctx, uint64_t *n);
  * its peers' flags -- a poll made too early is a wasted round trip and traffic on the flag lines.  The intervals are a
  * built-in table per group shape (wait_class 1: groups of 25 + 25 workgroups, 1..80 sequences; 2 and 3: groups of 13 + 25,
  * without / with layer 1's input projection in the kernel), swept on one MI355X.  fvad_ctx_set_option(ctx, "ws2_calibrate",
- * "1") measures them on THIS device (about 0.1 s, the model must be loaded; the table's entry stays unless a candidate is
+ * "1") measures them on THIS device (about 0.2 s, the model must be loaded; the table's entry stays unless a candidate is
  * more than 1.5 % faster); "ws2_waits" = layer 1's wait | layer 2's << 16, in 10 ns ticks, sets them by hand for every class.
  * Timing only: results do not depend on them.  Returns the waits in effect for a class, packed like "ws2_waits"; 0 for an
  * unknown class. */

@@ -1774,7 +1774,7 @@ def test_first_poll_waits_are_timing_only(fv, weights7):
         ctx.set_option("ws2_calibrate", 1)
         cal = {c: ctx.ws2_waits(c) for c in (1, 2, 3)}
         for c in (1, 3):  # measured classes stay within the search window around the table's entry; class 2 is not measured
-            assert abs(cal[c][0] - table[c][0]) <= 80 and abs(cal[c][1] - table[c][1]) <= 80, (cal, table)
+            assert abs(cal[c][0] - table[c][0]) <= 100 and abs(cal[c][1] - table[c][1]) <= 100, (cal, table)
         assert cal[2] == table[2]
         for n, f in feats.items():
             assert np.array_equal(ctx.nsnet2_forward(f), ref[n]), n
