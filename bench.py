@@ -777,7 +777,7 @@ def main():
     ctx.close()
 
 
-BATCH_CURVE_POINTS = ((1, 1), (8, 1), (2, 41), (16, 16), (64, 16), (128, 16), (128, 32), (128, 64), (128, 128), (384, 128))
+BATCH_CURVE_POINTS = ((1, 1), (8, 1), (2, 41), (16, 16), (64, 16), (128, 16), (128, 32), (128, 64), (128, 96), (128, 128), (384, 128))
 
 
 def batch_curve(fv, ctx, host_pcm, points=BATCH_CURVE_POINTS, budget_s=0.4):
