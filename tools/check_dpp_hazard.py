@@ -1,11 +1,11 @@
-"""The spectral kernels issue v_fmac_f32_dpp through inline assembly (csrc/kernels_fft.hip: dpp_butterfly, dpp_butterfly_raw), which
+"""The spectral kernels issue v_fmac_f32_dpp through inline assembly (csrc/fft_device.h: dpp_butterfly, dpp_butterfly_raw), which
 the compiler's hazard recogniser does not see: a DPP read of a VGPR needs two wait states after a VALU write of that VGPR.  This
-script compiles kernels_fft.hip to assembly and checks every DPP instruction against the instructions in front of it -- a
+script compiles the spectral translation units to assembly and checks every DPP instruction against the instructions in front of it -- a
 register-allocator copy or a spill reload landing inside a block of butterflies would otherwise corrupt results silently.
 python tools/check_dpp_hazard.py  (exit code 1 and a listing on a violation; needs hipcc, no GPU)"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "formula-vad_amd", "csrc", "kernels_fft.hip")
+SRCS = [os.path.join(ROOT, "formula-vad_amd", "csrc", f) for f in ("kernels_fft.hip", "kernels_stft.hip", "kernels_vadfft.hip", "kernels_fftgen.hip")]
 
 
 def regs(tok):
@@ -57,19 +57,23 @@ def check(asm_text):
 
 
 def main():
+    n_all, bad_all = 0, []
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "k.s")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
-               "-I" + os.path.join(ROOT, "include"), "-x", "hip", "--cuda-device-only", "-S", SRC, "-o", out]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            print(r.stderr[-2000:])
-            return 2
-        n, bad = check(open(out).read())
-    print(f"{n} DPP instructions, {len(bad)} without two wait states behind a VALU write of their source")
-    for w, t in bad[:20]:
+        for src in SRCS:
+            out = os.path.join(d, "k.s")
+            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+                   "-I" + os.path.join(ROOT, "include"), "-x", "hip", "--cuda-device-only", "-S", src, "-o", out]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                print(r.stderr[-2000:])
+                return 2
+            n, bad = check(open(out).read())
+            n_all += n
+            bad_all += bad
+    print(f"{n_all} DPP instructions, {len(bad_all)} without two wait states behind a VALU write of their source")
+    for w, t in bad_all[:20]:
         print("   ", w, "->", t)
-    return 1 if bad or n == 0 else 0
+    return 1 if bad_all or n_all == 0 else 0
 
 
 if __name__ == "__main__":
