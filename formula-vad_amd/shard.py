@@ -139,6 +139,9 @@ def run_time_split_rank_graph(ctx, pcm, c0, c1, window=496, lanes=4, want_denois
     (src/NSNet2.zig:188-203; `time_split_job`), sixteen keep the 1024-sample frame grid where the unsplit stream has it,
     and because a window's length is a multiple of 16 chunks no frame straddles two windows.  The stream's very first
     window starts at chunk 0 and needs no halo (zero history IS its state, NSNet2.zig:77-79).
+    Throughput follows the batch curve of one launch (bench.py `extra.batch_curve`): the default replay is 4 x 512 = 2048 chunks
+    (1.9e7 frames/s on one MI355X); `lanes=8, window=1008` makes it 8192 chunks (2.2e7, and half the halo overhead) at 0.8 GB
+    per buffer -- worth it when the share is many replays long.
     pcm: host float32 array holding the stream at least up to chunk c1 (a prefix is enough).  Returns what
     run_time_split_rank returns, bit-identical to the unsplit run in `reproducible` mode."""
     H = ALIGN_CHUNKS
