@@ -42,7 +42,11 @@ RcclApi* rccl()
             api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (api.handle) break;
         }
-        if (!api.handle) { api.err = std::string("dlopen(librccl.so) failed: ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!api.handle) {
+            const char* why = dlerror(); // one call: dlerror() clears the message it returns
+            api.err = std::string("dlopen(librccl.so) failed: ") + (why ? why : "?");
+            return;
+        }
 #define SYM(field, sym)                                                             \
     api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, sym));      \
     if (!api.field) { api.err = std::string("RCCL symbol missing: ") + sym; return; }

@@ -683,8 +683,6 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
             FVAD_HIP(ctx, hipMemsetAsync(ws.carries, 0, n_scratch * sizeof(LaneCarry), st));
             ws.carries_clean = n_scratch;
         }
-        if ((long)(n_lanes * n_chunks) > planned_max_chunks(ctx, (long)(n_lanes * n_chunks), opts.max_chunks_per_launch))
-            ws.carries_clean = 0; // several launches: the even carries get written
         std::vector<LaneJob> jobs(n_lanes);
         for (size_t l = 0; l < n_lanes; ++l) {
             jobs[l].d_in = d_pcm ? d_pcm + l * lane_stride : nullptr;
@@ -697,7 +695,11 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
             jobs[l].cur = 0;
             jobs[l].d_rms = d_chunk_rms ? d_chunk_rms + l * n_chunks : nullptr;
         }
-        int r = run_chunks(ctx, jobs, opts.max_chunks_per_launch, capture_descs, capture_dev);
+        long launches = 0;
+        int r = run_chunks(ctx, jobs, opts.max_chunks_per_launch, capture_descs, capture_dev, &launches);
+        // several launches: the even carries get written (what run_chunks DID, not what planned_max_chunks predicts; a
+        // failed call may have made some of its launches)
+        if (launches != 1) ws.carries_clean = 0;
         if (r) return r;
         // one K4 launch for every lane's frames
         for (size_t l = 0; l < n_lanes; ++l) h_jobs[l] = {den + l * n_den, d_band_sum + l * n_frames, nullptr, (long)n_frames};
@@ -706,7 +708,7 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
             ws.jobs_mirror.assign(h_jobs, h_jobs + n_lanes);
         }
         time_begin(ctx, "fft1024_bandsum");
-        fvad_launch_vadfft_jobs(d_jobs, (int)n_lanes, (long)n_frames, plan, opts.min_bin, opts.max_bin, st, 0, ctx->n_cu, ctx->tune.k4_plain_loads ? 1 : 0);
+        FVAD_HIP(ctx, (hipError_t)fvad_launch_vadfft_jobs(d_jobs, (int)n_lanes, (long)n_frames, plan, opts.min_bin, opts.max_bin, st, 0, ctx->n_cu, ctx->tune.k4_plain_loads ? 1 : 0));
         time_end(ctx);
         return FVAD_OK;
     };

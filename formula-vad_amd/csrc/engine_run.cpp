@@ -405,7 +405,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
             time_begin(ctx, "fft1024_bandsum");
             int any_bins = 0;
             for (size_t l = l0; l < l1; ++l) any_bins |= lanes[l].fft_bins != nullptr;
-            fvad_launch_vadfft_jobs(ws.fft_jobs + l0, (int)(l1 - l0), mf, plan, opts.min_bin, opts.max_bin, st, any_bins, ctx->n_cu, ctx->tune.k4_plain_loads ? 1 : 0);
+            FVAD_HIP(ctx, (hipError_t)fvad_launch_vadfft_jobs(ws.fft_jobs + l0, (int)(l1 - l0), mf, plan, opts.min_bin, opts.max_bin, st, any_bins, ctx->n_cu, ctx->tune.k4_plain_loads ? 1 : 0));
             time_end(ctx);
         }
         for (size_t l = l0; l < l1; ++l) {

@@ -393,5 +393,5 @@ __device__ __forceinline__ void dpp_block_end() { __builtin_amdgcn_sched_barrier
 
 
 // the generic mixed-radix kernels' launcher (kernels_fftgen.hip), used by K4's and the batch launchers for other sizes
-void fvad_launch_rfft_generic_any(const float* frames, long n_frames, const float* window, VadFftPlan pl, float* bins, float* mag,
-                                  const VadFftJob* jobs, int n_jobs, long max_frames, int min_bin, int max_bin, hipStream_t stream);
+int fvad_launch_rfft_generic_any(const float* frames, long n_frames, const float* window, VadFftPlan pl, float* bins, float* mag,
+                                 const VadFftJob* jobs, int n_jobs, long max_frames, int min_bin, int max_bin, hipStream_t stream);

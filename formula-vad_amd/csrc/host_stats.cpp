@@ -1,7 +1,7 @@
 // host_stats.cpp -- Evaluator + statistics + Audacity label parsing (host).
 // Mirrors src/Evaluator.zig:90-156, src/Evaluator/SpeechSegment.zig, src/Evaluator/statistics.zig
 // and src/Evaluator/formats.zig:7-36 of the reference; all f32, the reference's summation order.
-// The per-stream SingleStats (13 floats) is what ranks exchange in the multi-GPU run; the
+// The per-stream SingleStats (11 floats: fvad_single_stats) is what ranks exchange in the multi-GPU run; the
 // aggregate is then formed on rank 0 in plan order (statistics.zig:124-129).
 #include <algorithm>
 #include <cmath>

@@ -261,8 +261,10 @@ struct LaneJob {
     const int16_t* d_in16 = nullptr; // device, PCM16 input instead of d_in (16-bit transport)
     int16_t* d_den16 = nullptr;      // device, optional PCM16 copy of the denoised audio
 };
+// n_launches (optional): how many K1 -> NSNet2 -> K3 launches the call was cut into (a lane cut over several launches has its
+// even carry written: see Workspace::carries_clean)
 int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, ChunkDesc* capture_descs = nullptr,
-               ChunkDesc* capture_dev = nullptr);
+               ChunkDesc* capture_dev = nullptr, long* n_launches = nullptr);
 void time_begin(fvad_ctx* ctx, const char* name);
 void time_end(fvad_ctx* ctx);
 } // namespace fvad

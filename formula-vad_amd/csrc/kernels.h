@@ -167,14 +167,15 @@ void fvad_launch_vadfft(const float* den, long n_frames, VadFftPlan pl, int min_
 // all lanes in one launch: jobs is a device array of n_jobs entries, max_frames = max n_frames
 // any_bins: some job has a `bins` tap (the full-spectrum kernel must run; band sums come from the band kernel either way);
 // plain_loads: the band kernel stages its frames with plain 8-byte loads, the path of unaligned jobs (context option k4_plain_loads)
-void fvad_launch_vadfft_jobs(const VadFftJob* jobs, int n_jobs, long max_frames, VadFftPlan pl,
-                             int min_bin, int max_bin, hipStream_t stream, int any_bins, int n_cu, int plain_loads = 0);
+// (returns a hipError_t as int: a failed hipFuncSetAttribute must not leave the caller with stale band sums and FVAD_OK)
+int fvad_launch_vadfft_jobs(const VadFftJob* jobs, int n_jobs, long max_frames, VadFftPlan pl,
+                            int min_bin, int max_bin, hipStream_t stream, int any_bins, int n_cu, int plain_loads = 0);
 // batched FFT.fft for B3 / BASELINE config 2: n_fft in {320, 512, 1024, 2048} (pl is used for n_fft != 320)
-void fvad_launch_rfft_batch(const float* frames, long n_frames, int n_fft, const float* window,
-                            FftTables tb, VadFftPlan pl, float* bins_or_null, float* mag_or_null,
-                            hipStream_t stream);
+int fvad_launch_rfft_batch(const float* frames, long n_frames, int n_fft, const float* window,
+                           FftTables tb, VadFftPlan pl, float* bins_or_null, float* mag_or_null,
+                           hipStream_t stream); // hipError_t as int
 void fvad_launch_irfft_batch(const float* bins, long n_frames, FftTables tb, float* out,
                              hipStream_t stream);
 // FFT.invFft for any even size (pl.generic plans; tables of the FORWARD transform, conjugated in the kernel): bins
 // [n_frames][n/2 + 1][2] -> out [n_frames][n], unscaled like kiss_fftri
-void fvad_launch_irfft_generic(const float* bins, long n_frames, VadFftPlan pl, float* out, hipStream_t stream);
+int fvad_launch_irfft_generic(const float* bins, long n_frames, VadFftPlan pl, float* out, hipStream_t stream); // hipError_t as int

@@ -427,13 +427,13 @@ __global__ __launch_bounds__(64 * RB8_WAVES, 3) void rfft320_batch8_kernel(const
     }
 }
 
-void fvad_launch_rfft_batch(const float* frames, long n_frames, int n_fft, const float* window,
-                            FftTables tb, VadFftPlan pl, float* bins_or_null, float* mag_or_null,
-                            hipStream_t stream)
+int fvad_launch_rfft_batch(const float* frames, long n_frames, int n_fft, const float* window,
+                           FftTables tb, VadFftPlan pl, float* bins_or_null, float* mag_or_null,
+                           hipStream_t stream)
 {
-    if (n_frames <= 0) return;
+    if (n_frames <= 0) return (int)hipSuccess;
     if (n_fft != kNFft && pl.generic) {
-        fvad_launch_rfft_generic_any(frames, n_frames, window, pl, bins_or_null, mag_or_null, nullptr, 0, 0, 0, 0, stream);
+        return fvad_launch_rfft_generic_any(frames, n_frames, window, pl, bins_or_null, mag_or_null, nullptr, 0, 0, 0, 0, stream);
     } else if (n_fft != kNFft) {
         VADFFT_DISPATCH(n_fft, hipLaunchKernelGGL(rfftN_batch_kernel<R>, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0,
                                                   stream, frames, n_frames, window, pl, bins_or_null, mag_or_null))
@@ -454,7 +454,7 @@ void fvad_launch_rfft_batch(const float* frames, long n_frames, int n_fft, const
             constexpr size_t lds8 = (size_t)(RB8_WAVES * RB8_FR * RB8_FS + 2 * 81 + 2 + kNFft + 8 * 20 * 2 + RB8_WAVES * RB8_FR * 2) * sizeof(float) + RB8_FR * kNBins * 2;
             hipLaunchKernelGGL(rfft320_batch8_kernel, dim3((unsigned)groups8), dim3(64 * RB8_WAVES), lds8, stream, frames, n_frames, window, tb,
                                bins_or_null, mag_or_null);
-            return;
+            return (int)hipGetLastError();
         }
         long groups = (n_frames + 15) / 16; // 4 wavefronts x 4 frames per workgroup and iteration
         if (groups > 2048) groups = 2048;
@@ -467,6 +467,7 @@ void fvad_launch_rfft_batch(const float* frames, long n_frames, int n_fft, const
             hipLaunchKernelGGL(rfft320_batch_kernel<false>, dim3((unsigned)groups), dim3(256), 0, stream, frames,
                                n_frames, window, tb, bins_or_null, mag_or_null, vec_ok);
     }
+    return (int)hipGetLastError();
 }
 
 // FFT.invFft for many 320-point frames: bins [n][161][2] -> out [n][320], unscaled

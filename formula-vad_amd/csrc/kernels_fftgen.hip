@@ -158,19 +158,23 @@ __global__ __launch_bounds__(256) void irfft_generic_kernel(const float* __restr
     for (int j = threadIdx.x; j < M; j += 256) { o[2 * j] = T[j].r; o[2 * j + 1] = T[j].i; }
 }
 
-void fvad_launch_irfft_generic(const float* bins, long n_frames, VadFftPlan pl, float* out, hipStream_t stream)
+int fvad_launch_irfft_generic(const float* bins, long n_frames, VadFftPlan pl, float* out, hipStream_t stream)
 {
-    if (n_frames <= 0) return;
-    const size_t lds = (size_t)(pl.n / 2 + 1) * 2 * sizeof(cpx);
-    (void)hipFuncSetAttribute((const void*)irfft_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (n_frames <= 0) return (int)hipSuccess;
+    const size_t lds = (size_t)(pl.n / 2 + 1) * 2 * sizeof(cpx); // up to 131 KB: the attribute call can fail
+    const hipError_t e = hipFuncSetAttribute((const void*)irfft_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(irfft_generic_kernel, dim3((unsigned)n_frames), dim3(256), lds, stream, bins, n_frames, pl, out);
+    return (int)hipGetLastError();
 }
 
-void fvad_launch_rfft_generic_any(const float* frames, long n_frames, const float* window, VadFftPlan pl, float* bins, float* mag,
-                                const VadFftJob* jobs, int n_jobs, long max_frames, int min_bin, int max_bin, hipStream_t stream)
+int fvad_launch_rfft_generic_any(const float* frames, long n_frames, const float* window, VadFftPlan pl, float* bins, float* mag,
+                                 const VadFftJob* jobs, int n_jobs, long max_frames, int min_bin, int max_bin, hipStream_t stream)
 {
     const size_t lds = (size_t)(pl.n / 2 + 1) * 2 * sizeof(cpx);
-    (void)hipFuncSetAttribute((const void*)rfft_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t e = hipFuncSetAttribute((const void*)rfft_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
     const dim3 grid((unsigned)(jobs ? max_frames : n_frames), (unsigned)(jobs ? n_jobs : 1));
     hipLaunchKernelGGL(rfft_generic_kernel, grid, dim3(256), lds, stream, frames, n_frames, window, pl, bins, mag, jobs, min_bin, max_bin);
+    return (int)hipGetLastError();
 }

@@ -311,14 +311,12 @@ void fvad_launch_vadfft(const float* den, long n_frames, VadFftPlan pl, int min_
                                               n_frames, pl, min_bin, max_bin, band_sum, bins_or_null))
 }
 
-void fvad_launch_vadfft_jobs(const VadFftJob* jobs, int n_jobs, long max_frames, VadFftPlan pl,
-                             int min_bin, int max_bin, hipStream_t stream, int any_bins, int n_cu, int plain)
+int fvad_launch_vadfft_jobs(const VadFftJob* jobs, int n_jobs, long max_frames, VadFftPlan pl,
+                            int min_bin, int max_bin, hipStream_t stream, int any_bins, int n_cu, int plain)
 {
-    if (n_jobs <= 0 || max_frames <= 0) return;
-    if (pl.generic) {
-        fvad_launch_rfft_generic_any(nullptr, 0, nullptr, pl, nullptr, nullptr, jobs, n_jobs, max_frames, min_bin, max_bin, stream);
-        return;
-    }
+    if (n_jobs <= 0 || max_frames <= 0) return (int)hipSuccess;
+    if (pl.generic)
+        return fvad_launch_rfft_generic_any(nullptr, 0, nullptr, pl, nullptr, nullptr, jobs, n_jobs, max_frames, min_bin, max_bin, stream);
     // 1024 points and a band inside bins 1..47 (the reference's 500-2000 Hz is 11..43): the four-frames-per-wavefront
     // kernel writes the band sums; the full-spectrum kernel runs (first) only when some job wants the magnitude tap, so
     // that a call's band sums have the same bits with and without the tap
@@ -335,12 +333,15 @@ void fvad_launch_vadfft_jobs(const VadFftJob* jobs, int n_jobs, long max_frames,
         if (per_job > wg_all) per_job = wg_all;
         constexpr size_t lds = (size_t)(4 * 64 * V4_ROW + 16 * V4_ROW + 16 * 48) * sizeof(float);
         if (min_bin == 11 && max_bin == 43) { // VADMachine.zig:146-151 at 48 kHz / 1024 points
-            if (hipFuncSetAttribute((const void*)vadfft1024_band_kernel<11, 43>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return;
+            const hipError_t e = hipFuncSetAttribute((const void*)vadfft1024_band_kernel<11, 43>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e; // no kernel has written the band sums: the caller must not return FVAD_OK
             hipLaunchKernelGGL((vadfft1024_band_kernel<11, 43>), dim3((unsigned)per_job, (unsigned)n_jobs), dim3(256), lds, stream, jobs, pl, min_bin, max_bin, plain);
         } else {
-            if (hipFuncSetAttribute((const void*)vadfft1024_band_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return;
+            const hipError_t e = hipFuncSetAttribute((const void*)vadfft1024_band_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
             hipLaunchKernelGGL((vadfft1024_band_kernel<0, 0>), dim3((unsigned)per_job, (unsigned)n_jobs), dim3(256), lds, stream, jobs, pl, min_bin, max_bin, plain);
         }
     }
+    return (int)hipGetLastError();
 }
 

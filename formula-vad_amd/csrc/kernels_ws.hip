@@ -1300,7 +1300,7 @@ static int ws2_kernel_for(long n_seq_pad, int T, int n_cu, int variant, bool* gi
             const bool groups_13_25 = G * 2 * GRU_J > n_cu || (variant & 16);
             if (!(variant & 1024) && groups_13_25 && ws2k_fits(n_seq_pad, T, n_cu, variant, true)) { *gi1k = true; return 1; }
             if (ws2k_fits(n_seq_pad, T, n_cu, variant, false)) return 1;
-        } else if ((long long)n_seq_pad * T * (3 * GRU_H) * 4 < (1ll << 32)) return 2;
+        } else if ((long long)n_seq_pad * T * (3 * GRU_H) * 4 < (1ll << 31)) return 2; // gru_ws2m's buffer resources and offsets are plain int arithmetic (like ws2k_fits)
     }
     return RT <= 4 ? 3 : 0;
 }
@@ -1456,7 +1456,8 @@ int fvad_launch_gru_ws(const float* gi, const float* R2frag, const float* bR, fl
                        hipStream_t stream)
 {
     const int gi_js = tile_major ? 48 : 16, gi_gs = tile_major ? 16 : GRU_H;
-    // spin_ticks (100 MHz ticks; context option ws_spin_ticks, default 0.25 s): 0 makes every wait that does not
+    // spin_ticks (100 MHz ticks; context option ws_spin_ticks, default: max(2 ms, 20 x the launch's expected duration),
+    // nn_dispatch.cpp ws_spin_deadline): 0 makes every wait that does not
     // succeed at once give up, which is how the tests drive the gru_lat fallback behind this kernel
     int RT = 0, G = 0;
     if (!fvad_gru_ws_shape(n_seq_pad, n_cu, &RT, &G)) return -1;

@@ -716,8 +716,9 @@ long planned_max_chunks(const fvad_ctx* ctx, long total, long max_chunks)
 }
 
 // K1 -> NSNet2 -> K3 over every chunk of every job, in launches of <= max_chunks chunks.
-int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, ChunkDesc* capture_descs, ChunkDesc* capture_dev)
+int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, ChunkDesc* capture_descs, ChunkDesc* capture_dev, long* n_launches)
 {
+    if (n_launches) *n_launches = 0;
     // capture_descs != nullptr: the call is being captured into a hipGraph.  Every launch gets its own
     // region of the graph's private descriptor table (host copy capture_descs, device copy capture_dev,
     // uploaded once by the caller after the capture): the graph holds no copy node and does not depend on
@@ -805,6 +806,7 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
         fvad_launch_istft(dd, (int)n, ctx->tb, ws.spec, ws.gains, kFramesPerChunk, 0, ctx->stream, fft_parts);
         time_end(ctx);
         for (size_t t : touched) jobs[t].cur ^= 1;
+        if (n_launches) ++*n_launches;
         job = j;
         chunk_in_job = c;
     }

@@ -103,7 +103,7 @@ int fvad_fft_forward(fvad_fft* f, const float* first, size_t n_first, const floa
     hipStream_t st = ctx->stream;
     FVAD_HIP(ctx, hipMemcpyAsync(f->d_in, f->h_in.data(), f->n_fft * sizeof(float), hipMemcpyHostToDevice, st));
     FVAD_HIP(ctx, hipMemcpyAsync(f->d_win, window, f->n_fft * sizeof(float), hipMemcpyHostToDevice, st));
-    fvad_launch_rfft_batch(f->d_in, 1, (int)f->n_fft, f->d_win, ctx->tb, f->plan, f->d_out, nullptr, st);
+    FVAD_HIP(ctx, (hipError_t)fvad_launch_rfft_batch(f->d_in, 1, (int)f->n_fft, f->d_win, ctx->tb, f->plan, f->d_out, nullptr, st));
     FVAD_HIP(ctx, hipMemcpyAsync(bins, f->d_out, n_bins * sizeof(fvad_complex), hipMemcpyDeviceToHost, st));
     FVAD_HIP(ctx, hipStreamSynchronize(st));
     return FVAD_OK;
@@ -121,7 +121,7 @@ int fvad_fft_inverse(fvad_fft* f, const fvad_complex* bins, size_t n_bins, float
     hipStream_t st = ctx->stream;
     FVAD_HIP(ctx, hipMemcpyAsync(f->d_out, bins, n_bins * sizeof(fvad_complex), hipMemcpyHostToDevice, st));
     if (f->n_fft == 320) fvad_launch_irfft_batch(f->d_out, 1, ctx->tb, f->d_in, st);
-    else fvad_launch_irfft_generic(f->d_out, 1, f->plan, f->d_in, st);
+    else FVAD_HIP(ctx, (hipError_t)fvad_launch_irfft_generic(f->d_out, 1, f->plan, f->d_in, st));
     FVAD_HIP(ctx, hipMemcpyAsync(result, f->d_in, f->n_fft * sizeof(float), hipMemcpyDeviceToHost, st));
     FVAD_HIP(ctx, hipStreamSynchronize(st));
     return FVAD_OK;
@@ -138,8 +138,7 @@ int fvad_fft_forward_batch(fvad_fft* f, const float* frames, size_t n_frames, co
     hipStream_t st = ctx->stream;
     const size_t nb = fvad_fft_bin_count(f);
     if (on_device) {
-        fvad_launch_rfft_batch(frames, (long)n_frames, (int)f->n_fft, window, ctx->tb, f->plan, (float*)bins, magnitudes, st);
-        FVAD_HIP(ctx, hipGetLastError());
+        FVAD_HIP(ctx, (hipError_t)fvad_launch_rfft_batch(frames, (long)n_frames, (int)f->n_fft, window, ctx->tb, f->plan, (float*)bins, magnitudes, st));
         return FVAD_OK;
     }
     float *d_fr = nullptr, *d_bins = nullptr, *d_mag = nullptr;
@@ -153,10 +152,10 @@ int fvad_fft_forward_batch(fvad_fft* f, const float* frames, size_t n_frames, co
     }
     hipMemcpyAsync(d_fr, frames, n_frames * f->n_fft * sizeof(float), hipMemcpyHostToDevice, st);
     hipMemcpyAsync(f->d_win, window, f->n_fft * sizeof(float), hipMemcpyHostToDevice, st);
-    fvad_launch_rfft_batch(d_fr, (long)n_frames, (int)f->n_fft, f->d_win, ctx->tb, f->plan, d_bins, d_mag, st);
+    const int launch_rc = fvad_launch_rfft_batch(d_fr, (long)n_frames, (int)f->n_fft, f->d_win, ctx->tb, f->plan, d_bins, d_mag, st);
     if (bins) hipMemcpyAsync(bins, d_bins, n_frames * nb * 2 * sizeof(float), hipMemcpyDeviceToHost, st);
     if (magnitudes) hipMemcpyAsync(magnitudes, d_mag, n_frames * nb * sizeof(float), hipMemcpyDeviceToHost, st);
-    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) rc = set_err(ctx, FVAD_ERR_HIP, "batched FFT failed");
+    if (hipStreamSynchronize(st) != hipSuccess || launch_rc != (int)hipSuccess || hipGetLastError() != hipSuccess) rc = set_err(ctx, FVAD_ERR_HIP, "batched FFT failed");
     cleanup();
     return rc;
 }

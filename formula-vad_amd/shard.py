@@ -139,9 +139,11 @@ def run_time_split_rank_graph(ctx, pcm, c0, c1, window=496, lanes=4, want_denois
     (src/NSNet2.zig:188-203; `time_split_job`), sixteen keep the 1024-sample frame grid where the unsplit stream has it,
     and because a window's length is a multiple of 16 chunks no frame straddles two windows.  The stream's very first
     window starts at chunk 0 and needs no halo (zero history IS its state, NSNet2.zig:77-79).
-    Throughput follows the batch curve of one launch (bench.py `extra.batch_curve`): the default replay is 4 x 512 = 2048 chunks
-    (1.9e7 frames/s on one MI355X); `lanes=8, window=1008` makes it 8192 chunks (2.2e7, and half the halo overhead) at 0.8 GB
-    per buffer -- worth it when the share is many replays long.
+    The REPLAY's rate follows the batch curve of one launch (bench.py `extra.batch_curve`): the default replay is 4 x 512 = 2048
+    chunks (1.9e7 frames/s on one MI355X); `lanes=8, window=1008` makes it 8192 chunks (2.2e7, and half the halo overhead) at
+    0.8 GB per buffer.  This Python loop around it is a correctness harness, not the fast path: it packs the lanes on the host
+    and copies synchronously each replay, so its own rate is host-bound (a few 1e6 frames/s); a production host keeps the
+    corpus on the device (fvad_engine_enqueue_device with no_wait) or goes through fvad_engine_run's pipelined staging.
     pcm: host float32 array holding the stream at least up to chunk c1 (a prefix is enough).  Returns what
     run_time_split_rank returns, bit-identical to the unsplit run in `reproducible` mode."""
     H = ALIGN_CHUNKS
@@ -159,10 +161,6 @@ def run_time_split_rank_graph(ctx, pcm, c0, c1, window=496, lanes=4, want_denois
             break
         s = out_hi - H
     n_samp = L * CHUNK
-    d_pcm = ctx.device_alloc(lanes * n_samp * 4)
-    d_den = ctx.device_alloc(lanes * n_samp * 4)
-    d_band = ctx.device_alloc(lanes * fpl * 4)
-    d_rms = ctx.device_alloc(lanes * L * 4)
     h_in = np.zeros((lanes, n_samp), np.float32)
     h_band = np.empty((lanes, fpl), np.float32)
     h_rms = np.empty((lanes, L), np.float32)
@@ -173,13 +171,19 @@ def run_time_split_rank_graph(ctx, pcm, c0, c1, window=496, lanes=4, want_denois
     f_hi = -(-(c1 * CHUNK) // FFT) if c1 < n_have else (n_have * CHUNK) // FFT
     band = np.empty(f_hi - f_lo, np.float32)
     replays = 0
+    bufs = []                                        # freed in `finally`, however many of the allocations succeeded
     try:
+        d_pcm, d_den, d_band, d_rms = (bufs.append(ctx.device_alloc(n)) or bufs[-1]
+                                       for n in (lanes * n_samp * 4, lanes * n_samp * 4, lanes * fpl * 4, lanes * L * 4))
         for i in range(0, len(starts), lanes):
             grp = starts[i:i + lanes]
-            h_in[:] = 0.0                            # lanes past the share's end (and audio past the prefix) are silence
-            for j, s in enumerate(grp):
-                seg = pcm[s * CHUNK: min(s + L, n_have) * CHUNK]
-                h_in[j, : seg.shape[0]] = seg
+            for j in range(lanes):                   # lanes past the share's end (and audio past the prefix) are silence:
+                if j < len(grp):                     # only the tail a lane does not overwrite is zeroed (up to 0.8 GB otherwise)
+                    seg = pcm[grp[j] * CHUNK: min(grp[j] + L, n_have) * CHUNK]
+                    h_in[j, : seg.shape[0]] = seg
+                    h_in[j, seg.shape[0]:] = 0.0
+                else:
+                    h_in[j] = 0.0
             ctx.to_device(d_pcm, h_in)
             ctx.enqueue_device(d_pcm, lanes, n_samp, n_samp, d_den, d_band, d_rms, use_graph=use_graph)
             replays += 1
@@ -200,7 +204,7 @@ def run_time_split_rank_graph(ctx, pcm, c0, c1, window=496, lanes=4, want_denois
                     base = s * CHUNK // FFT                                   # lane's first frame (s is a multiple of 16)
                     band[g0 - f_lo: g1 - f_lo] = h_band[j, g0 - base: g1 - base]
     finally:
-        for d in (d_pcm, d_den, d_band, d_rms):
+        for d in bufs:
             ctx.device_free(d)
     return {"denoised": den, "chunk_rms": rms, "band_sum": band, "first_frame_index": f_lo * FFT, "replays": replays,
             "lane_starts": starts}

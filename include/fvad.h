@@ -321,9 +321,14 @@ const char *fvad_ctx_last_nn_path(const fvad_ctx *ctx);
  * restores the default.  The environment variables FVAD_<NAME> are read ONCE, by
  * fvad_ctx_create, as initial values (a bad value fails the creation); the data path never reads the environment. */
 int fvad_ctx_set_option(fvad_ctx *ctx, const char *name, const char *value);
-/* Network passes in which the weight-stationary small-batch recurrence (gru_ws_kernel) gave up waiting for a peer
- * workgroup -- the chip was shared with another process -- and the low-latency kernel redid the GRU layers (same
- * bits: both accumulate in the same order).  Waits for the context's stream. */
+/* Network passes in which a weight-stationary small-batch recurrence (gru_ws_kernel, or the pipelined gru_ws2k / gru_ws2m /
+ * gru_ws2) gave up waiting for a peer workgroup -- the chip was shared with another process, or with a long kernel of another
+ * context of this process -- and the low-latency kernel redid the GRU layers.  A spin gives up after max(2 ms, 20 x the
+ * launch's own expected duration) (option "ws_spin_ticks" overrides).  Bits: gru_ws and its fallback accumulate in the same
+ * order (same bits); the pipelined kernels compute layer 2's input projection in the kernel and their fallback does not, so
+ * a pass that fell back differs from one that did not by round-off (<= 2e-6 in the gains): default-mode results of small
+ * launches are load-dependent within that bound.  "reproducible" = "1" never runs these kernels.  Waits for the context's
+ * stream. */
 int fvad_ctx_ws_fallbacks(fvad_ctx *ctx, uint64_t *n);
 /* The pipelined recurrence of launches up to 96 sequences (gru_ws2k) waits a fixed interval before a step's first poll of
  * its peers' flags -- a poll made too early is a wasted round trip and traffic on the flag lines.  The intervals are a
