@@ -179,6 +179,16 @@ def gather_all_stats(pkg, fv, ctx, dist, world, args, cdev, local_ids, local_sta
     return out, note, None
 
 
+def stats_digest(allst, agg):
+    """sha256 over the plan-order per-stream statistics (11 f32 each) and the aggregate struct built from them"""
+    import hashlib
+    h = hashlib.sha256()
+    for a in allst:
+        h.update(np.ascontiguousarray(a, dtype=np.float32).tobytes())
+    h.update(bytes(agg))
+    return h.hexdigest()
+
+
 def roll_labels(labels, shift_s, period_s, reps):
     """labels of np.tile(np.roll(x, shift), reps): every burst moves by shift_s modulo the period (split where it
     wraps) and repeats every period"""
@@ -302,7 +312,10 @@ def run_cfg4(args, pkg, fv, ctx, torch, dist, rank, world, cdev, steps=None, war
                        "parallelism": f"streams sharded over {world} rank(s), no data-path collective"},
             "audio_seconds_per_s": frames * n_steps / elapsed / 100.0,
             "aggregate": {"n_streams": n_streams, "tpr": agg.true_positive_rate.overall, "ppv": agg.precision.overall,
-                          "collective": collective, "rccl_ranks": rccl_ranks},
+                          "collective": collective, "rccl_ranks": rccl_ranks,
+                          # the gathered per-stream SingleStats in plan order and the aggregate formed from them, as bytes:
+                          # equal digests from 1 rank and from N ranks = "the same report" (statistics.zig:116-172 sums in slice order)
+                          "stats_sha256": stats_digest(allst, agg)},
             "rank0_step_s": timing,
         }
         if not emit:
@@ -745,7 +758,7 @@ def main():
             "roofline_pipeline": pipeline_of(head),
             "kernel_ms_per_step": {k: v / args.steps for k, v in ktimes.items()},
             "aggregate": {"ms": agg_ms, "n_streams": lanes * world, "tpr": agg.true_positive_rate.overall,
-                          "ppv": agg.precision.overall, "collective": collective},
+                          "ppv": agg.precision.overall, "collective": collective, "stats_sha256": stats_digest(allst, agg)},
             "self_check": self_check,
             "parity_note": "parity unpinned: the checker is oracle/, a CPU restatement of the reference; the reference holds no "
                            "golden vector for FFT / NSNet2 / band sums / segments and cannot be built here (DESIGN.md section 4)",

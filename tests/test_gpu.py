@@ -1273,7 +1273,45 @@ def test_bench_cfg4_one_rank_equals_two_rank_rehearsal():
     b = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert a["n_gpus"] == 1 and b["n_gpus"] == 2
     assert a["aggregate"]["tpr"] == b["aggregate"]["tpr"] and a["aggregate"]["ppv"] == b["aggregate"]["ppv"]
+    assert a["aggregate"]["stats_sha256"] == b["aggregate"]["stats_sha256"]      # every stream's statistics and the aggregate, byte for byte
     assert 0.5 < a["aggregate"]["tpr"] <= 1.0 and a["aggregate"]["n_streams"] == 21
+
+
+def test_two_ranks_on_real_rccl_give_the_one_rank_report():
+    # The multi-GPU leg on REAL RCCL (simulator.zig:221-232's join of the per-file threads + report_generator.zig:48-68,
+    # here fvad_comm_create / fvad_stats_allgather over ncclAllGather): needs two GPUs, so it skips on the one-GPU boxes this
+    # suite normally sees and runs by itself the day a multi-GPU node is leased.  BASELINE config 4's plan (cut to 5 x 600 s) on
+    # one rank and on two: the gathered plan-order SingleStats and the aggregate must be the same BYTES; and the default
+    # headline run with --gpus 2 must have gone through a two-rank RCCL communicator, its cfg4_strong block included.
+    import json
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:          # (counts devices without initialising the runtime)
+        pytest.skip("needs two GPUs: real RCCL refuses two ranks on one device")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True, timeout=1200, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    plan = ["--config", "cfg4", "--cfg4-streams", "5", "--cfg4-seconds", "600", "--steps", "1", "--warmup", "0"]
+    one = run(plan)
+    two = run(plan + ["--gpus", "2"])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["aggregate"]["rccl_ranks"] == 2 and "ncclAllGather" in two["aggregate"]["collective"], two["aggregate"]
+    assert two["aggregate"]["stats_sha256"] == one["aggregate"]["stats_sha256"]
+    assert two["aggregate"]["tpr"] == one["aggregate"]["tpr"] and two["aggregate"]["ppv"] == one["aggregate"]["ppv"]
+    d = run(["--gpus", "2", "--lanes", "16", "--seconds", "64", "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline",
+             "--cfg4-streams", "5", "--cfg4-seconds", "600"])
+    assert d["n_gpus"] == 2 and d["ranks"]["launched"] == 2 and d["ranks"]["backend"] == "nccl" and d["ranks"]["rccl_ranks"] == 2, d["ranks"]
+    assert d["self_check"]["ok"] and d["aggregate"]["n_streams"] == 32
+    c4 = d["cfg4_strong"]
+    assert c4["aggregate"]["rccl_ranks"] == 2 and c4["aggregate"]["stats_sha256"] == one["aggregate"]["stats_sha256"], c4
 
 
 def test_bench_gpus_2_launches_two_ranks_itself():
