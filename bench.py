@@ -385,6 +385,9 @@ def pmc_traffic(chunks_per_launch, nn_math="f32"):
         _, name, k, v, d = sorted(cands, key=lambda c: (c[0], c[1]))[-1]
         digest = d.get("kernel_source_digest")
         return {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
+                "hbm_bytes_basis": v.get("hbm_bytes_basis", "2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction)"),
+                "hbm_bytes_by_request_size": v.get("hbm_bytes_by_request_size"),
+                "hbm_bytes_fetch_x2_plus_write": v.get("hbm_bytes_fetch_x2_plus_write", v["hbm_bytes_per_launch"]),
                 "hbm_bytes_per_launch_raw_counters": v.get("hbm_bytes_per_launch_raw_counters"),
                 "mfma_busy_frac": v.get("mfma_busy_frac"), "clock_GHz": v.get("clock_GHz"),
                 "kernel": k, "profile": "profiles/" + name, "profile_commit": d.get("source_commit"),
@@ -612,8 +615,16 @@ def main():
                         "gru_rec3_kernel<12, 2, true> (fp32 v_mfma_f32_16x16x4_f32; also writes h as three bf16 pieces)"
                         if m["nn_math"] == "bf16x3" else "gru_rec3_kernel<12, 2, false> (fp32 v_mfma_f32_16x16x4_f32)"),
              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-             # HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction)
+             # HBM bytes per launch from the PMC passes.  Three figures, and which one is believed: `traffic` is the sum of request
+             # counts x request sizes (TCC_EA0_RDREQ_32B / 64B / 128B, WRREQ_64B: no correction) when the profile has those passes;
+             # 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction) agrees with it to three digits on every kernel here,
+             # because they issue 128-byte read requests almost exclusively and FETCH_SIZE tallies each at 64; the raw FETCH_SIZE +
+             # WRITE_SIZE under-counts the reads by half (tools/fetch_calib.hip under the same passes: known byte counts)
              "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
+             "traffic_basis": pmc.get("hbm_bytes_basis") if pmc else None,
+             "traffic_by_request_size": pmc.get("hbm_bytes_by_request_size") if pmc else None,
+             "traffic_fetch_x2_plus_write": pmc.get("hbm_bytes_fetch_x2_plus_write") if pmc else None,
+             "traffic_uncorrected_counters": pmc.get("hbm_bytes_per_launch_raw_counters") if pmc else None,
              # plain scalars beside the figure, so a record that keeps only `roofline`'s top level still says where the bytes
              # come from and whether the kernels have changed since they were counted
              "traffic_profile": pmc.get("profile") if pmc else None,

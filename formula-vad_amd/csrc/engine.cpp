@@ -544,7 +544,7 @@ int fvad_nsnet2_forward(fvad_ctx* ctx, const float* features, size_t n_seq, size
     FVAD_HIP(ctx, hipMemsetAsync(ws.feat, 0, (size_t)n_pad * T * kFeatStride * sizeof(float), ctx->stream));
     FVAD_HIP(ctx, hipMemcpy2DAsync(ws.feat, kFeatStride * sizeof(float), features, kNBins * sizeof(float),
                                    kNBins * sizeof(float), n_seq * T, hipMemcpyHostToDevice, ctx->stream));
-    rc = run_nn(ctx, n_pad, (int)T, 0);
+    rc = run_nn(ctx, n_pad, (int)T, 0, (long)n_seq);
     if (rc) return rc;
     FVAD_HIP(ctx, hipMemcpy2DAsync(gains, kNBins * sizeof(float), ws.gains, kFeatStride * sizeof(float),
                                    kNBins * sizeof(float), n_seq * T, hipMemcpyDeviceToHost, ctx->stream));

@@ -245,7 +245,8 @@ int ensure_gru_ws(fvad_ctx* ctx);
 int get_vad_plan(fvad_ctx* ctx, size_t n, VadFftPlan* out, bool force_generic = false);
 bool fvad_fft_size_ok(size_t n); // even, 4 .. kVadFftMax
 // NSNet2 on ws.feat -> ws.gains for n_chunks sequences of T rows; gains rows skip..T-1 only
-int run_nn(fvad_ctx* ctx, long n_chunks_pad, int T, int skip);
+// n_real: the sequences of the padded batch that are real (the tail layers of a small launch run on their rows only); 0 = all
+int run_nn(fvad_ctx* ctx, long n_chunks_pad, int T, int skip, long n_real = 0);
 int calibrate_ws2_waits(fvad_ctx* ctx);
 
 struct LaneJob {

@@ -79,6 +79,15 @@ int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const fl
                            int ldc, long rows, int nt, int n_blocks, int S_steps, int act,
                            int map_T, int map_skip, hipStream_t stream, int n_valid_tiles = 0,
                            const unsigned* guard = nullptr);
+// rows of a small-batch GEMM launch (panel_gemm_s_kernel): n_rows compact rows in ceil(n_rows / 64) panels; L > 0: compact row
+// r = seq * L + tt is A's row seq * in_T + in_t0 + tt and C's row seq * out_T + out_t0 + tt (steps [t0, t0 + L) of every
+// sequence); L == 0: rows as they are
+struct GemmRowMap {
+    int n_rows = 0, L = 0, in_T = 0, in_t0 = 0, out_T = 0, out_t0 = 0;
+};
+int fvad_launch_panel_gemm_s_rows(const float* A, int lda, const float* Wfrag, const float* bias, float* C, int ldc,
+                                  GemmRowMap rm, int nt, int n_blocks, int S_steps, int act, hipStream_t stream,
+                                  int n_valid_tiles = 0, const unsigned* guard = nullptr);
 // small batches (kernels_nn.hip: panel_gemm_s_kernel): nt = 2 or 4 tiles per column block, S_steps in {11, 25, 38}
 int fvad_launch_panel_gemm_s(const float* A, int lda, const float* Wfrag, const float* bias, float* C, int ldc,
                              long rows, int nt, int n_blocks, int S_steps, int act, int map_T, int map_skip,

@@ -192,10 +192,15 @@ int fvad_launch_panel_gemm(const float* A, int lda, const float* Wfrag, const fl
 // tools/small_gemm.hip measures the variants: fc2 / fc3 / fc4 of the 82-chunk batch 41.7 / 59.3 / 33.9 us ->
 // 24.3 / 34.2 / 14.2 us, of a one-chunk push 25 -> 8 us.  Every output is still the k-ordered chain of f32 fmas with
 // the bias added after it: bit-identical to panel_gemm_kernel (asserted by the tool and by the parity tests).
+// Rows: the launch covers `rm.n_rows` compact rows r (the grid is ceil(n_rows / 64) panels; a panel's rows past n_rows read
+// row n_rows - 1 again and store nothing).  rm.L > 0: r = seq * L + tt is steps [t0, t0 + L) of sequence seq -- A's row
+// seq * in_T + in_t0 + tt, C's row seq * out_T + out_t0 + tt -- which serves the warm-up skip (L = T - skip, in_T = T,
+// in_t0 = skip, out rows compact) and launches over the REAL sequences of a padded batch (n_rows = n_real * L).  rm.L == 0:
+// rows as they are.  A row's arithmetic does not depend on which panel or launch computes it.
 template <int NT, int KS, int S, int PF, int ACT>
 __global__ __launch_bounds__(256) void panel_gemm_s_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ Wfrag, const float* __restrict__ bias,
-    float* __restrict__ C, int ldc, int row_map_T, int row_map_skip, int n_valid_tiles, const unsigned* guard)
+    float* __restrict__ C, int ldc, GemmRowMap rm, int n_valid_tiles, const unsigned* guard)
 {
     constexpr int NB = PF + 1;
     __shared__ __attribute__((aligned(16))) float slab[NB][KS * NT * 256];
@@ -208,12 +213,14 @@ __global__ __launch_bounds__(256) void panel_gemm_s_kernel(
     const int m = lane & 15;
     const int q = lane >> 4;
     const int nblk = blockIdx.y;
-    const unsigned row = (blockIdx.x * 4 + wave) * 16 + m;
-    unsigned a_row = row;
-    if (row_map_T > 0) { // compact row index -> rows skip..T-1 of every T-row sequence of A (panel_gemm_kernel)
-        const unsigned per = (unsigned)(row_map_T - row_map_skip);
-        const unsigned qd = row / per;
-        a_row = qd * (unsigned)row_map_T + (unsigned)row_map_skip + (row - qd * per);
+    const unsigned row_raw = (blockIdx.x * 4 + wave) * 16 + m;
+    const bool row_ok = row_raw < (unsigned)rm.n_rows;
+    const unsigned row = row_ok ? row_raw : (unsigned)rm.n_rows - 1u;
+    unsigned a_row = row, c_row = row;
+    if (rm.L > 0) {
+        const unsigned qd = row / (unsigned)rm.L, tt = row - qd * (unsigned)rm.L;
+        a_row = qd * (unsigned)rm.in_T + (unsigned)rm.in_t0 + tt;
+        c_row = qd * (unsigned)rm.out_T + (unsigned)rm.out_t0 + tt;
     }
     const float* a_ptr = A + (size_t)a_row * (size_t)lda + 4 * q;
     const f32x4* w_src = reinterpret_cast<const f32x4*>(Wfrag + (size_t)nblk * S * (NT * 256));
@@ -279,9 +286,9 @@ __global__ __launch_bounds__(256) void panel_gemm_s_kernel(
         }
     }
 
-    float* c_ptr = C + (size_t)row * (size_t)ldc + nblk * (NT * 16) + 4 * q;
+    float* c_ptr = C + (size_t)c_row * (size_t)ldc + nblk * (NT * 16) + 4 * q;
     const float* b_ptr = bias + nblk * (NT * 16) + 4 * q;
-    const int valid_t = n_valid_tiles - nblk * NT; // tiles past the output's width are computed but not stored
+    const int valid_t = row_ok ? n_valid_tiles - nblk * NT : 0; // tiles past the output's width are computed but not stored
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if (t < valid_t) {
@@ -304,17 +311,28 @@ int fvad_launch_panel_gemm_s(const float* A, int lda, const float* Wfrag, const 
                              long rows, int nt, int n_blocks, int S_steps, int act, int map_T, int map_skip,
                              hipStream_t stream, int n_valid_tiles, const unsigned* guard)
 {
+    if (rows <= 0 || rows % 64 != 0) return -1; // (this form: whole 64-row panels of a padded batch)
+    GemmRowMap rm{};
+    rm.n_rows = (int)rows;
+    if (map_T > 0) { rm.L = map_T - map_skip; rm.in_T = map_T; rm.in_t0 = map_skip; rm.out_T = rm.L; rm.out_t0 = 0; }
+    return fvad_launch_panel_gemm_s_rows(A, lda, Wfrag, bias, C, ldc, rm, nt, n_blocks, S_steps, act, stream, n_valid_tiles, guard);
+}
+
+int fvad_launch_panel_gemm_s_rows(const float* A, int lda, const float* Wfrag, const float* bias, float* C, int ldc,
+                                  GemmRowMap rm, int nt, int n_blocks, int S_steps, int act, hipStream_t stream,
+                                  int n_valid_tiles, const unsigned* guard)
+{
     if (n_valid_tiles <= 0) n_valid_tiles = nt * n_blocks;
-    if (rows <= 0 || rows % 64 != 0) return -1;
-    const dim3 grid((unsigned)(rows / 64), (unsigned)n_blocks);
+    if (rm.n_rows <= 0 || rm.L < 0 || (rm.L > 0 && (rm.in_T < rm.L || rm.out_T < rm.L || rm.in_t0 < 0 || rm.out_t0 < 0))) return -1;
+    const dim3 grid((unsigned)((rm.n_rows + 63) / 64), (unsigned)n_blocks);
 #define CASES(S_, ACT_)                                                                                              \
     if (S_steps == S_ && act == ACT_) {                                                                              \
         if (nt == 2)                                                                                                 \
             hipLaunchKernelGGL((panel_gemm_s_kernel<2, 2, S_, 3, ACT_>), grid, dim3(256), 0, stream, A, lda, Wfrag,  \
-                               bias, C, ldc, map_T, map_skip, n_valid_tiles, guard);                                 \
+                               bias, C, ldc, rm, n_valid_tiles, guard);                                              \
         else if (nt == 4)                                                                                            \
             hipLaunchKernelGGL((panel_gemm_s_kernel<4, 1, S_, 4, ACT_>), grid, dim3(256), 0, stream, A, lda, Wfrag,  \
-                               bias, C, ldc, map_T, map_skip, n_valid_tiles, guard);                                 \
+                               bias, C, ldc, rm, n_valid_tiles, guard);                                              \
         else                                                                                                         \
             return -1;                                                                                               \
         return 0;                                                                                                    \

@@ -409,9 +409,10 @@ static int run_nn_generic(fvad_ctx* ctx, long n_pad, int T, int skip)
     return FVAD_OK;
 }
 
-int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
+int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip, long n_real)
 {
     if (!ctx->dm.loaded) return set_err(ctx, FVAD_ERR_NO_MODEL, "NSNet2 weights not loaded");
+    if (n_real <= 0 || n_real > n_pad) n_real = n_pad;
     if (ctx->dm.generic) return run_nn_generic(ctx, n_pad, T, skip);
     Workspace& ws = ctx->ws;
     const DeviceModel& m = ctx->dm;
@@ -603,14 +604,26 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip)
         rc |= launch_gru(ctx, gcs, ws.gi, m.r2v2, m.br2.p, ws.h2, n_pad, T, 1, 1);
         time_end(ctx);
     }
+    // fc2 .. fc4 over the rows of the REAL sequences only (nobody reads a padded batch's other rows: K3 and the callers of
+    // fvad_nsnet2_forward take the real ones): 82 chunks = 4100 rows in 65 panels instead of 4800 in 75, a one-chunk push one
+    // panel instead of 25.  (Measured: nothing at 82 chunks -- 650 or 750 workgroups are three per CU on the fullest CUs either
+    // way -- but a one-chunk push's three launches lose their 450 idle workgroups each.)
+    GemmRowMap r2{}, r3{};
+    r2.L = r3.L = T - skip;
+    r2.n_rows = r3.n_rows = (int)(n_real * (T - skip));
+    r2.in_T = T; r2.in_t0 = skip; r2.out_T = T - skip; r2.out_t0 = 0; // fc2 reads h2 rows [sequence][T], writes rows [sequence][T - skip]
+    r3.in_T = r3.out_T = T - skip;
+    (void)rows_out;
     time_begin(ctx, "fc2_gemm");
-    rc |= fvad_launch_panel_gemm_s(ws.h2, 400, m.s_fc2_w[fam].p, m.fc2_b.p, ws.f2, 640, rows_out, snt, nb_fc, 25, FVAD_ACT_RELU, skip ? T : 0, skip, st);
+    rc |= fvad_launch_panel_gemm_s_rows(ws.h2, 400, m.s_fc2_w[fam].p, m.fc2_b.p, ws.f2, 640, r2, snt, nb_fc, 25, FVAD_ACT_RELU, st);
     time_end(ctx);
     time_begin(ctx, "fc3_gemm");
-    rc |= fvad_launch_panel_gemm_s(ws.f2, 640, m.s_fc3_w[fam].p, m.fc3_b.p, ws.f3, 640, rows_out, snt, nb_fc, 38, FVAD_ACT_RELU, 0, 0, st);
+    rc |= fvad_launch_panel_gemm_s_rows(ws.f2, 640, m.s_fc3_w[fam].p, m.fc3_b.p, ws.f3, 640, r3, snt, nb_fc, 38, FVAD_ACT_RELU, st);
     time_end(ctx);
     time_begin(ctx, "fc4_gemm");
-    rc |= fvad_launch_panel_gemm_s(ws.f3, 640, m.s_fc4_w[fam].p, m.s_fc4_b.p, ws.gains, kFeatStride, rows_out, snt, nb_fc4, 38, FVAD_ACT_SIGMOID, 0, 0, st, 11);
+    // fc4 has 11 tiles: in 4-tile blocks that is 3 workgroups per panel, each a chain of 608 MFMAs per wavefront on a chip that
+    // is otherwise idle (82 chunks: 195 workgroups); 2-tile blocks are twice the workgroups at half the chain (15 -> 10 us there)
+    rc |= fvad_launch_panel_gemm_s_rows(ws.f3, 640, m.s_fc4_w[0].p, m.s_fc4_b.p, ws.gains, kFeatStride, r3, 2, 6, 38, FVAD_ACT_SIGMOID, st, 11);
     time_end(ctx);
     if (rc) return set_err(ctx, FVAD_ERR_INVALID_ARGUMENT, "no kernel instance for this layer shape");
     FVAD_HIP(ctx, hipGetLastError());
@@ -800,7 +813,7 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
                                                kNBins * sizeof(float), t.count * (size_t)kRowsPerChunk, hipMemcpyDeviceToHost, ctx->stream));
         }
         const long n_pad = padded_batch(ctx, n, kRowsPerChunk, kWarmupRows);
-        rc = run_nn(ctx, n_pad, kRowsPerChunk, kWarmupRows);
+        rc = run_nn(ctx, n_pad, kRowsPerChunk, kWarmupRows, n);
         if (rc) return rc;
         time_begin(ctx, "istft320_ola_up3");
         fvad_launch_istft(dd, (int)n, ctx->tb, ws.spec, ws.gains, kFramesPerChunk, 0, ctx->stream, fft_parts);

@@ -23,9 +23,38 @@ for name, key in (("fetch_size", "fetch_kib"), ("write_size", "write_kib")):
         if "rocclr" in k:
             continue
         out.setdefault(k, {})[key] = sum(v) / len(v)
+# request counts by size, when the round's passes include them (tools/profile_round.sh rdreq / wrreq): bytes = sum of
+# count x size, no correction factor -- what settles which of "FETCH_SIZE" and "2 x FETCH_SIZE" is right for a kernel's own
+# access shape (round 5: every kernel of this library issues 128-byte read requests almost exclusively, FETCH_SIZE tallies
+# them at 64 bytes, and 2 x FETCH_SIZE + WRITE_SIZE equals the request-sized total to three digits)
+for name, cols in (("rdreq", ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")),
+                   ("wrreq", ("TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"))):
+    path = os.path.join(here, f"{tag}_pmc_{name}.csv")
+    if not os.path.exists(path):
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        agg[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        if "rocclr" in k or k not in out:
+            continue
+        m = {c: sum(x) / len(x) for c, x in v.items()}
+        if name == "rdreq":
+            out[k]["read_requests"] = {"total": m.get(cols[0], 0.0), "32B": m.get(cols[1], 0.0), "64B": m.get(cols[2], 0.0), "128B": m.get(cols[3], 0.0)}
+            out[k]["hbm_read_bytes_by_request_size"] = 32 * m.get(cols[1], 0.0) + 64 * m.get(cols[2], 0.0) + 128 * m.get(cols[3], 0.0)
+        else:
+            w, w64 = m.get(cols[0], 0.0), m.get(cols[1], 0.0)
+            out[k]["hbm_write_bytes_by_request_size"] = 64 * w64 + 32 * (w - w64)
 for k, v in out.items():
-    v["hbm_bytes_per_launch"] = (2 * v.get("fetch_kib", 0) + v.get("write_kib", 0)) * 1024
+    v["hbm_bytes_fetch_x2_plus_write"] = (2 * v.get("fetch_kib", 0) + v.get("write_kib", 0)) * 1024
     v["hbm_bytes_per_launch_raw_counters"] = (v.get("fetch_kib", 0) + v.get("write_kib", 0)) * 1024
+    if "hbm_read_bytes_by_request_size" in v:
+        v["hbm_bytes_by_request_size"] = v["hbm_read_bytes_by_request_size"] + v.get("hbm_write_bytes_by_request_size", v.get("write_kib", 0) * 1024)
+        v["hbm_bytes_per_launch"] = v["hbm_bytes_by_request_size"]
+        v["hbm_bytes_basis"] = "request counts x request sizes (TCC_EA0_RDREQ_32B/64B/128B, WRREQ_64B): no correction factor"
+    else:
+        v["hbm_bytes_per_launch"] = v["hbm_bytes_fetch_x2_plus_write"]
+        v["hbm_bytes_basis"] = "2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction; confirmed against request sizes in round 5)"
 # MFMA busy fraction and clock from the third pass, when present (GRBM_GUI_ACTIVE is summed over the 8
 # XCDs; SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs)
 mf = os.path.join(here, f"{tag}_pmc_mfma_busy.csv")
@@ -80,5 +109,5 @@ json.dump({"chunks_per_launch": chunks, "recorded_at": datetime.datetime.now(dat
            "source_commit": commit, "kernel_source_digest": sys.argv[4] if len(sys.argv) > 4 else _digest(), "kernels": out},
           open(os.path.join(here, f"{tag}_pmc_summary.json"), "w"), indent=1)
 for k, v in out.items():
-    print(f"{k:45s} {v['hbm_bytes_per_launch'] / 1e9:7.2f} GB/launch corrected, {v['hbm_bytes_per_launch_raw_counters'] / 1e9:7.2f} raw, "
+    print(f"{k:45s} {v['hbm_bytes_per_launch'] / 1e9:7.2f} GB/launch ({'request-sized' if 'hbm_bytes_by_request_size' in v else '2xFETCH+WRITE'}), 2xFETCH+WRITE {v['hbm_bytes_fetch_x2_plus_write'] / 1e9:7.2f}, raw FETCH+WRITE {v['hbm_bytes_per_launch_raw_counters'] / 1e9:7.2f}, "
           f"mfma busy {v.get('mfma_busy_frac', 0):.3f}, clock {v.get('clock_GHz', 0):.2f} GHz")

@@ -35,6 +35,29 @@ __global__ __launch_bounds__(256) void fetch_rows(const float* __restrict__ src,
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) *sink = acc.x;
 }
 
+// gru_rec3_kernel's own reads of gi (kernels_nn.hip: gi_off = (m T 1200 + 4 q) 4 bytes, three float4 loads per unit tile at
+// +192 J, +64, +128): a wavefront owns 16 SEQUENCES, so the 16 rows of one wave-instruction are T x 4800 bytes apart, and a
+// row's 4800 bytes are consumed as 25 chunks of 192 contiguous bytes, one time step after the other.  12 wavefronts per
+// workgroup like the kernel's <12, 2> instance.  Every byte of [n_seq][T][1200] f32 is read exactly once.
+template <int T>
+__global__ __launch_bounds__(768) void fetch_gi_tiles(const float* __restrict__ gi, size_t n_seq, float* sink)
+{
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4, w = threadIdx.x >> 6;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t seq0 = ((size_t)blockIdx.x * 12 + w) * 16; seq0 + 16 <= n_seq; seq0 += (size_t)gridDim.x * 192) {
+        const float* base = gi + (seq0 + m) * (size_t)T * 1200 + 4 * q;
+        for (int t = 0; t < T; ++t)
+#pragma unroll 5
+            for (int J = 0; J < 25; ++J) {
+                const float* p = base + (size_t)t * 1200 + 48 * J;
+                acc += *reinterpret_cast<const f32x4*>(p);
+                acc += *reinterpret_cast<const f32x4*>(p + 16);
+                acc += *reinterpret_cast<const f32x4*>(p + 32);
+            }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) *sink = acc.x;
+}
+
 int main()
 {
     const size_t bytes = 2ull << 30;
@@ -46,9 +69,10 @@ int main()
         hipLaunchKernelGGL(fetch_rows<1600>, dim3(4096), dim3(256), 0, 0, buf, bytes / 1600 / 16 * 16, sink);
         hipLaunchKernelGGL(fetch_rows<704>, dim3(4096), dim3(256), 0, 0, buf, bytes / 704 / 16 * 16, sink);
         hipLaunchKernelGGL(fetch_rows<4800>, dim3(4096), dim3(256), 0, 0, buf, bytes / 4800 / 16 * 16, sink);
+        hipLaunchKernelGGL(fetch_gi_tiles<54>, dim3(256), dim3(768), 0, 0, buf, bytes / (54 * 4800) / 16 * 16, sink);
     }
     hipDeviceSynchronize();
-    printf("fetch_stream: %zu bytes\nfetch_rows<1600>: %zu bytes\nfetch_rows<704>: %zu bytes\nfetch_rows<4800>: %zu bytes\n", bytes,
-           bytes / 1600 / 16 * 16 * 1600, bytes / 704 / 16 * 16 * 704, bytes / 4800 / 16 * 16 * 4800);
+    printf("fetch_stream: %zu bytes\nfetch_rows<1600>: %zu bytes\nfetch_rows<704>: %zu bytes\nfetch_rows<4800>: %zu bytes\nfetch_gi_tiles<54>: %zu bytes\n", bytes,
+           bytes / 1600 / 16 * 16 * 1600, bytes / 704 / 16 * 16 * 704, bytes / 4800 / 16 * 16 * 4800, bytes / (54 * 4800) / 16 * 16 * (size_t)(54 * 4800));
     return 0;
 }
