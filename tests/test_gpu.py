@@ -1126,6 +1126,43 @@ def test_pipeline_stereo_channel_ratio_near_threshold(fv, gpu_ctx, weights7, pkg
     assert ratio_margin < 1e-2
 
 
+def test_default_mode_random_pushes_give_the_one_shot_segments(fv, gpu_ctx, pkg):
+    # The reference gives the same results however audio is pushed (AudioPipeline.zig:118-143 only re-blocks).  Here the NSNet2
+    # kernel family follows the launch size by default, and families agree to ~1e-6 in the gains, not bit for bit -- so a
+    # 2-hour stream pushed in random pieces (0.3 .. 25 s: the pipelined weight-stationary kernels) and the same stream preloaded
+    # in one push (one 14400-chunk launch: the large-batch family) differ in the last bits of every band sum.  What must NOT differ is the
+    # result: the segment lists, sample for sample.  And the audit says how far the stream stayed from flipping a decision:
+    # the smallest relative distance of `short_term` from its threshold over the two hours must dwarf the ~1e-5 the families
+    # are apart, or the equality above would be luck.
+    period = 600
+    base, _ = pkg.synth.make_stream(float(period) + 0.5, seed=4242)
+    base = base[0][: period * 48000]
+    x = np.concatenate([np.roll(base, 7919 * k) for k in range(12)]).astype(np.float32)   # 7200 s: every 600 s the pattern at another phase
+    one = fv.AudioPipeline(gpu_ctx, n_channels=1, trace=False)
+    one.push_samples(x[None])
+    assert "gru_rec3" in gpu_ctx.last_nn_path() or "gru_lat" in gpu_ctx.last_nn_path(), gpu_ctx.last_nn_path()
+    segs_one = one.segments()
+    thr_one, _, n_one = one.audit()
+    rng = np.random.default_rng(99)
+    many = fv.AudioPipeline(gpu_ctx, n_channels=1, trace=False)
+    pos, n_push, paths = 0, 0, set()
+    while pos < x.shape[0]:
+        n = int(rng.integers(int(0.3 * 48000), 25 * 48000))
+        many.push_samples(x[None, pos: pos + n])
+        paths.add(gpu_ctx.last_nn_path().split("+")[-1].strip().split(" ")[0])
+        pos += n
+        n_push += 1
+    segs_many = many.segments()
+    thr_many, _, n_many = many.audit()
+    assert n_push > 400 and n_one == n_many == x.shape[0] // 1024
+    assert any(p.startswith("gru_ws2") for p in paths), paths          # the small pushes really ran another family
+    assert len(segs_one) > 100, len(segs_one)
+    assert [(s[0], s[1]) for s in segs_many] == [(s[0], s[1]) for s in segs_one]
+    worst = min(thr_one, thr_many)
+    print(f"worst threshold margin over 2 h: one push {thr_one:.3e}, {n_push} random pushes {thr_many:.3e}; kernel families {sorted(paths)}")
+    assert worst > 1e-4, f"a frame sat {worst:.2e} from the threshold: equal segment lists would be luck"
+
+
 def test_pipeline_errors_and_skip_processing(fv, gpu_ctx):
     with pytest.raises(fv.FvadError) as e:
         fv.AudioPipeline(gpu_ctx, sample_rate=44100)
