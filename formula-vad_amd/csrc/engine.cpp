@@ -438,7 +438,7 @@ uint32_t fvad_ctx_ws2_waits(const fvad_ctx* ctx, int wait_class)
 {
     if (!ctx || wait_class < 1 || wait_class > 3) return 0;
     const Tuning& tn = ctx->tune;
-    return tn.ws2_waits ? tn.ws2_waits : tn.ws2_waits_cal[wait_class] ? tn.ws2_waits_cal[wait_class] : fvad_gru_ws2_builtin_waits(wait_class);
+    return tn.ws2_waits ? tn.ws2_waits : tn.ws2_waits_cal[wait_class] ? tn.ws2_waits_cal[wait_class] : fvad_gru_ws2_builtin_waits(wait_class, ctx->n_cu == 256 && !(tn.ws2_variant & (8 | 64 | 2048)));
 }
 
 int fvad_ctx_ws_fallbacks(fvad_ctx* ctx, uint64_t* n)

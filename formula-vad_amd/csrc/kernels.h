@@ -113,7 +113,8 @@ int fvad_launch_gru_rec_h3(const float* gi, const float* Rfrag, const float* bR,
 // computes it first from feat, W1frag_nt2 (the small-batch GEMM's 2-tile column blocks of W') and bG1 (tile-major)
 int fvad_launch_gru_ws2_fallback(float* gi, const float* feat, const float* W1frag_nt2, const float* bG1, const float* R1frag, const float* bR1,
                                  const float* W2frag_nt2, const float* bW2, const float* R2frag, const float* bR2, float* h1, float* h2,
-                                 long n_seq_pad, int T, unsigned* sync, unsigned long long* fallbacks, hipStream_t stream);
+                                 long n_seq_pad, int T, unsigned* sync, unsigned long long* fallbacks, hipStream_t stream,
+                                 int zero_at = 0, int zero_n = 0); // sync[zero_at, zero_at + zero_n): more words the last workgroup zeroes for the next pass
 int fvad_launch_gru_lat(const float* gi, const float* R2frag, const float* bR, float* hout,
                         long n_seq_pad, int T, const unsigned* guard, int tile_major, hipStream_t stream, int row_tiles = 1);
 // small batches: recurrent weights stationary in registers across 25 x G workgroups, h exchanged per step
@@ -146,11 +147,15 @@ const char* fvad_gru_ws2_kernel_name(long n_seq_pad, int T, int n_cu, int varian
 int fvad_launch_gru_ws2(const float* gi1, const float* feat, const float* W1frag, const float* bG1, const float* R1frag, const float* bR1,
                         const float* W2frag, const float* bW2, const float* R2frag, const float* bR2, float* hout2, float* hx,
                         unsigned* flags, unsigned* err, long n_seq_pad, int T, int n_cu, unsigned long long spin_ticks, int variant,
-                        unsigned waits, hipStream_t stream); // waits: gru_ws2k's first-poll waits (layer 1 | layer 2 << 16, 10 ns ticks); 0 = built in
+                        unsigned waits, hipStream_t stream, unsigned* lsync = nullptr); // waits: gru_ws2k's first-poll waits (layer 1 | layer 2 << 16, 10 ns ticks); 0 = built in
+// lsync: kWs2LocalWords zeroed words (layer 1's XCD-local flags and the placement tickets): gru_ws2k's layer 1 exchanges h1 inside
+// one XCD where fvad_gru_ws2_local_layer1 says the launch's shape allows it
+constexpr int kWs2LocalWords = 176;
+bool fvad_gru_ws2_local_layer1(long n_seq_pad, int T, int n_cu, int variant);
 // which table of built-in first-poll waits gru_ws2k uses for this launch: 0 not that kernel, 1 groups of 25 + 25, 2 groups of 13 + 25,
 // 3 groups of 13 + 25 with layer 1's input projection in the kernel (what ws2_calibrate measures and overrides)
 int fvad_gru_ws2_wait_class(long n_seq_pad, int T, int n_cu, int variant);
-unsigned fvad_gru_ws2_builtin_waits(int wait_class); // the table's entry, packed like `waits`
+unsigned fvad_gru_ws2_builtin_waits(int wait_class, bool local_layer1 = false); // the table's entry, packed like `waits` (local_layer1: the table of launches whose layer 1 exchanges inside one XCD)
 int fvad_launch_gru_gen(const float* gi, int gi_ld, const float* R2frag, const float* bR, float* hout, int h_ld,
                         long n_seq_pad, int T, int J, hipStream_t stream);
 int fvad_launch_gru_rec3(const float* gi, const float* R2frag, const float* bR, float* hout,

@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(512) void gru_ws2_fallback_kernel(float* gi, const 
                                                                const float* __restrict__ W2frag_nt2, const float* __restrict__ bW2,
                                                                const float* __restrict__ R2frag, const float* __restrict__ bR2,
                                                                float* h1, float* h2, int T, unsigned* sync,
-                                                               unsigned long long* fallbacks)
+                                                               unsigned long long* fallbacks, int zero_at, int zero_n)
 {
     __shared__ __attribute__((aligned(16))) float hs[2][GRU_J * 256];
     __shared__ int s_last;
@@ -1136,16 +1136,17 @@ __global__ __launch_bounds__(512) void gru_ws2_fallback_kernel(float* gi, const 
     if (s_last) {
         if (threadIdx.x == 0 && run) *fallbacks += 1ull;
         for (int i = threadIdx.x; i < 514; i += 512) sync[i] = 0u;
+        for (int i = threadIdx.x; i < zero_n; i += 512) sync[zero_at + i] = 0u; // gru_ws2k's XCD-local flags and placement tickets
     }
 }
 
 int fvad_launch_gru_ws2_fallback(float* gi, const float* feat, const float* W1frag_nt2, const float* bG1, const float* R1frag, const float* bR1,
                                  const float* W2frag_nt2, const float* bW2, const float* R2frag, const float* bR2, float* h1, float* h2,
-                                 long n_seq_pad, int T, unsigned* sync, unsigned long long* fallbacks, hipStream_t stream)
+                                 long n_seq_pad, int T, unsigned* sync, unsigned long long* fallbacks, hipStream_t stream, int zero_at, int zero_n)
 {
     if (n_seq_pad <= 0 || n_seq_pad % 16) return -1;
     hipLaunchKernelGGL(gru_ws2_fallback_kernel, dim3((unsigned)(n_seq_pad / 16)), dim3(512), 0, stream, gi, feat, W1frag_nt2, bG1, R1frag, bR1, W2frag_nt2, bW2,
-                       R2frag, bR2, h1, h2, T, sync, fallbacks);
+                       R2frag, bR2, h1, h2, T, sync, fallbacks, zero_at, zero_n);
     return 0;
 }
 

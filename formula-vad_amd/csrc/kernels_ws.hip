@@ -566,11 +566,16 @@ constexpr unsigned WS2K_WAIT_L1_G = 240, WS2K_WAIT_L2_G = 280, WS2K_WAIT_L1_ONE_
 // layer 2's fetch of the next h1 (wavefront 15) in groups of 13 + 25: 0.505 -> 0.491 ms at 82 chunks (0.55 ms at twice this
 // wait: it is on the critical path then); none in groups of 25 + 25, where it costs a one-chunk push 10-25 us
 constexpr unsigned WS2K_WAIT_H1 = 120;
+// With layer 1 exchanging inside one XCD (lsync) its loop is ~1 us per step shorter and LAYER 2 paces the pipeline: the time no
+// longer depends on layer 1's wait (0 .. 2.4 us: the same), and layer 2's waits move -- swept on a grid (layer 1 x layer 2 x
+// layer 2's h1 wait; 82 sequences: 336 us without the local exchange, 289 - 292 us anywhere in 0 .. 0.4 / 1.6 .. 2.0 / 0.2 .. 0.5 us;
+// 64 sequences: 301 -> 263 - 266 us at 1.4 .. 1.8 us and no h1 wait; one sequence: 288 -> 254 - 258 us at 1.2 .. 1.4 us)
+constexpr unsigned WS2K_WAIT_L1_LOCAL = 20, WS2K_WAIT_L2_LOCAL = 180, WS2K_WAIT_L2_LOCAL_ONE = 140, WS2K_WAIT_H1_LOCAL = 32;
 
 // GI1K: layer 1 computes its input projection in the kernel (feat = the features, rows of kFeatStride floats); otherwise
 // `feat` is gi1, the output of the GEMM launched in front (tile-major rows of 1200), as in round 3 -- kept for A/B runs on
 // one box (context option ws2_variant bit 1024) and as the form the 8-wavefront kernel still uses
-template <bool TRACE, bool GI1K>
+template <bool TRACE, bool GI1K, bool LOCAL>
 __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict__ feat, const float* __restrict__ W1frag,
                                                         const float* __restrict__ bG1, const float* __restrict__ R1frag,
                                                         const float* __restrict__ bR1, const float* __restrict__ W2frag,
@@ -578,8 +583,18 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
                                                         const float* __restrict__ bR2, float* __restrict__ hout2,
                                                         float* hx1, float* hx2, unsigned* flags1, unsigned* flags2,
                                                         unsigned* err, int T, int n_rt, unsigned long long spin_ticks,
-                                                        int variant, int nl1, unsigned waits)
+                                                        int variant, int nl1, unsigned waits, float* hx1l, unsigned* lsync)
 {
+    // lsync != nullptr: LAYER 1 EXCHANGES h1 INSIDE ONE XCD.  Layer 1 is the loop that paces the pipeline, and four memory round
+    // trips of its hand-off cross the fabric (tools/handoff_rate.hip: 2.5 us per step for 13 workgroups spread over the chip,
+    // 1.4 us when all of them sit on one XCD, store plainly -- the tile stays in that XCD's L2 -- and read with L2-served sc1
+    // loads).  Workgroups are dealt to the XCCs round-robin (idle_cu_census.hip), so every XCC gets an eighth of the grid; a
+    // workgroup reads the XCC it is on, takes a ticket of that XCC, and the first tickets of the first XCCs become the layer-1
+    // sets (two groups of 13 per XCC, or one group of 25), everybody else takes a layer-2 place from one global ticket -- the
+    // grouping is a fact read from the hardware, not an assumption about dispatch.  Layer 1 then publishes every tile twice: a
+    // plain store + plain flag for its peers (the critical path), and behind that the write-through store + sc1 flag into the
+    // ring layer 2 reads from wherever it is (with the ring's back-pressure checked there, off the critical path).
+    //   lsync: [0, 160) layer 1's local flags, [160, 168) tickets per XCC, [168] the layer-2 ticket -- zeroed per pass like the flags.
     // dynamic LDS, in float4s: hbA[25][64], hbB[25][64] (the row tile's h1 and h2; layer 1 has no h2 and keeps the step's
     // input rows x_t there: two parities of 11 blocks); per tile slot: xch[3 gates][2 chains][64] recurrent partial products;
     // xci[2 parities][12 blocks][64]: the input projection of the step (layer 1: W' x_t for its two tiles; layer 2: W_ih h1,
@@ -616,9 +631,34 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     // MFMA phase, which paces the whole pipeline, is 104 MFMAs deep on a SIMD instead of 156)
     const int gsz = nl1 + GRU_J;
     const bool one = nl1 == GRU_J;
-    const int g = blockIdx.x / gsz;               // the group = the row tile
-    const int r38 = blockIdx.x - g * gsz;
+    int g_ = (int)blockIdx.x / gsz;               // the group = the row tile
+    int r38_ = (int)blockIdx.x - g_ * gsz;
+    if (LOCAL) {
+        __attribute__((address_space(3))) volatile int* s_role = (__attribute__((address_space(3))) volatile int*)(lds3 + O_WORDS * 16) + 3;
+        if (tid == 0) {
+            unsigned xcc = 0;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 7u;
+            const int tk = (int)atomicAdd(lsync + 160 + xcc, 1u);
+            const int per_host = one ? GRU_J : 26;                         // layer-1 workgroups an XCC hosts: one group of 25, or two of 13
+            const int gl = one ? (int)xcc : 2 * (int)xcc + tk / 13;        // the layer-1 group this ticket belongs to
+            int role;
+            if (tk < per_host && gl < n_rt) role = gl * 64 + (one ? tk : tk % 13);
+            else {
+                const int t2 = (int)atomicAdd(lsync + 168, 1u);
+                role = t2 < n_rt * GRU_J ? (t2 / GRU_J) * 64 + nl1 + t2 % GRU_J : -1; // -1: the launch has more workgroups than places
+            }
+            s_role[0] = role;
+        }
+        __syncthreads();
+        const int role = s_role[0];
+        if (role < 0) return;
+        g_ = role >> 6;
+        r38_ = role & 63;
+    }
+    const int g = g_, r38 = r38_;
     const int layer = r38 >= nl1;
+    const bool loc = LOCAL && !layer;  // this workgroup exchanges h1 through its XCD's L2
     const int pair = layer ? r38 - nl1 : r38;     // layer 1: pair of unit tiles (or the unit tile); layer 2: the unit tile
     const bool tr = TRACE && g == 0 && (r38 == 0 || r38 == nl1);
     const bool gate_wave = wave < 12;
@@ -707,16 +747,20 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
-    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(hx1, 0, 4 * n_rt * GRU_J * 1024, 0x00020000);
-    const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(hx2, 0, 2 * n_rt * GRU_J * 1024, 0x00020000);
+    // ONE buffer resource over the whole exchange area (the launcher lays it out contiguously: four ring slots of h1, two slots of
+    // h2, two XCD-local slots of h1): three resources were twelve scalar registers of a kernel that has none to spare
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(hx1, 0, 8 * n_rt * GRU_J * 1024, 0x00020000);
+    const unsigned o_h2 = (unsigned)(4 * n_rt * GRU_J) * 1024u, o_loc = (unsigned)(6 * n_rt * GRU_J) * 1024u;
+    (void)hx2; (void)hx1l;
     const unsigned lane16 = (unsigned)lane * 16u;
     // one flag per unit tile and layer (25 + 25 per group)
     __attribute__((address_space(1))) unsigned* my_flag =
         (__attribute__((address_space(1))) unsigned*)((layer ? flags2 : flags1) + g * GRU_J + Jc);
     // the polling wavefront (14): lanes 0..24 watch layer 1's flags of this group, lanes 32..56 layer 2's
     __attribute__((address_space(1))) unsigned* poll_flag =
-        (__attribute__((address_space(1))) unsigned*)(lane < 32 ? flags1 + g * GRU_J + (lane < GRU_J ? lane : 0)
+        (__attribute__((address_space(1))) unsigned*)(lane < 32 ? (loc ? lsync : flags1) + g * GRU_J + (lane < GRU_J ? lane : 0)
                                                                 : flags2 + g * GRU_J + (lane - 32 < GRU_J ? lane - 32 : 0));
+    __attribute__((address_space(1))) unsigned* my_flag_l = (__attribute__((address_space(1))) unsigned*)((LOCAL ? lsync : flags1) + g * GRU_J + Jc);
 
     // (Hand-off form: the guide's write-through one -- sc1 payload, drain, sc1 flag; the polling wavefront loads only after
     // its poll has matched -- with sc1 LDS-DMA loads where the guide's measured table has sc1 loads to registers, and one
@@ -738,11 +782,12 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     // publishes late and makes its peers' polls miss: 400 us instead of 350.)  Timing only: results do not depend on it.
     // waits != 0 (context options ws2_waits / ws2_calibrate): layer 1's wait in the low half, layer 2's in the high half, ticks.
     const unsigned wait_ticks = waits ? (layer ? waits >> 16 : waits & 0xFFFFu)
+                                      : LOCAL ? (layer ? (one ? WS2K_WAIT_L2_LOCAL_ONE : WS2K_WAIT_L2_LOCAL) : WS2K_WAIT_L1_LOCAL)
                                                       : GI1K ? (layer ? (one ? WS2K_WAIT_L2_ONE_G : WS2K_WAIT_L2_G) : (one ? WS2K_WAIT_L1_ONE_G : WS2K_WAIT_L1_G))
                                                              : (layer ? (one ? WS2K_WAIT_L2_ONE : WS2K_WAIT_L2) : (one ? WS2K_WAIT_L1_ONE : WS2K_WAIT_L1));
     auto acquire = [&](int pw, unsigned need1, unsigned need2, bool from_h2, unsigned slot, int st, int ev, int ready, bool timed) {
         if (wave == pw) {
-            const unsigned wt = timed ? wait_ticks : ((pw == 15 && !one) ? WS2K_WAIT_H1 : 0u);
+            const unsigned wt = timed ? wait_ticks : ((pw == 15 && !one) ? (LOCAL ? WS2K_WAIT_H1_LOCAL : WS2K_WAIT_H1) : 0u);
             if (wt) {
                 const unsigned long long until = __builtin_amdgcn_s_memrealtime() + wt;
                 while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(1);
@@ -768,8 +813,13 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
                 if (from_h2) {
 #pragma unroll
                     for (int S = 0; S < GRU_J; ++S)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void*)(lds3 + (GRU_J + S) * 1024), 16, lane16,
-                                                                 slot + row0 + S * 1024, 0, WS_AUX_SC1);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)(lds3 + (GRU_J + S) * 1024), 16, lane16,
+                                                                 o_h2 + slot + row0 + S * 1024, 0, WS_AUX_SC1);
+                } else if (loc) {
+#pragma unroll
+                    for (int S = 0; S < GRU_J; ++S)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)(lds3 + S * 1024), 16, lane16,
+                                                                 o_loc + slot + row0 + S * 1024, 0, WS_AUX_SC1);
                 } else {
 #pragma unroll
                     for (int S = 0; S < GRU_J; ++S)
@@ -882,12 +932,43 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
                 }
             }
             hpv[tslot * 64 + lane] = h;
+            if (loc) {
+                // for the peers, inside the XCD: a plain store (the line stays in this XCD's L2), the drain, a plain flag
+                const unsigned offl = (unsigned)((((t & 1) * n_rt + g) * GRU_J + J) * 1024);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs1, lane16, o_loc + offl, 0);
+                if (wave == 12) WS_STAMP(t, 7);
+                if (GI1K && lane == 0) g_done[tslot] = t + 1;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (wave == 12) WS_STAMP(t, 8);
+                if (lane == 0) __hip_atomic_store(my_flag_l, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // for layer 2, wherever it runs: the ring of four slots, behind its back-pressure (layer 2 has published step
+                // t - 4 before slot t % 4 is overwritten: it reads h1_s in its step s) -- all of it off layer 1's critical path
+                if (t >= 4 && !WS_DIAG(variant, 4)) {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    __attribute__((address_space(1))) unsigned* f2 = (__attribute__((address_space(1))) unsigned*)(flags2 + g * GRU_J + (lane < GRU_J ? lane : 0));
+                    for (;;) {
+                        const unsigned v = lane < GRU_J ? __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+                        if (__all(v >= (unsigned)(t - 3))) break;
+                        if (*s_dead) break;
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) {
+                            if (lane == 0) { __hip_atomic_store((__attribute__((address_space(1))) unsigned*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *s_dead = 1; }
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                const unsigned off = (unsigned)((((t & 3) * n_rt + g) * GRU_J + J) * 1024);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs1, lane16, off, WS_AUX_SC1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(my_flag, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
             if (layer == 0) {
                 const unsigned off = (unsigned)((((t & 3) * n_rt + g) * GRU_J + J) * 1024);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs1, lane16, off, WS_AUX_SC1);
             } else {
                 const unsigned off = (unsigned)((((t & 1) * n_rt + g) * GRU_J + J) * 1024);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs2, lane16, off, WS_AUX_SC1);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs1, lane16, o_h2 + off, WS_AUX_SC1);
             }
             // this wavefront stored the whole tile: it drains and raises the tile's flag itself
             if (wave == 12) WS_STAMP(t, 7);
@@ -926,7 +1007,8 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
             // h1_{t-1} of every peer, and -- before slot t % 4 is overwritten -- h1_{t-4} consumed by every layer-2 peer
             // (layer 2 reads h1_s in its step s: it has published h2_{t-4}, flag t - 3, only after that)
             request_gi(t);
-            acquire(14, (unsigned)t, (t >= 4 && !WS_DIAG(variant, 4)) ? (unsigned)(t - 3) : 0u, false, (unsigned)(((t - 1) & 3) * n_rt * GRU_J) * 1024u, t, 0, -1, true);
+            if (loc) acquire(14, (unsigned)t, 0u, false, (unsigned)(((t - 1) & 1) * n_rt * GRU_J) * 1024u, t, 0, -1, true);
+            else acquire(14, (unsigned)t, (t >= 4 && !WS_DIAG(variant, 4)) ? (unsigned)(t - 3) : 0u, false, (unsigned)(((t - 1) & 3) * n_rt * GRU_J) * 1024u, t, 0, -1, true);
             if (!barrier_alive()) return;
             if (wave == 0) WS_STAMP(t, 4);
             if (gate_wave && tile_ok) chain(hbA, 0u);
@@ -1311,7 +1393,16 @@ bool fvad_gru_ws2_ok(long n_seq_pad, int T, int n_cu, int variant)
     return ws2_kernel_for(n_seq_pad, T, n_cu, variant, &k) != 0;
 }
 
-size_t fvad_gru_ws2_exchange_floats(long n_seq_pad) { return (size_t)6 * (size_t)(n_seq_pad / 16) * GRU_J * 256; }
+size_t fvad_gru_ws2_exchange_floats(long n_seq_pad) { return (size_t)8 * (size_t)(n_seq_pad / 16) * GRU_J * 256; } // 4 + 2 slots across the chip, 2 inside an XCD
+
+// Layer 1 of gru_ws2k exchanging inside one XCD: 8 XCCs of 32 CUs (MI355X), one row tile per group, and places for the sets:
+// two groups of 13 per XCC (six groups on three XCCs), or one group of 25 (up to five on five).  variant bit 2048 switches it off.
+bool fvad_gru_ws2_local_layer1(long n_seq_pad, int T, int n_cu, int variant)
+{
+    bool k;
+    if (n_cu != 256 || (variant & (8 | 64 | 2048)) || ws2_kernel_for(n_seq_pad, T, n_cu, variant, &k) != 1) return false;
+    return true;
+}
 
 // the 16-wavefront kernel (one row tile per group) computes layer 1's input projection itself: no GEMM launch in front of it.
 // It addresses the features and h2 through 32-bit buffer offsets, so a launch whose h2 exceeds 2 GiB keeps the other kernel.
@@ -1351,8 +1442,10 @@ int fvad_gru_ws2_wait_class(long n_seq_pad, int T, int n_cu, int variant)
     return one ? 1 : gi1k ? 3 : 2;
 }
 
-unsigned fvad_gru_ws2_builtin_waits(int wait_class)
+unsigned fvad_gru_ws2_builtin_waits(int wait_class, bool local_layer1)
 {
+    if (local_layer1 && wait_class >= 1 && wait_class <= 3)
+        return WS2K_WAIT_L1_LOCAL | ((wait_class == 1 ? WS2K_WAIT_L2_LOCAL_ONE : WS2K_WAIT_L2_LOCAL) << 16);
     switch (wait_class) {
     case 1: return WS2K_WAIT_L1_ONE | (WS2K_WAIT_L2_ONE << 16);
     case 2: return WS2K_WAIT_L1 | (WS2K_WAIT_L2 << 16);
@@ -1364,7 +1457,7 @@ unsigned fvad_gru_ws2_builtin_waits(int wait_class)
 int fvad_launch_gru_ws2(const float* gi1, const float* feat, const float* W1frag, const float* bG1, const float* R1frag, const float* bR1,
                         const float* W2frag, const float* bW2, const float* R2frag, const float* bR2, float* hout2, float* hx,
                         unsigned* flags, unsigned* err, long n_seq_pad, int T, int n_cu, unsigned long long spin_ticks, int variant,
-                        unsigned waits, hipStream_t stream)
+                        unsigned waits, hipStream_t stream, unsigned* lsync)
 {
     int RT = 0, G = 0;
     if (!fvad_gru_ws2_shape(n_seq_pad, n_cu, &RT, &G)) return -1;
@@ -1380,15 +1473,23 @@ int fvad_launch_gru_ws2(const float* gi1, const float* feat, const float* W1frag
         const size_t lds_k = (size_t)(2 * GRU_J * 64 + 12 * 64 + 24 * 64 + 2 * 64 + 48 + 176 + 2 * 3 * (kFeatStride / 16) * 64) * 16;
         // up to five row tiles (80 sequences) on 256 CUs: 25 + 25 workgroups per group; six: 13 + 25 (variant 16: always)
         const int nl1 = (G * 2 * GRU_J <= n_cu && !(variant & 16)) ? GRU_J : 13;
-        const dim3 grid((unsigned)(G * (nl1 + GRU_J)));
+        // layer 1 inside one XCD (lsync): every XCC that hosts a layer-1 set must be dealt at least the set's workgroups, and the
+        // grid is dealt round-robin over 8 XCCs: at least 8 x 25 workgroups for sets of 25 (the surplus finds no place and leaves)
+        const bool local1 = lsync != nullptr && fvad_gru_ws2_local_layer1(n_seq_pad, T, n_cu, variant);
+        unsigned n_wg = (unsigned)(G * (nl1 + GRU_J));
+        if (local1 && n_wg < 8u * (nl1 == GRU_J ? GRU_J : 26)) n_wg = 8u * (nl1 == GRU_J ? GRU_J : 26); // (two groups of 13 per host XCC)
+        const dim3 grid(n_wg);
+        float* hx1l = hx + (size_t)6 * n_rt * GRU_J * 256; // behind the four + two cross-XCD slots
+        unsigned* ls = local1 ? lsync : nullptr;
         const float* in1 = gi1k ? feat : gi1;
-#define WS2K_LAUNCH(TRACE_, GI1K_)                                                                                                              \
+#define WS2K_LAUNCH_(TRACE_, GI1K_, LOCAL_)                                                                                                     \
         {                                                                                                                                       \
-            if (hipFuncSetAttribute((const void*)gru_ws2k_kernel<TRACE_, GI1K_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return -2; \
-            hipLaunchKernelGGL((gru_ws2k_kernel<TRACE_, GI1K_>), grid, dim3(1024), lds_k, stream, in1, W1frag, bG1, R1frag, bR1, W2frag, bW2, R2frag, bR2, \
-                               hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant, nl1, waits);                                \
+            if (hipFuncSetAttribute((const void*)gru_ws2k_kernel<TRACE_, GI1K_, LOCAL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return -2; \
+            hipLaunchKernelGGL((gru_ws2k_kernel<TRACE_, GI1K_, LOCAL_>), grid, dim3(1024), lds_k, stream, in1, W1frag, bG1, R1frag, bR1, W2frag, bW2, R2frag, bR2, \
+                               hout2, hx1, hx2, flags, flags + 256, err, T, n_rt, spin_ticks, variant, nl1, waits, hx1l, ls);                      \
             return 0;                                                                                                                           \
         }
+#define WS2K_LAUNCH(TRACE_, GI1K_) { if (ls) WS2K_LAUNCH_(TRACE_, GI1K_, true) WS2K_LAUNCH_(TRACE_, GI1K_, false) }
 #if FVAD_DIAG
         if (variant & 64) { // step trace (tools/ws2_trace.py)
             if (gi1k) WS2K_LAUNCH(true, true)
@@ -1398,6 +1499,7 @@ int fvad_launch_gru_ws2(const float* gi1, const float* feat, const float* W1frag
         if (gi1k) WS2K_LAUNCH(false, true)
         WS2K_LAUNCH(false, false)
 #undef WS2K_LAUNCH
+#undef WS2K_LAUNCH_
     }
     if (which == 2) { // 2..16 row tiles per group, streamed through LDS
         const size_t lds_m = (size_t)(4 * GRU_J * 64 + 24 * 64 + RT * 128 + 48 + 1) * 16; // >= 129 KB: one workgroup per CU

@@ -104,7 +104,8 @@ struct GruChoice {
     int waves;
 };
 
-constexpr size_t kWsSyncWords = 520 + 2000; // 2 x 256 flags + error word, padded to a multiple of 16 bytes; then gru_ws2k's step trace (ws2_variant 64)
+constexpr size_t kWsLocalAt = 520 + 2000; // 2 x 256 flags + error word + ticket; gru_ws2k's step trace (ws2_variant 64); then its XCD-local flags and tickets
+constexpr size_t kWsSyncWords = kWsLocalAt + kWs2LocalWords;
 
 // gru_ws launches spin on each other's flags, so two of them must not share the chip half-resident.
 // Within a process every such launch waits (on the GPU) for the previous one on the same device; across
@@ -581,12 +582,13 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip, long n_real)
         rc |= ws_serialised(ctx, [&] {
             return fvad_launch_gru_ws2(ws.gi, ws.feat, m.s_w1frag.p, m.gi1f_b.p, m.r1v2.p, m.br1.p, m.s_w2frag.p, m.s_bw2.p, m.r2v2.p, m.br2.p, ws.h2,
                                        ws.hx, ws.ws_sync, err, n_pad, T, ctx->n_cu, ws_spin_deadline(ctx, gru_ws2_cost_both_layers(n_pad, T, ctx->n_cu, tn.ws2_variant) * T / 55.0), tn.ws2_variant,
-                                       tn.ws2_waits ? tn.ws2_waits : tn.ws2_waits_cal[fvad_gru_ws2_wait_class(n_pad, T, ctx->n_cu, tn.ws2_variant)], st);
+                                       tn.ws2_waits ? tn.ws2_waits : tn.ws2_waits_cal[fvad_gru_ws2_wait_class(n_pad, T, ctx->n_cu, tn.ws2_variant)], st,
+                                       ws.ws_sync + kWsLocalAt);
         });
         // one launch behind it: the whole fallback (layer 1, layer 2's input projection, layer 2 -- run only if the
         // error word was raised), the pass count, and the reset of the polled words for the next pass
         rc |= fvad_launch_gru_ws2_fallback(ws.gi, gi1_in_kernel ? ws.feat : nullptr, m.s_gi1f_w[0].p, m.gi1f_b.p, m.r1v2.p, m.br1.p, m.s_gi2_w[0].p,
-                                           m.gi2_btm.p, m.r2v2.p, m.br2.p, ws.h1, ws.h2, n_pad, T, ws.ws_sync, ws.ws_fallbacks, st);
+                                           m.gi2_btm.p, m.r2v2.p, m.br2.p, ws.h1, ws.h2, n_pad, T, ws.ws_sync, ws.ws_fallbacks, st, (int)kWsLocalAt, kWs2LocalWords);
         {   // the launch above leaves the words zeroed -- once it has RUN: a sequence under capture has not
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(st, &cap);
@@ -673,7 +675,7 @@ int calibrate_ws2_waits(fvad_ctx* ctx)
         const int cls = fvad_gru_ws2_wait_class(n_pad, T, ctx->n_cu, tn.ws2_variant);
         if (cls == 0 || done[cls] || pick_gru(ctx, n_pad, T, false).version != 6) continue;
         done[cls] = true;
-        const unsigned base = fvad_gru_ws2_builtin_waits(cls);
+        const unsigned base = fvad_gru_ws2_builtin_waits(cls, fvad_gru_ws2_local_layer1(n_pad, T, ctx->n_cu, tn.ws2_variant));
         float t_base = 0;
         if ((rc = time_pass(n_pad, base, &t_base))) break;
         unsigned best = base;
