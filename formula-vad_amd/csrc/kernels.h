@@ -150,7 +150,7 @@ int fvad_launch_gru_ws2(const float* gi1, const float* feat, const float* W1frag
                         unsigned waits, hipStream_t stream, unsigned* lsync = nullptr); // waits: gru_ws2k's first-poll waits (layer 1 | layer 2 << 16, 10 ns ticks); 0 = built in
 // lsync: kWs2LocalWords zeroed words (layer 1's XCD-local flags and the placement tickets): gru_ws2k's layer 1 exchanges h1 inside
 // one XCD where fvad_gru_ws2_local_layer1 says the launch's shape allows it
-constexpr int kWs2LocalWords = 176;
+constexpr int kWs2LocalWords = 336;
 bool fvad_gru_ws2_local_layer1(long n_seq_pad, int T, int n_cu, int variant);
 // which table of built-in first-poll waits gru_ws2k uses for this launch: 0 not that kernel, 1 groups of 25 + 25, 2 groups of 13 + 25,
 // 3 groups of 13 + 25 with layer 1's input projection in the kernel (what ws2_calibrate measures and overrides)

@@ -570,7 +570,9 @@ constexpr unsigned WS2K_WAIT_H1 = 120;
 // longer depends on layer 1's wait (0 .. 2.4 us: the same), and layer 2's waits move -- swept on a grid (layer 1 x layer 2 x
 // layer 2's h1 wait; 82 sequences: 336 us without the local exchange, 289 - 292 us anywhere in 0 .. 0.4 / 1.6 .. 2.0 / 0.2 .. 0.5 us;
 // 64 sequences: 301 -> 263 - 266 us at 1.4 .. 1.8 us and no h1 wait; one sequence: 288 -> 254 - 258 us at 1.2 .. 1.4 us)
-constexpr unsigned WS2K_WAIT_L1_LOCAL = 20, WS2K_WAIT_L2_LOCAL = 180, WS2K_WAIT_L2_LOCAL_ONE = 140, WS2K_WAIT_H1_LOCAL = 32;
+// With layer 2 inside one XCD as well (at most four groups) an early poll is an L2 hit and costs nothing: the time is flat
+// (228 - 233 us at 1, 32 and 64 sequences) for layer-2 waits of 0 .. 1.2 us and any layer-1 wait, 5 - 10 us more from 1.4 us on
+constexpr unsigned WS2K_WAIT_L1_LOCAL = 20, WS2K_WAIT_L2_LOCAL = 180, WS2K_WAIT_L2_LOCAL_ONE = 140, WS2K_WAIT_L2_LOCAL_BOTH = 60, WS2K_WAIT_H1_LOCAL = 32;
 
 // GI1K: layer 1 computes its input projection in the kernel (feat = the features, rows of kFeatStride floats); otherwise
 // `feat` is gi1, the output of the GEMM launched in front (tile-major rows of 1200), as in round 3 -- kept for A/B runs on
@@ -594,7 +596,8 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     // grouping is a fact read from the hardware, not an assumption about dispatch.  Layer 1 then publishes every tile twice: a
     // plain store + plain flag for its peers (the critical path), and behind that the write-through store + sc1 flag into the
     // ring layer 2 reads from wherever it is (with the ring's back-pressure checked there, off the critical path).
-    //   lsync: [0, 160) layer 1's local flags, [160, 168) tickets per XCC, [168] the layer-2 ticket -- zeroed per pass like the flags.
+    //   lsync: [0, 160) layer 1's local flags, [160, 168) tickets per XCC, [168] the layer-2 ticket, [176, 336) layer 2's local flags
+    //   (with at most four groups of 25 + 25 every layer-2 set has an XCC of its own as well) -- zeroed per pass like the flags.
     // dynamic LDS, in float4s: hbA[25][64], hbB[25][64] (the row tile's h1 and h2; layer 1 has no h2 and keeps the step's
     // input rows x_t there: two parities of 11 blocks); per tile slot: xch[3 gates][2 chains][64] recurrent partial products;
     // xci[2 parities][12 blocks][64]: the input projection of the step (layer 1: W' x_t for its two tiles; layer 2: W_ih h1,
@@ -644,6 +647,8 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
             const int gl = one ? (int)xcc : 2 * (int)xcc + tk / 13;        // the layer-1 group this ticket belongs to
             int role;
             if (tk < per_host && gl < n_rt) role = gl * 64 + (one ? tk : tk % 13);
+            else if (one && 2 * n_rt <= 8) // every set has an XCC of its own: XCC n_rt + g hosts layer 2 of group g
+                role = ((int)xcc >= n_rt && (int)xcc < 2 * n_rt && tk < GRU_J) ? ((int)xcc - n_rt) * 64 + nl1 + tk : -1;
             else {
                 const int t2 = (int)atomicAdd(lsync + 168, 1u);
                 role = t2 < n_rt * GRU_J ? (t2 / GRU_J) * 64 + nl1 + t2 % GRU_J : -1; // -1: the launch has more workgroups than places
@@ -659,6 +664,8 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     const int g = g_, r38 = r38_;
     const int layer = r38 >= nl1;
     const bool loc = LOCAL && !layer;  // this workgroup exchanges h1 through its XCD's L2
+    // ... and with at most four groups of 25 + 25 every layer-2 set sits on an XCC of its own too: h2 goes the same way
+    const bool loc2 = LOCAL && layer && one && 2 * n_rt <= 8;
     const int pair = layer ? r38 - nl1 : r38;     // layer 1: pair of unit tiles (or the unit tile); layer 2: the unit tile
     const bool tr = TRACE && g == 0 && (r38 == 0 || r38 == nl1);
     const bool gate_wave = wave < 12;
@@ -749,8 +756,8 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
 
     // ONE buffer resource over the whole exchange area (the launcher lays it out contiguously: four ring slots of h1, two slots of
     // h2, two XCD-local slots of h1): three resources were twelve scalar registers of a kernel that has none to spare
-    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(hx1, 0, 8 * n_rt * GRU_J * 1024, 0x00020000);
-    const unsigned o_h2 = (unsigned)(4 * n_rt * GRU_J) * 1024u, o_loc = (unsigned)(6 * n_rt * GRU_J) * 1024u;
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(hx1, 0, 10 * n_rt * GRU_J * 1024, 0x00020000);
+    const unsigned o_h2 = (unsigned)((loc2 ? 8 : 4) * n_rt * GRU_J) * 1024u, o_loc = (unsigned)(6 * n_rt * GRU_J) * 1024u; // (layer 2's XCD-local slots: 8 .. 10)
     (void)hx2; (void)hx1l;
     const unsigned lane16 = (unsigned)lane * 16u;
     // one flag per unit tile and layer (25 + 25 per group)
@@ -759,8 +766,8 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     // the polling wavefront (14): lanes 0..24 watch layer 1's flags of this group, lanes 32..56 layer 2's
     __attribute__((address_space(1))) unsigned* poll_flag =
         (__attribute__((address_space(1))) unsigned*)(lane < 32 ? (loc ? lsync : flags1) + g * GRU_J + (lane < GRU_J ? lane : 0)
-                                                                : flags2 + g * GRU_J + (lane - 32 < GRU_J ? lane - 32 : 0));
-    __attribute__((address_space(1))) unsigned* my_flag_l = (__attribute__((address_space(1))) unsigned*)((LOCAL ? lsync : flags1) + g * GRU_J + Jc);
+                                                                : (loc2 ? lsync + 176 : flags2) + g * GRU_J + (lane - 32 < GRU_J ? lane - 32 : 0));
+    __attribute__((address_space(1))) unsigned* my_flag_l = (__attribute__((address_space(1))) unsigned*)((LOCAL ? lsync + (layer ? 176 : 0) : flags1) + g * GRU_J + Jc);
 
     // (Hand-off form: the guide's write-through one -- sc1 payload, drain, sc1 flag; the polling wavefront loads only after
     // its poll has matched -- with sc1 LDS-DMA loads where the guide's measured table has sc1 loads to registers, and one
@@ -782,7 +789,7 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
     // publishes late and makes its peers' polls miss: 400 us instead of 350.)  Timing only: results do not depend on it.
     // waits != 0 (context options ws2_waits / ws2_calibrate): layer 1's wait in the low half, layer 2's in the high half, ticks.
     const unsigned wait_ticks = waits ? (layer ? waits >> 16 : waits & 0xFFFFu)
-                                      : LOCAL ? (layer ? (one ? WS2K_WAIT_L2_LOCAL_ONE : WS2K_WAIT_L2_LOCAL) : WS2K_WAIT_L1_LOCAL)
+                                      : LOCAL ? (layer ? (one ? (loc2 ? WS2K_WAIT_L2_LOCAL_BOTH : WS2K_WAIT_L2_LOCAL_ONE) : WS2K_WAIT_L2_LOCAL) : WS2K_WAIT_L1_LOCAL)
                                                       : GI1K ? (layer ? (one ? WS2K_WAIT_L2_ONE_G : WS2K_WAIT_L2_G) : (one ? WS2K_WAIT_L1_ONE_G : WS2K_WAIT_L1_G))
                                                              : (layer ? (one ? WS2K_WAIT_L2_ONE : WS2K_WAIT_L2) : (one ? WS2K_WAIT_L1_ONE : WS2K_WAIT_L1));
     auto acquire = [&](int pw, unsigned need1, unsigned need2, bool from_h2, unsigned slot, int st, int ev, int ready, bool timed) {
@@ -968,13 +975,17 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs1, lane16, off, WS_AUX_SC1);
             } else {
                 const unsigned off = (unsigned)((((t & 1) * n_rt + g) * GRU_J + J) * 1024);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs1, lane16, o_h2 + off, WS_AUX_SC1);
+                if (loc2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs1, lane16, o_h2 + off, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs1, lane16, o_h2 + off, WS_AUX_SC1);
             }
             // this wavefront stored the whole tile: it drains and raises the tile's flag itself
             if (wave == 12) WS_STAMP(t, 7);
             if (GI1K && layer == 0 && lane == 0) g_done[tslot] = t + 1; // the gate wavefronts may start the next step's input projection
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (wave == 12) WS_STAMP(t, 8);
+            // (layer 2 inside one XCD: the plain flag its peers poll first, then the sc1 flag layer 1's back-pressure check reads
+            // across the chip -- that one stands for "h1 of this step has been consumed", not for any stored byte)
+            if (loc2 && lane == 0) __hip_atomic_store(my_flag_l, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (lane == 0) __hip_atomic_store(my_flag, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (layer && !WS_DIAG(variant, 2)) { // the row-major copy the next layer (fc2) reads: not part of the hand-off
                 unsigned l16 = lane16;
@@ -1393,7 +1404,7 @@ bool fvad_gru_ws2_ok(long n_seq_pad, int T, int n_cu, int variant)
     return ws2_kernel_for(n_seq_pad, T, n_cu, variant, &k) != 0;
 }
 
-size_t fvad_gru_ws2_exchange_floats(long n_seq_pad) { return (size_t)8 * (size_t)(n_seq_pad / 16) * GRU_J * 256; } // 4 + 2 slots across the chip, 2 inside an XCD
+size_t fvad_gru_ws2_exchange_floats(long n_seq_pad) { return (size_t)10 * (size_t)(n_seq_pad / 16) * GRU_J * 256; } // 4 + 2 slots across the chip, 2 + 2 inside an XCD
 
 // Layer 1 of gru_ws2k exchanging inside one XCD: 8 XCCs of 32 CUs (MI355X), one row tile per group, and places for the sets:
 // two groups of 13 per XCC (six groups on three XCCs), or one group of 25 (up to five on five).  variant bit 2048 switches it off.
