@@ -1,5 +1,6 @@
 """BASELINE config 2 (FFT isolation): device-resident rate of fvad_fft_forward_batch (window + rFFT-320 + |X|) at
-1024 and 2^20 frames, magnitudes only and bins + magnitudes.  python tools/fft_batch_rate.py"""
+1024 and 2^20 frames, magnitudes only and bins + magnitudes, with a digest of the outputs (two builds on one box: FVAD_LIB_PATH).
+python tools/fft_batch_rate.py"""
 import importlib.util, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,6 +28,12 @@ for n in (1024, 1 << 20):
             L.fvad_fft_forward_batch(f.h, d_x, n, d_win, b, m, 1)
         ctx.synchronize()
         dt = (time.perf_counter() - t0) / reps
-        print(f"n={n} {what}: {dt*1e6:.1f} us/launch, {n*nbytes/dt/1e9:.0f} GB/s = {n*nbytes/dt/8e12:.3f} of 8 TB/s", flush=True)
+        import hashlib
+        h_m = np.empty((n, 161), np.float32); ctx.to_host(h_m, m)
+        dig = hashlib.sha256(h_m.tobytes())
+        if b is not None:
+            h_b = np.empty((n, 161, 2), np.float32); ctx.to_host(h_b, b)
+            dig.update(h_b.tobytes())
+        print(f"n={n} {what}: {dt*1e6:.1f} us/launch, {n*nbytes/dt/1e9:.0f} GB/s = {n*nbytes/dt/8e12:.3f} of 8 TB/s   digest {dig.hexdigest()[:16]}", flush=True)
     for d in (d_x, d_mag, d_bins):
         ctx.device_free(d)
