@@ -964,7 +964,7 @@ def side_measurements(pkg, fv, ctx, torch, dev):
         fr = n_l * n_s * 100
         extra[name] = {"frames_per_s": fr / best, "ms": best * 1e3, "streams": n_l, "seconds_per_stream": n_s,
                        "host_link_GBps": fr * (3840 if den else 1920) / best / 1e9,
-                       "note": "fvad_engine_run on pageable host buffers (best of 3): staged H2D, kernels and D2H pipelined over 4 lane groups"}
+                       "note": "fvad_engine_run on pageable host buffers (best of 3): staged H2D, kernels and D2H pipelined over lane groups (sizes by the formats' rates: csrc/engine_run.cpp plan_groups)"}
     # 16-bit transport: the same streams handed over as PCM16 (converted by the kernel that reads them) and, in the
     # second figure, the denoised audio taken back as PCM16 too
     try:

@@ -3,10 +3,12 @@
 // Part of libfvad_hip.so.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -31,21 +33,6 @@ int ensure_pin(fvad_ctx* ctx, Workspace::PinRing& ring)
     FVAD_HIP(ctx, hipHostMalloc((void**)&ring.base, 2 * kPinSlots * kPinSlotBytes, hipHostMallocDefault));
     for (hipEvent_t& e : ring.ev) FVAD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return FVAD_OK;
-}
-
-void parallel_memcpy(const std::vector<CopySeg>& blocks, size_t first, size_t n, char* slots, bool to_pinned, int n_threads)
-{
-    auto work = [&](size_t t) {
-        for (size_t i = t; i < n; i += (size_t)n_threads) {
-            const CopySeg& b = blocks[first + i];
-            if (to_pinned) memcpy(slots + i * kPinSlotBytes, b.host, b.bytes);
-            else memcpy(b.host, slots + i * kPinSlotBytes, b.bytes);
-        }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < n_threads && (size_t)t < n; ++t) th.emplace_back(work, (size_t)t);
-    work(0);
-    for (auto& x : th) x.join();
 }
 
 // host -> device (to_device) or device -> host, ordered on ctx->stream; returns after the last DMA has
@@ -113,37 +100,93 @@ int staged_copy(fvad_ctx* ctx, const std::vector<CopySeg>& segs, bool to_device,
     if (blocks.empty()) return FVAD_OK;
     int rc = ensure_pin(ctx, ring);
     if (rc) return rc;
-    const size_t n_waves = (blocks.size() + kPinSlots - 1) / kPinSlots;
-    auto wave_n = [&](size_t w) { return std::min((size_t)kPinSlots, blocks.size() - w * kPinSlots); };
-    auto half = [&](size_t w) { return ring.base + (w & 1) * kPinSlots * kPinSlotBytes; };
+    // Block by block through the ring's 32 slots: copy threads move user memory <-> slots (block i on thread i mod T, so
+    // blocks finish about in order), the calling thread enqueues the DMAs in order, an event per slot says when its DMA is done.
+    // What is not overlapped is ONE block's host copy at the start (host -> device) or at the end (device -> host) -- the
+    // wave-by-wave form before it (16 slots copied, then their 16 DMAs) exposed a whole wave: 1.3 ms per call of ~100 MB and
+    // more, i.e. per lane group of fvad_engine_run (tools/pcie_run.py with FVAD_TRACE_RUN=1).
+    const size_t nb = blocks.size();
+    constexpr size_t NS = 2 * kPinSlots;
+    const int T = std::max(1, std::min<int>(ctx->tune.copy_threads, (int)nb));
+    std::unique_ptr<std::atomic<unsigned char>[]> copied(new std::atomic<unsigned char>[nb]), queued(new std::atomic<unsigned char>[nb]);
+    for (size_t i = 0; i < nb; ++i) { copied[i].store(0, std::memory_order_relaxed); queued[i].store(0, std::memory_order_relaxed); }
+    std::atomic<bool> failed{false};
+    auto slot = [&](size_t i) { return ring.base + (i % NS) * kPinSlotBytes; };
+    auto wait_flag = [&](std::atomic<unsigned char>& f) {
+        while (!f.load(std::memory_order_acquire)) {
+            if (failed.load(std::memory_order_relaxed)) return false;
+            std::this_thread::yield();
+        }
+        return true;
+    };
+    hipError_t herr = hipSuccess;
+    std::vector<std::thread> th;
     if (to_device) {
-        for (size_t w = 0; w < n_waves; ++w) {
-            if (w >= 2) FVAD_HIP(ctx, hipEventSynchronize(ring.ev[w & 1])); // this half's previous DMA is done
-            parallel_memcpy(blocks, w * kPinSlots, wave_n(w), half(w), true, ctx->tune.copy_threads);
-            for (size_t i = 0; i < wave_n(w); ++i) {
-                const CopySeg& b = blocks[w * kPinSlots + i];
-                FVAD_HIP(ctx, hipMemcpyAsync(b.dev, half(w) + i * kPinSlotBytes, b.bytes, hipMemcpyHostToDevice, st));
-            }
-            FVAD_HIP(ctx, hipEventRecord(ring.ev[w & 1], st));
-        }
-        // the ring may be reused by a later call: its last two halves must have left the host
-        for (size_t w = (n_waves >= 2 ? n_waves - 2 : 0); w < n_waves; ++w) FVAD_HIP(ctx, hipEventSynchronize(ring.ev[w & 1]));
-    } else {
-        for (size_t w = 0; w <= n_waves; ++w) {
-            if (w < n_waves) {
-                for (size_t i = 0; i < wave_n(w); ++i) {
-                    const CopySeg& b = blocks[w * kPinSlots + i];
-                    FVAD_HIP(ctx, hipMemcpyAsync(half(w) + i * kPinSlotBytes, b.dev, b.bytes, hipMemcpyDeviceToHost, st));
+        auto worker = [&](size_t t) {
+            hipSetDevice(ctx->device);
+            for (size_t i = t; i < nb; i += (size_t)T) {
+                if (i >= NS) { // the slot's previous DMA (block i - NS) must have left it
+                    if (!wait_flag(queued[i - NS])) return;
+                    if (hipEventSynchronize(ring.ev[i % NS]) != hipSuccess) { failed.store(true); return; }
                 }
-                FVAD_HIP(ctx, hipEventRecord(ring.ev[w & 1], st));
+                memcpy(slot(i), blocks[i].host, blocks[i].bytes);
+                copied[i].store(1, std::memory_order_release);
             }
-            if (w >= 1) { // drain the previous wave while this one's DMA runs
-                FVAD_HIP(ctx, hipEventSynchronize(ring.ev[(w - 1) & 1]));
-                parallel_memcpy(blocks, (w - 1) * kPinSlots, wave_n(w - 1), half(w - 1), false, ctx->tune.copy_threads);
-            }
+        };
+        for (int t = 0; t < T; ++t) th.emplace_back(worker, (size_t)t);
+        for (size_t i = 0; i < nb && !failed.load(); ++i) {
+            if (!wait_flag(copied[i])) break;
+            if ((herr = hipMemcpyAsync(blocks[i].dev, slot(i), blocks[i].bytes, hipMemcpyHostToDevice, st)) != hipSuccess ||
+                (herr = hipEventRecord(ring.ev[i % NS], st)) != hipSuccess) { failed.store(true); break; }
+            queued[i].store(1, std::memory_order_release);
         }
+        for (auto& x : th) x.join();
+        if (failed.load()) return set_err(ctx, FVAD_ERR_HIP, herr != hipSuccess ? hipGetErrorString(herr) : "staged host -> device copy failed");
+        // the ring may be reused by a later call: the last DMA (they run in order) must have left the host
+        FVAD_HIP(ctx, hipEventSynchronize(ring.ev[(nb - 1) % NS]));
+    } else {
+        auto worker = [&](size_t t) {
+            hipSetDevice(ctx->device);
+            for (size_t i = t; i < nb; i += (size_t)T) {
+                if (!wait_flag(queued[i])) return;
+                if (hipEventSynchronize(ring.ev[i % NS]) != hipSuccess) { failed.store(true); return; }
+                memcpy(blocks[i].host, slot(i), blocks[i].bytes);
+                copied[i].store(1, std::memory_order_release);
+            }
+        };
+        for (int t = 0; t < T; ++t) th.emplace_back(worker, (size_t)t);
+        for (size_t i = 0; i < nb && !failed.load(); ++i) {
+            if (i >= NS && !wait_flag(copied[i - NS])) break; // the slot has been emptied into user memory
+            if ((herr = hipMemcpyAsync(slot(i), blocks[i].dev, blocks[i].bytes, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+                (herr = hipEventRecord(ring.ev[i % NS], st)) != hipSuccess) { failed.store(true); break; }
+            queued[i].store(1, std::memory_order_release);
+        }
+        for (auto& x : th) x.join();
+        if (failed.load()) return set_err(ctx, FVAD_ERR_HIP, herr != hipSuccess ? hipGetErrorString(herr) : "staged device -> host copy failed");
     }
     return FVAD_OK;
+}
+
+// ---- lane groups of a pipelined call (host buffers): which sizes.
+// While the GPU runs group g the calling thread stages group g + 1 and a second thread drains group g - 1, so a call costs the
+// staging of its FIRST group + the kernels of all groups + the drain of its LAST group -- unless staging cannot keep up, and
+// less per chunk the larger a group's launch is.  Four equal groups (rounds 2-4) expose a quarter of the input and, with
+// denoised audio going back, a quarter of the output.  Measured on 128 streams x 64 s (tools/pcie_sweep.sh, fourteen schedules
+// x five format combinations, one MI355X box; ms per call, the equal split first):
+//   input staged faster than ~2 x the kernels' rate (PCM16: 850 chunks / ms against 400):  1,3,4,8     45.6 -> 41.1
+//   the same with denoised PCM16 going back (a small last group too):                      1,3,4,4,3,1 50.1 -> 45.8
+//   input at 1.3 x the kernels' rate (page-locked f32, DMA'd in place: 530 / ms):          2,2,4,4,4   48.4 -> 44.6
+//   input at the kernels' rate (pageable f32 through the ring: 410 / ms):                  4,4,4,4     50.0 (every other one slower:
+//                                      a group cannot start before it has arrived, and small launches run the spin kernels of
+//                                      the small-batch family, beside which the DMA itself slows down)
+// A model of staging / kernel / drain rates was tried first and picked worse schedules than the equal split (it prices neither the
+// launch sizes that fill the chip badly -- 5120 chunks cost what 8192 do -- nor the DMA beside the spin kernels): the table is
+// what was measured.  parts: sixteenths of the call's chunks per group.
+void plan_groups(double stage_rate, bool big_drain, std::vector<int>& parts)
+{
+    if (stage_rate >= 800.0) parts = big_drain ? std::vector<int>{1, 3, 4, 4, 3, 1} : std::vector<int>{1, 3, 4, 8};
+    else if (stage_rate >= 500.0) parts = big_drain ? std::vector<int>{2, 4, 4, 4, 2} : std::vector<int>{2, 2, 4, 4, 4};
+    else parts = {4, 4, 4, 4};
 }
 } // namespace
 
@@ -283,24 +326,66 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
     size_t h2d_bytes = 0;
     for (const CopySeg& c : h2d) h2d_bytes += c.bytes;
     int G = 1;
-    if (!opts.on_device && n_lanes >= 8 && h2d_bytes >= (64u << 20) && !ctx->tune.no_pipeline) G = 4;
+    std::vector<int> parts;
+    if (!opts.on_device && n_lanes >= 8 && h2d_bytes >= (64u << 20) && !ctx->tune.no_pipeline) {
+        // rates of this call's formats, chunks per ms (one chunk: 96 000 bytes as f32, 48 000 as PCM16): pageable memory through
+        // the page-locked ring ~41 GB/s in, ~37 GB/s out; page-locked user memory at the link's 51 GB/s (tools/drain_rate.hip)
+        bool in16 = false, in_pinned = false, out32 = false, out16 = false, out_pinned = false;
+        auto pinned = [](const void* p) {
+            hipPointerAttribute_t attr;
+            if (p && hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeHost) return true;
+            (void)hipGetLastError();
+            return false;
+        };
+        for (size_t l = 0; l < n_lanes; ++l) {
+            const fvad_lane& L = lanes[l];
+            if (!L.n_chunks) continue;
+            if (!L.pcm) in16 = true;
+            if (L.denoised) out32 = true; else if (L.denoised_i16) out16 = true;
+        }
+        for (size_t l = 0; l < n_lanes; ++l)
+            if (lanes[l].n_chunks) {
+                in_pinned = pinned(lanes[l].pcm ? (const void*)lanes[l].pcm : (const void*)lanes[l].pcm_i16);
+                out_pinned = pinned(lanes[l].denoised ? (const void*)lanes[l].denoised : (const void*)lanes[l].denoised_i16);
+                break;
+            }
+        const double in_gbps = in_pinned ? 51.0 : 41.0;
+        (void)out_pinned;
+        const double stage_rate = in_gbps * 1e6 / (in16 ? 48000.0 : 96000.0);
+        if (!ctx->tune.run_groups.empty()) { // context option run_groups: measurements, tests
+            int cur = 0;
+            for (char c : ctx->tune.run_groups + ",") {
+                if (c == ',') { parts.push_back(cur); cur = 0; } else cur = cur * 10 + (c - '0');
+            }
+        } else if (chunks_total >= 8192) plan_groups(stage_rate, out32 || out16, parts); // (a sixteenth of less is a launch of a few hundred chunks)
+        else parts = {4, 4, 4, 4};
+        G = (int)parts.size();
+    }
+    // group boundaries: contiguous lanes, chunk counts as planned (a group is at least one lane; a plan's group that no lane
+    // boundary falls into is merged with its neighbour)
+    std::vector<size_t> gb(1, 0);
+    if (G > 1) {
+        size_t acc = 0;
+        int g = 0, cum = parts[0];
+        for (size_t l = 0; l < n_lanes && g + 1 < G; ++l) {
+            acc += lanes[l].n_chunks;
+            while (g + 1 < G && acc * 16 >= chunks_total * (size_t)cum) {
+                if (gb.back() != l + 1 && l + 1 < n_lanes) gb.push_back(l + 1);
+                cum += parts[++g];
+            }
+        }
+    }
+    gb.push_back(n_lanes);
+    G = (int)gb.size() - 1;
     if (G > 1) {
         if (!ws.copy_in) FVAD_HIP(ctx, hipStreamCreateWithFlags(&ws.copy_in, hipStreamNonBlocking));
         if (!ws.copy_out) FVAD_HIP(ctx, hipStreamCreateWithFlags(&ws.copy_out, hipStreamNonBlocking));
+    }
+    hipStream_t s_in = G > 1 ? ws.copy_in : st, s_out = G > 1 ? ws.copy_out : st;
+    if (G > 1) {
         for (int g = 0; g < G; ++g) {
             if (!ws.grp_in[g]) FVAD_HIP(ctx, hipEventCreateWithFlags(&ws.grp_in[g], hipEventDisableTiming));
             if (!ws.grp_k[g]) FVAD_HIP(ctx, hipEventCreateWithFlags(&ws.grp_k[g], hipEventDisableTiming));
-        }
-    }
-    hipStream_t s_in = G > 1 ? ws.copy_in : st, s_out = G > 1 ? ws.copy_out : st;
-    // group boundaries: contiguous lanes, about equal chunk counts
-    std::vector<size_t> gb(G + 1, n_lanes);
-    gb[0] = 0;
-    {
-        size_t acc = 0, g = 1;
-        for (size_t l = 0; l < n_lanes && g < (size_t)G; ++l) {
-            acc += lanes[l].n_chunks;
-            if (acc * G >= chunks_total * g) gb[g++] = l + 1;
         }
     }
     // K4 job table for every lane (pointers are known up front; uploaded in front of the first K4 launch)
@@ -337,21 +422,57 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
 
     auto outputs_of = [&](size_t l0, size_t l1) -> int {
         std::vector<CopySeg> d2h;
+        // Band sums and RMS of consecutive lanes are contiguous in the workspace: they leave as TWO copies into the page-locked
+        // bounce buffer and are dealt to the lanes' arrays from there -- not two per lane (a small copy is a blit KERNEL, which
+        // finds no compute unit while a persistent GEMM or recurrence of a later group holds every register of the chip: 64 of
+        // them per group took up to 7 ms; tools/pcie_run.py with FVAD_TRACE_RUN=1)
+        size_t band_n = 0, rms_n = 0;
+        for (size_t l = l0; l < l1; ++l) { band_n += lanes[l].n_fft_frames; rms_n += lanes[l].n_chunks; }
+        const size_t rms_at = (band_n * sizeof(float) + 63) & ~(size_t)63;
+        const bool gathered = l1 > l0 && rms_at + rms_n * sizeof(float) <= kPinSmallBytes;
+        if (gathered && band_n + rms_n) {
+            Workspace::PinSmall& b = ctx->ws.small_out;
+            if (!b.base) {
+                if (!b.ev) FVAD_HIP(ctx, hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+                FVAD_HIP(ctx, hipHostMalloc((void**)&b.base, kPinSmallBytes, hipHostMallocDefault));
+            }
+            if (band_n) FVAD_HIP(ctx, hipMemcpyAsync(b.base, ws.band + band_off[l0], band_n * sizeof(float), hipMemcpyDeviceToHost, s_out));
+            if (rms_n) FVAD_HIP(ctx, hipMemcpyAsync(b.base + rms_at, d_rms + rms_off[l0], rms_n * sizeof(float), hipMemcpyDeviceToHost, s_out));
+            FVAD_HIP(ctx, hipStreamSynchronize(s_out));
+            const float* hb = reinterpret_cast<const float*>(b.base);
+            const float* hr = reinterpret_cast<const float*>(b.base + rms_at);
+            for (size_t l = l0; l < l1; ++l) {
+                fvad_lane& L = lanes[l];
+                if (L.n_fft_frames) memcpy(L.band_sum, hb + (band_off[l] - band_off[l0]), L.n_fft_frames * sizeof(float));
+                if (L.n_chunks) memcpy(L.chunk_rms, hr + (rms_off[l] - rms_off[l0]), L.n_chunks * sizeof(float));
+            }
+        }
         for (size_t l = l0; l < l1; ++l) {
             fvad_lane& L = lanes[l];
             if (L.n_fft_frames) {
-                d2h.push_back({L.band_sum, ws.band + band_off[l], L.n_fft_frames * sizeof(float)});
+                if (!gathered) d2h.push_back({L.band_sum, ws.band + band_off[l], L.n_fft_frames * sizeof(float)});
                 if (L.fft_bins) d2h.push_back({L.fft_bins, ws.bins + band_off[l] * NB, L.n_fft_frames * NB * sizeof(float)});
             }
             if (L.n_chunks) {
-                d2h.push_back({L.chunk_rms, d_rms + rms_off[l], L.n_chunks * sizeof(float)});
+                if (!gathered) d2h.push_back({L.chunk_rms, d_rms + rms_off[l], L.n_chunks * sizeof(float)});
                 if (L.denoised && !opts.on_device) d2h.push_back({L.denoised, jobs[l].d_den, L.n_chunks * kChunk48 * sizeof(float)});
                 if (L.denoised_i16 && !opts.on_device) d2h.push_back({L.denoised_i16, jobs[l].d_den16, L.n_chunks * kChunk48 * sizeof(int16_t)});
             }
         }
+        if (d2h.empty()) return FVAD_OK;
         return staged_copy(ctx, d2h, false, s_out);
     };
 
+    static const bool trace_run = getenv("FVAD_TRACE_RUN") != nullptr; // timeline of the call on stderr (tools/pcie_run.py)
+    const auto t_start = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what, int g) {
+        if (trace_run) fprintf(stderr, "[run] %8.3f ms  %s %d\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), what, g);
+    };
+    if (trace_run && G > 1) {
+        fprintf(stderr, "[run] groups:");
+        for (int g = 0; g < G; ++g) { size_t n = 0; for (size_t l = gb[g]; l < gb[g + 1]; ++l) n += lanes[l].n_chunks; fprintf(stderr, " %zu", n); }
+        fprintf(stderr, " chunks\n");
+    }
     // a second host thread drains group g's outputs (its own pinned ring and stream) while this one stages
     // group g+1's input: both are memcpy-bound host work
     std::atomic<int> groups_recorded{0};
@@ -367,7 +488,9 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
                     std::this_thread::yield();
                 }
                 if (hipStreamWaitEvent(s_out, ws.grp_k[g], 0) != hipSuccess) { rc_out = FVAD_ERR_HIP; return; }
+                if (trace_run) { hipEventSynchronize(ws.grp_k[g]); stamp("kernels done, group", g); }
                 if ((rc_out = outputs_of(gb[g], gb[g + 1]))) return;
+                stamp("drained group", g);
             }
         });
     struct Joiner { std::thread& t; std::atomic<bool>& a; ~Joiner() { if (t.joinable()) { a.store(true); t.join(); } } } joiner{out_thread, abort_out};
@@ -384,6 +507,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
             }
         }
         if ((rc = staged_copy(ctx, in_g, true, s_in))) return rc;
+        stamp("staged group", g);
         if (G > 1) {
             FVAD_HIP(ctx, hipEventRecord(ws.grp_in[g], s_in));
             FVAD_HIP(ctx, hipStreamWaitEvent(st, ws.grp_in[g], 0));
@@ -427,6 +551,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
             FVAD_HIP(ctx, hipEventRecord(ws.grp_k[g], st));
             groups_recorded.store(g + 1, std::memory_order_release);
         }
+        stamp("enqueued group", g);
     }
     if (G > 1) {
         out_thread.join(); // all groups recorded: the worker runs to completion

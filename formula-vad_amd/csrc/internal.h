@@ -120,8 +120,8 @@ struct Workspace {
     unsigned long long* ws_fallbacks = nullptr; // device counter: network passes in which gru_ws gave up (gru_lat redid the layers)
     VadFftJob* fft_jobs = nullptr; VadFftJob* h_fft_jobs = nullptr; size_t fft_jobs_cap = 0; // host table: two slots of fft_jobs_cap
     hipEvent_t jobs_ev[2] = {nullptr, nullptr}; int jobs_slot = 0; // slot's upload has left the host (no_wait calls)
-    // pinned staging ring for large host <-> device transfers (two halves of kPinSlots slots)
-    struct PinRing { char* base = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
+    // pinned staging ring for large host <-> device transfers: 32 slots of 8 MB, an event per slot (its DMA is done)
+    struct PinRing { char* base = nullptr; hipEvent_t ev[32] = {}; };
     PinRing ring_in, ring_out; // host->device staging / device->host draining (used by different threads)
     // small transfers (a live push: 96 KB in, a few hundred bytes out): one page-locked bounce buffer per direction, so that
     // the copies are truly asynchronous (a copy to or from pageable memory blocks the calling thread)
@@ -166,6 +166,7 @@ struct Tuning {
     int h3_waves = 0;            // 0 / 8 / 12
     long max_chunks = 49152;     // chunks per launch when the caller passes 0
     bool no_pipeline = false;    // host-buffer path: single lane group
+    std::string run_groups;      // host-buffer path: the lane groups' sizes in sixteenths of the call ("4,4,4,4"); empty = planned
     int gru_lat_tiles = 0;       // row tiles per workgroup of gru_lat (1, 2, 3: the same bits); 0 = by launch size (the cost model)
     bool k4_plain_loads = false; // vadfft1024_band_kernel: stage frames with plain 8-byte loads even when they are 16-byte aligned (the path
                                  // an unaligned job takes; same arithmetic, same bits: tests)

@@ -730,6 +730,21 @@ def test_engine_host_buffer_pipelining_is_invisible(fv, gpu_ctx, pkg):
                 assert np.abs(x["denoised"] - y["denoised"]).max() <= 2e-5 * np.abs(y["denoised"]).max()
                 assert_rel(x["band_sum"], y["band_sum"], 1e-5, what="band sums across kernel families")
     assert np.all(np.isfinite(a[0]["denoised"])) and np.abs(a[0]["denoised"]).max() > 0
+    # ... and whatever sizes the lane groups have (the engine plans them from the formats' rates; context option run_groups sets
+    # them in sixteenths of the call): same bits in one kernel family, ragged lanes and merged groups included
+    with gpu_ctx.options(reproducible="1"):
+        with gpu_ctx.options(no_pipeline="1"):
+            ref = gpu_ctx.engine_run(lanes, want_denoised=True)
+        for sched in ("1,3,4,8", "1,3,4,4,3,1", "2,2,4,4,4", "8,8", "1,1,1,1,1,1,10"):
+            with gpu_ctx.options(run_groups=sched):
+                c = gpu_ctx.engine_run(lanes, want_denoised=True)
+            for x, y in zip(c, ref):
+                assert np.array_equal(x["denoised"], y["denoised"]) and np.array_equal(x["band_sum"], y["band_sum"]), sched
+                assert np.array_equal(x["chunk_rms"], y["chunk_rms"]), sched
+    for bad in ("4,4,4", "16,1", "0,16", "4;4;4;4", "1,1,1,1,1,1,1,9", "x"):
+        with pytest.raises(Exception):
+            gpu_ctx.set_option("run_groups", bad)
+    gpu_ctx.set_option("run_groups", "")
 
 
 def test_engine_accepts_page_locked_buffers(fv, gpu_ctx, pkg):

@@ -1,6 +1,8 @@
 """bench.py's `extra.pcie_inclusive_*` on their own: fvad_engine_run on 128 streams x 64 s of host audio (pageable f32, pageable
 PCM16, page-locked f32; with and without the denoised audio copied back), best of 3.  Context options as name=value arguments
-(copy_threads=16, no_pipeline=1, ...): python tools/pcie_run.py [option=value ...]"""
+(copy_threads=16, no_pipeline=1, run_groups=1,3,4,8 ...): python tools/pcie_run.py [option=value ...]
+FVAD_TRACE_RUN=1 in the environment makes the library print a timeline of every call on stderr (when each lane group is
+staged, enqueued, finished, drained)."""
 import ctypes as C, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

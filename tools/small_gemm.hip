@@ -257,6 +257,9 @@ int main()
         {"fc4 4800x600->161", 4800, 600, 161},    {"gi1f 64x176->1200", 64, 176, 1200},   {"fc3 64x600->600", 64, 600, 600},
         {"fc4 64x600->161", 64, 600, 161},        {"gi1f 1088x176->1200", 1088, 176, 1200}, {"fc3 1024x600->600", 1024, 600, 600},
         {"fc4 1024x600->161", 1024, 600, 161},    {"fc3 16384x600->600", 16384, 600, 600},
+        // the 82-chunk batch's REAL rows: 4100 = 64 full panels + 4 rows (65 panels as launched; 64 if the remainder went elsewhere)
+        {"fc2 4160x400->600", 4160, 400, 600},    {"fc2 4096x400->600", 4096, 400, 600},  {"fc3 4160x600->600", 4160, 600, 600},
+        {"fc3 4096x600->600", 4096, 600, 600},    {"fc4 4160x600->161", 4160, 600, 161},  {"fc4 4096x600->161", 4096, 600, 161},
     };
     for (const Shape& sh : shapes) {
         const int lda = 640 > sh.K ? 640 : sh.K, ldc = 1280;
@@ -284,7 +287,7 @@ int main()
 #define RUN2(NT, KS, S, PF) us = run2<NT, KS, S, PF>(sh, dA, lda, W, dB, dC, ldc, &got); if (us >= 0) report("v2 NT" #NT " KS" #KS " PF" #PF, us, true);
 #define ALLS(NT, KS, PF) RUN2(NT, KS, 11, PF) RUN2(NT, KS, 25, PF) RUN2(NT, KS, 38, PF)
         ALLS(4, 2, 2) ALLS(4, 2, 3) ALLS(4, 2, 4) ALLS(4, 1, 3) ALLS(4, 1, 4) ALLS(4, 1, 6) ALLS(3, 2, 3) ALLS(3, 1, 4) ALLS(2, 2, 3) ALLS(2, 2, 4) ALLS(2, 1, 6) ALLS(2, 4, 2)
-        ALLS(1, 4, 2) ALLS(1, 2, 4) ALLS(5, 2, 3) ALLS(6, 2, 2)
+        ALLS(1, 4, 2) ALLS(1, 2, 4) ALLS(5, 2, 3) ALLS(6, 2, 2) ALLS(5, 1, 4) ALLS(5, 1, 3) ALLS(3, 1, 6) ALLS(6, 1, 3) ALLS(8, 1, 2)
         CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
     }
     return 0;
