@@ -732,7 +732,11 @@ static int enqueue_device_impl(fvad_ctx* ctx, const float* d_pcm, const int16_t*
     if (opts.use_graph && !ctx->timing) {
         const long total = (long)(n_lanes * n_chunks);
         const long maxc = planned_max_chunks(ctx, total, opts.max_chunks_per_launch);
-        if ((rc = ensure_workspace(ctx, std::min(total, maxc), kRowsPerChunk, kWarmupRows, total % std::min(total, maxc)))) return rc; // no allocation while capturing
+        {
+            std::vector<long> plan;
+            plan_launches(ctx, total, opts.max_chunks_per_launch, plan);
+            if ((rc = ensure_workspace_plan(ctx, plan))) return rc; // no allocation while capturing
+        }
         if ((rc = ensure_gru_ws(ctx))) return rc;
         Workspace::GraphCache& gc = ws.graph;
         const void* pcm_key = d_pcm ? (const void*)d_pcm : (const void*)d_pcm16;

@@ -235,7 +235,9 @@ int upload_model(fvad_ctx* ctx);                                              //
 int dev_alloc(fvad_ctx* ctx, float** p, size_t n_floats, bool zero);          // engine.cpp
 int grow(fvad_ctx* ctx, float** p, size_t* cap, size_t need);                 // engine.cpp
 void free_workspace_nn(Workspace& ws);                                        // nn_dispatch.cpp
-long planned_max_chunks(const fvad_ctx* ctx, long total, long max_chunks);    // nn_dispatch.cpp: chunks per launch of a call
+long planned_max_chunks(const fvad_ctx* ctx, long total, long max_chunks);    // nn_dispatch.cpp: the largest launch of a call's plan
+void plan_launches(const fvad_ctx* ctx, long total, long max_chunks, std::vector<long>& plan); // the launches of a call, in order
+int ensure_workspace_plan(fvad_ctx* ctx, const std::vector<long>& plan);       // the workspace for every launch of a plan
 long padded_batch(const fvad_ctx* ctx, long n, int T, int skip);              // nn_dispatch.cpp: sequences a launch of n is padded to
 // FVAD_NN_MATH_F32 / FVAD_NN_MATH_F16X3: what run_nn uses on this context with the loaded model, at every batch size
 int nn_math_effective(const fvad_ctx* ctx);

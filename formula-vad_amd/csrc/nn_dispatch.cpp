@@ -95,6 +95,19 @@ int ensure_workspace(fvad_ctx* ctx, long n_chunks, int T, int skip, long n_last)
     return FVAD_OK;
 }
 
+// the workspace for every launch of a plan (plan_launches): the largest launch, and the other launch whose padding is the widest
+int ensure_workspace_plan(fvad_ctx* ctx, const std::vector<long>& plan)
+{
+    long largest = 0, other = 0, other_pad = 0;
+    for (long n : plan) largest = std::max(largest, n);
+    for (long n : plan) {
+        if (n == largest) continue;
+        const long pad = padded_batch(ctx, n, kRowsPerChunk, kWarmupRows);
+        if (pad > other_pad) { other_pad = pad; other = n; }
+    }
+    return ensure_workspace(ctx, largest, kRowsPerChunk, kWarmupRows, other);
+}
+
 // Large batches: the LDS-DMA kernels with 192 / 128 / 64 sequences per workgroup; small batches keep
 // one wavefront (16 sequences) per workgroup so that more CUs take part.
 struct GruChoice {
@@ -717,17 +730,81 @@ int calibrate_ws2_waits(fvad_ctx* ctx)
 // recurrence, which keeps 128-210 of the 256 CUs busy (2048 chunks: 7.4 ms = 13.8 M frames/s); two or three equal launches of
 // at most 1536 chunks stay on the pipelined kernels (2 x 2.77 ms = 18.5 M frames/s).  Measured crossover (bench.py's batch
 // curve): 4.86 ms + 1.26 us per chunk against 2.69 us per chunk.
-long planned_max_chunks(const fvad_ctx* ctx, long total, long max_chunks)
+// ... and above that the launch sizes that fill the chip are few: 4096 chunks are one round of gru_lat's 256 workgroups, 8192 of
+// gru_lat2's, 12288 of gru_lat3's, 16384 of gru_rec3<4>'s, 32768 of <8>'s, 49152 of <12>'s -- a launch just above one of them pays
+// a whole further round of the recurrence (tools/batch_sizes.py, ms per call: 4096 chunks 9.98, 5120 14.9, 8192 18.6, 9216 23.3,
+// 12288 26.8, 13312 30.4, 16384 34.1, 20480 50.8, 32768 65.8).  A call whose size the caller leaves to the engine is therefore cut
+// into launches of such a size and a remainder, when the measured curve says that pays by more than 4 %: 5120 = 4096 + 1024
+// (12.8 ms for 14.9), 9216 = 8192 + 1024, 20480 = 16384 + 4096 (44.1 for 50.8).
+static double launch_ms(double n) // one launch of n chunks, device-resident, default kernel selection (one MI355X box)
 {
-    if (max_chunks > 0) return max_chunks;
-    max_chunks = ctx->tune.max_chunks;
-    const Tuning& tn = ctx->tune;
-    if (!ctx->dm.generic && nn_math_effective(ctx) == FVAD_NN_MATH_F32 && !tn.reproducible && tn.gru_kernel.empty() && tn.gemm_kernel.empty() &&
-        total > 1536 && total <= 3400 && max_chunks >= total) {
-        const long k = (total + 1535) / 1536;
-        max_chunks = ((total + k - 1) / k + 15) / 16 * 16;
+    struct Seg { double n0, t0, n1, t1; };
+    static const Seg segs[] = {{0, 0.30, 1536, 3.97},          // pipelined weight-stationary recurrence
+                               {1536, 6.7, 4096, 9.98},        // gru_lat, 97..256 workgroups: the recurrence costs what 4096 chunks cost
+                               {4096, 13.9, 8192, 18.59},      // gru_lat2
+                               {8192, 22.2, 12288, 26.77},     // gru_lat3
+                               {12288, 29.1, 16384, 34.1},     // gru_rec3<4>
+                               {16384, 45.9, 32768, 65.78},    // gru_rec3<8>
+                               {32768, 77.1, 49152, 97.3}};    // gru_rec3<12> (its lower end is an estimate)
+    for (const Seg& g : segs)
+        if (n <= g.n1) return g.t0 + (g.t1 - g.t0) * (n - g.n0) / (g.n1 - g.n0);
+    return 97.3 * n / 49152.0;
+}
+// cost of `total` chunks under plan_launches' rules, and the plan itself (sizes in launch order, the remainder last)
+static double plan_cost(long total, long limit, std::vector<long>* plan)
+{
+    if (total <= 0) return 0.0;
+    if (total <= 1536 && total <= limit) { if (plan) plan->push_back(total); return launch_ms((double)total); }
+    if (total <= 3400 && limit >= 1536) { // two or three equal launches on the pipelined kernels (the crossover above)
+        const long k = (total + 1535) / 1536, each = ((total + k - 1) / k + 15) / 16 * 16;
+        double c = 0;
+        for (long left = total; left > 0; left -= each) { const long n = std::min(left, each); c += launch_ms((double)n); if (plan) plan->push_back(n); }
+        return c;
     }
-    return max_chunks;
+    static const long sizes[] = {49152, 32768, 16384, 12288, 8192, 4096};
+    double best = total <= limit ? launch_ms((double)total) : 1e30;
+    long best_size = total <= limit ? total : 0;
+    for (long sz : sizes) {
+        if (sz > limit || sz >= total) continue;
+        const double c = (double)(total / sz) * launch_ms((double)sz) + plan_cost(total % sz, limit, nullptr);
+        if (c < (best_size == total ? 0.96 * best : best)) { best = c; best_size = sz; }
+    }
+    if (best_size == 0) { // the caller's limit is below every size that fills the chip: launches of the limit
+        best_size = limit;
+        best = (double)(total / limit) * launch_ms((double)limit) + plan_cost(total % limit, limit, nullptr);
+    }
+    if (plan) {
+        if (best_size == total) plan->push_back(total);
+        else {
+            for (long i = 0; i < total / best_size; ++i) plan->push_back(best_size);
+            plan_cost(total % best_size, limit, plan);
+        }
+    }
+    return best;
+}
+
+// the launches of a call of `total` chunks: sizes in order.  max_chunks > 0: the caller's (or a test's) limit -- launches of that
+// size and a remainder, as ever; otherwise the plan above (default f32 kernel selection only: `reproducible`, forced kernels,
+// the emulations and run-time-sized models keep launches of the context's max_chunks)
+void plan_launches(const fvad_ctx* ctx, long total, long max_chunks, std::vector<long>& plan)
+{
+    plan.clear();
+    if (total <= 0) return;
+    const Tuning& tn = ctx->tune;
+    const bool planned = max_chunks <= 0 && !ctx->dm.generic && nn_math_effective(ctx) == FVAD_NN_MATH_F32 && !tn.reproducible &&
+                         tn.gru_kernel.empty() && tn.gemm_kernel.empty();
+    const long limit = max_chunks > 0 ? max_chunks : tn.max_chunks;
+    if (planned) { plan_cost(total, limit, &plan); return; }
+    for (long left = total; left > 0; left -= limit) plan.push_back(std::min(left, limit));
+}
+
+long planned_max_chunks(const fvad_ctx* ctx, long total, long max_chunks) // the largest launch of that plan
+{
+    std::vector<long> plan;
+    plan_launches(ctx, total, max_chunks, plan);
+    long m = 0;
+    for (long n : plan) m = std::max(m, n);
+    return m > 0 ? m : (max_chunks > 0 ? max_chunks : ctx->tune.max_chunks);
 }
 
 // K1 -> NSNet2 -> K3 over every chunk of every job, in launches of <= max_chunks chunks.
@@ -742,15 +819,18 @@ int run_chunks(fvad_ctx* ctx, std::vector<LaneJob>& jobs, long max_chunks, Chunk
     long total = 0;
     for (auto& j : jobs) total += (long)j.n_chunks;
     if (total == 0) return FVAD_OK;
-    max_chunks = planned_max_chunks(ctx, total, max_chunks);
-    int rc = ensure_workspace(ctx, std::min(total, max_chunks), kRowsPerChunk, kWarmupRows, total % std::min(total, max_chunks));
+    std::vector<long> plan;
+    plan_launches(ctx, total, max_chunks, plan);
+    int rc = ensure_workspace_plan(ctx, plan);
     if (rc) return rc;
     Workspace& ws = ctx->ws;
-    const long cap = std::min<long>(max_chunks, ws.cap_chunks);
+    size_t launch_i = 0;
 
     size_t job = 0, chunk_in_job = 0;
     while (job < jobs.size()) {
         // fill one launch, lane-contiguous
+        const long cap = std::min<long>(launch_i < plan.size() ? plan[launch_i] : plan.back(), ws.cap_chunks);
+        ++launch_i;
         long n = 0;
         std::vector<size_t> touched;
         struct Tap { size_t job, chunk0, count; long batch0; };
