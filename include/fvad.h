@@ -305,8 +305,10 @@ const char *fvad_ctx_last_nn_path(const fvad_ctx *ctx);
  * computes layer 2's input projection itself, and for 65..96 sequences layer 1's too, in the accumulation order of the GEMM
  * that otherwise runs in front: one set of bits for the whole range);
  * up to 2047 the narrow-block GEMMs with a weight-stationary or the low-latency recurrence; from 2048 the persistent GEMM
- * with the low-latency or the multi-wavefront recurrence (by a cost model over the CU count).  A call of 1537..3400
- * chunks whose launch size is left to the engine (max_chunks_per_launch = 0) runs as two or three equal launches.  Every selection runs f32 operands and f32 accumulation; they differ in
+ * with the low-latency or the multi-wavefront recurrence (by a cost model over the CU count).  A call whose launch size
+ * is left to the engine (max_chunks_per_launch = 0) is cut into launches that fill the chip: 1537..3400 chunks run as two or
+ * three equal launches, larger calls as launches of 4096 / 8192 / 12288 / 16384 / 32768 / 49152 chunks and a remainder where
+ * the measured curve says that pays (5120 = 4096 + 1024).  Every selection runs f32 operands and f32 accumulation; they differ in
  * accumulation order and agree to ~1e-6 in the gains, not bit for bit.  The option "reproducible" = "1" makes every
  * launch use one selection (persistent GEMM + multi-wavefront recurrence; small launches are padded to 128 sequences
  * and lose their low-latency kernels), so that a stream pushed in any pieces, split over any number of launches or
@@ -314,7 +316,8 @@ const char *fvad_ctx_last_nn_path(const fvad_ctx *ctx);
  *
  * Testing / tuning aids, none needed in production: name = "reproducible" | "nn_math" ("f32" | "f16x3" | "bf16x3": overrides
  * fvad_ctx_set_nn_math) | "gru_kernel" ("v3w12" | "v3w8" | "v3w4" | "v4w8" | "v5w0" | "v6w0") | "gemm_kernel" ("v1" |
- * "v3" | "v3nofold") | "h3_waves" ("8" | "12") | "max_chunks" | "copy_threads" | "no_pipeline" | "trace_kernels" |
+ * "v3" | "v3nofold") | "h3_waves" ("8" | "12") | "max_chunks" | "copy_threads" | "no_pipeline" | "run_groups" ("1,3,4,8": the lane groups of
+ * fvad_engine_run's host-buffer pipeline in sixteenths of the call, at most seven, instead of the planned ones) | "trace_kernels" |
  * "ws_spin_ticks" | "ws2_variant" (diagnostic bit mask; the timing-only bits exist in the diagnostics build alone) |
  * "ws2_waits" | "ws2_calibrate" (below) | "k4_plain_loads" (the band FFT's staging path of unaligned frames) | "gru_lat_tiles" ("1" | "2" | "3": row tiles per
  * workgroup of the low-latency recurrence instead of the cost model's choice; same bits); value NULL or ""
