@@ -431,6 +431,17 @@ int fvad_ctx_nn_math_effective(const fvad_ctx* ctx)
 
 const char* fvad_ctx_last_nn_path(const fvad_ctx* ctx) { return ctx ? ctx->last_nn_path.c_str() : ""; }
 
+// diagnostics for the tests, not part of the ABI in include/fvad.h: the launches a call of `total` chunks is cut into
+// (plan_launches, nn_dispatch.cpp) under the context's current options; returns their number (at most `cap` are written)
+int fvad_debug_plan_launches(fvad_ctx* ctx, long total, long max_chunks, long* out, int cap)
+{
+    if (!ctx || (cap > 0 && !out) || total < 0) return FVAD_ERR_INVALID_ARGUMENT;
+    std::vector<long> plan;
+    plan_launches(ctx, total, max_chunks, plan);
+    for (int i = 0; i < cap && i < (int)plan.size(); ++i) out[i] = plan[(size_t)i];
+    return (int)plan.size();
+}
+
 // diagnostics for tools/ws2_trace.py, not part of the ABI in include/fvad.h: the step trace gru_ws2k_kernel leaves behind
 // the polled words when the context option ws2_variant has bit 64 set (2 x 1000 shader-clock stamps)
 int fvad_debug_ws_trace(fvad_ctx* ctx, uint32_t* out, int n_words)

@@ -113,9 +113,12 @@ int staged_copy(fvad_ctx* ctx, const std::vector<CopySeg>& segs, bool to_device,
     std::atomic<bool> failed{false};
     auto slot = [&](size_t i) { return ring.base + (i % NS) * kPinSlotBytes; };
     auto wait_flag = [&](std::atomic<unsigned char>& f) {
-        while (!f.load(std::memory_order_acquire)) {
+        // (a wait is normally a fraction of a block's copy; on a host whose cores are busy elsewhere -- the GPU boxes are shared --
+        // a yield loop only takes time slices from the threads it waits for, so it backs off to short sleeps)
+        for (unsigned spins = 0; !f.load(std::memory_order_acquire); ++spins) {
             if (failed.load(std::memory_order_relaxed)) return false;
-            std::this_thread::yield();
+            if (spins < 256) std::this_thread::yield();
+            else std::this_thread::sleep_for(std::chrono::microseconds(30));
         }
         return true;
     };
@@ -488,7 +491,12 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
                     std::this_thread::yield();
                 }
                 if (hipStreamWaitEvent(s_out, ws.grp_k[g], 0) != hipSuccess) { rc_out = FVAD_ERR_HIP; return; }
-                if (trace_run) { hipEventSynchronize(ws.grp_k[g]); stamp("kernels done, group", g); }
+                // The host waits for the group's kernels in an EVENT wait.  A stream wait of that length (hipStreamSynchronize on
+                // s_out, which the copies below end in) can stall the calling thread's own enqueues for as long as it lasts: the
+                // staging of group g + 1 then starts only when group g is drained and the call is serialised -- 76 ms instead of
+                // 50, observed in bench.py (after its 16-thread CPU leg, never in a fresh process; FVAD_TRACE_RUN=1 shows it)
+                if (hipEventSynchronize(ws.grp_k[g]) != hipSuccess) { rc_out = FVAD_ERR_HIP; return; }
+                stamp("kernels done, group", g);
                 if ((rc_out = outputs_of(gb[g], gb[g + 1]))) return;
                 stamp("drained group", g);
             }

@@ -747,6 +747,38 @@ def test_engine_host_buffer_pipelining_is_invisible(fv, gpu_ctx, pkg):
     gpu_ctx.set_option("run_groups", "")
 
 
+def test_launch_plans(fv, gpu_ctx):
+    # a call whose launch size is left to the engine is cut into launches that fill the chip and a remainder (plan_launches):
+    # the plans behind docs/LAB_NOTES.md's table, and the invariants of every plan
+    import ctypes as C
+    L = fv.lib()
+    L.fvad_debug_plan_launches.restype = C.c_int
+    L.fvad_debug_plan_launches.argtypes = [C.c_void_p, C.c_long, C.c_long, C.POINTER(C.c_long), C.c_int]
+
+    def plan(total, max_chunks=0):
+        out = (C.c_long * 64)()
+        n = L.fvad_debug_plan_launches(gpu_ctx.h, total, max_chunks, out, 64)
+        assert 0 <= n <= 64
+        return [int(out[i]) for i in range(n)]
+
+    assert plan(82) == [82] and plan(1536) == [1536] and plan(4096) == [4096] and plan(16384) == [16384] and plan(49152) == [49152]
+    assert plan(2048) == [1024, 1024] and plan(3072) == [1536, 1536]
+    assert plan(5120) == [4096, 1024] and plan(9216) == [8192, 1024] and plan(20480) == [16384, 4096]
+    assert plan(7168) == [7168] and plan(12288) == [12288]                 # near the top of a tooth: left alone
+    assert plan(49152 * 3 + 100) == [49152] * 3 + [100]
+    rng = np.random.default_rng(9)
+    for total in [int(x) for x in rng.integers(1, 400000, 200)] + [1, 1537, 3400, 3401, 4097, 49153]:
+        p = plan(total)
+        assert sum(p) == total and all(0 < n <= 49152 for n in p), (total, p)
+        assert len(p) <= total // 49152 + 8, (total, p)
+    # the caller's limit, `reproducible` and forced kernels keep uniform launches
+    assert plan(5120, 2000) == [2000, 2000, 1120]
+    with gpu_ctx.options(reproducible="1"):
+        assert plan(5120) == [5120] and plan(100000) == [49152, 49152, 1696]
+    with gpu_ctx.options(max_chunks="3000"):
+        assert plan(7000) == [3000, 3000, 1000]
+
+
 def test_engine_accepts_page_locked_buffers(fv, gpu_ctx, pkg):
     # buffers from fvad_host_alloc are DMA'd in place instead of being staged: same results
     pcm, _ = pkg.synth.make_stream(30.0, seed=5)
