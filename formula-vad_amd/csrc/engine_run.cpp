@@ -136,7 +136,13 @@ int staged_copy(fvad_ctx* ctx, const std::vector<CopySeg>& segs, bool to_device,
                 copied[i].store(1, std::memory_order_release);
             }
         };
-        for (int t = 0; t < T; ++t) th.emplace_back(worker, (size_t)t);
+        try {
+            for (int t = 0; t < T; ++t) th.emplace_back(worker, (size_t)t);
+        } catch (...) { // no thread to be had: the ones that started leave at their next wait
+            failed.store(true);
+            for (auto& x : th) x.join();
+            return set_err(ctx, FVAD_ERR_HIP, "staged copy: cannot start a copy thread");
+        }
         for (size_t i = 0; i < nb && !failed.load(); ++i) {
             if (!wait_flag(copied[i])) break;
             if ((herr = hipMemcpyAsync(blocks[i].dev, slot(i), blocks[i].bytes, hipMemcpyHostToDevice, st)) != hipSuccess ||
@@ -157,7 +163,13 @@ int staged_copy(fvad_ctx* ctx, const std::vector<CopySeg>& segs, bool to_device,
                 copied[i].store(1, std::memory_order_release);
             }
         };
-        for (int t = 0; t < T; ++t) th.emplace_back(worker, (size_t)t);
+        try {
+            for (int t = 0; t < T; ++t) th.emplace_back(worker, (size_t)t);
+        } catch (...) { // no thread to be had: the ones that started leave at their next wait
+            failed.store(true);
+            for (auto& x : th) x.join();
+            return set_err(ctx, FVAD_ERR_HIP, "staged copy: cannot start a copy thread");
+        }
         for (size_t i = 0; i < nb && !failed.load(); ++i) {
             if (i >= NS && !wait_flag(copied[i - NS])) break; // the slot has been emptied into user memory
             if ((herr = hipMemcpyAsync(slot(i), blocks[i].dev, blocks[i].bytes, hipMemcpyDeviceToHost, st)) != hipSuccess ||
