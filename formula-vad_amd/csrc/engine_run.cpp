@@ -70,7 +70,10 @@ int staged_copy(fvad_ctx* ctx, const std::vector<CopySeg>& segs, bool to_device,
             FVAD_HIP(ctx, hipEventRecord(b.ev, st));
             return FVAD_OK;
         }
-        FVAD_HIP(ctx, hipStreamSynchronize(st));
+        // (an event wait, not a stream wait: a stream wait that lasts as long as the kernels in front of these copies has been
+        // seen to stall other threads' enqueues for as long -- fvad_engine_run's drain thread, below)
+        FVAD_HIP(ctx, hipEventRecord(b.ev, st));
+        FVAD_HIP(ctx, hipEventSynchronize(b.ev));
         off = 0;
         for (const CopySeg& s : segs) {
             if (!s.bytes) continue;
@@ -453,7 +456,8 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
             }
             if (band_n) FVAD_HIP(ctx, hipMemcpyAsync(b.base, ws.band + band_off[l0], band_n * sizeof(float), hipMemcpyDeviceToHost, s_out));
             if (rms_n) FVAD_HIP(ctx, hipMemcpyAsync(b.base + rms_at, d_rms + rms_off[l0], rms_n * sizeof(float), hipMemcpyDeviceToHost, s_out));
-            FVAD_HIP(ctx, hipStreamSynchronize(s_out));
+            FVAD_HIP(ctx, hipEventRecord(b.ev, s_out));
+            FVAD_HIP(ctx, hipEventSynchronize(b.ev));
             const float* hb = reinterpret_cast<const float*>(b.base);
             const float* hr = reinterpret_cast<const float*>(b.base + rms_at);
             for (size_t l = l0; l < l1; ++l) {
