@@ -73,6 +73,8 @@ def parse():
                          "cfg4: BASELINE config 4, 21 Miami-race-sized streams dealt round-robin to the ranks")
     ap.add_argument("--cfg4-streams", type=int, default=21)
     ap.add_argument("--cfg4-seconds", type=int, default=7200, help="seconds per stream (a multiple of 600)")
+    ap.add_argument("--cfg4-one-call", action="store_true",
+                    help="config 4: one device-resident call per step and the host VAD behind it (rounds 1-4) instead of time slices with the host VAD beside the GPU")
     return ap.parse_args()
 
 
@@ -253,15 +255,27 @@ def run_cfg4(args, pkg, fv, ctx, torch, dist, rank, world, cdev, steps=None, war
         collective = f"torch.distributed all_gather({args.dist_backend})"
     timing = {}
 
+    # The rank's streams as time slices, the host VAD of slice k beside the GPU's slice k + 1 (shard.run_sliced_with_vad): a slice
+    # is one launch of at most 49152 chunks, and at least four slices even for two or three streams (their VAD is 36 ms per
+    # two-hour stream on one core: a third of a rank's step if it ran behind the kernels)
+    H16 = pkg.shard.ALIGN_CHUNKS
+    slice_chunks = max(H16, min((49152 // max(n_l, 1) - H16) // H16 * H16, -(-n_chunks // (4 * H16)) * H16))
+
     def step():
         t0 = time.perf_counter()
-        if n_l:
+        all_segs = []
+        if n_l and not args.cfg4_one_call:
+            all_segs, info = pkg.shard.run_sliced_with_vad(ctx, d_pcm, n_l, n_samp, n_chunks, vb, slice_chunks=slice_chunks, n_threads=vad_threads)
+            t1 = t0 + info["gpu_s"]
+        elif n_l:
             fv.check(L.fvad_engine_enqueue_device(ctx.h, d_pcm, n_l, n_samp, n_samp, None, d_band, d_rms, None), "cfg4 enqueue", ctx.h)
             fv.check(L.fvad_ctx_copy_to_host(ctx.h, h_band.ctypes.data, d_band, h_band.nbytes), "cfg4 band", ctx.h)
             fv.check(L.fvad_ctx_copy_to_host(ctx.h, h_rms.ctypes.data, d_rms, h_rms.nbytes), "cfg4 rms", ctx.h)
             ctx.synchronize()
-        t1 = time.perf_counter()
-        all_segs = vb.run(h_band, h_rms, n_threads=vad_threads) if n_l else []
+            t1 = time.perf_counter()
+            all_segs = vb.run(h_band, h_rms, n_threads=vad_threads)
+        else:
+            t1 = time.perf_counter()
         local = []
         n_seg = 0
         for segs, sid in zip(all_segs, mine):
@@ -1073,6 +1087,20 @@ def side_measurements(pkg, fv, ctx, torch, dev):
             "s_host_vad_and_metadata": t_all - t_gpu, "segments": n_seg,
             "long_term_chain_evaluations": int(sum(a for a, _ in stats)), "long_term_pushes": int(sum(b for _, b in stats)),
             "note": "21 streams x 2 h on one GPU (the 8-GPU config gives each GPU 2-3 of them); host stage not overlapped"}
+        # the same corpus as time slices with the host stage of slice k (fvad_vad_batch_run_part) beside the GPU's slice k + 1
+        # (shard.run_sliced_with_vad: a slice is one 49152-chunk launch, 16 chunks of halo per lane and slice)
+        try:
+            vbs = fv.VadBatch(n_st)
+            t0 = time.perf_counter()
+            segs_ov, info = pkg.shard.run_sliced_with_vad(ctx, big.data_ptr(), n_st, big.stride(0), nch, vbs, n_threads=16)
+            t_ov = time.perf_counter() - t0
+            vbs.close()
+            extra["cfg4_shape_21_streams_x_7200s_one_gpu"]["host_stage_overlapped"] = {
+                "frames_per_s": n_st * n_sec * 100 / t_ov, "s_total": t_ov, "s_until_last_slice_on_host": info["gpu_s"],
+                "s_host_tail": info["host_tail_s"], "slices": info["slices"], "chunks_per_slice_and_lane": info["slice_chunks"],
+                "segments": sum(len(x) for x in segs_ov), "same_segment_count": sum(len(x) for x in segs_ov) == n_seg}
+        except Exception as e:
+            extra["cfg4_shape_21_streams_x_7200s_one_gpu"]["host_stage_overlapped"] = {"error": repr(e)}
         del big, b4, r4, base
     except Exception as e:  # e.g. not enough free HBM next to other tenants
         extra["cfg4_shape_21_streams_x_7200s_one_gpu"] = {"error": repr(e)}

@@ -301,6 +301,7 @@ pub extern "c" fn fvad_vad_run_many(vads: [*]const *Vad, n_streams: usize, band:
 pub extern "c" fn fvad_vad_batch_create(cfg: *const VadConfig, sample_rate: usize, n_channels: usize, fft_size: usize, n_streams: usize, out: *?*VadBatch) c_int;
 pub extern "c" fn fvad_vad_batch_destroy(b: ?*VadBatch) void;
 pub extern "c" fn fvad_vad_batch_run(b: *VadBatch, band: [*]const f32, band_stride: usize, n_frames: usize, chunk_rms: [*]const f32, rms_stride: usize, n_chunks: usize, chunk_size: usize, n_threads: c_int) c_int;
+pub extern "c" fn fvad_vad_batch_run_part(b: *VadBatch, band: [*]const f32, band_stride: usize, n_frames: usize, chunk_rms: [*]const f32, rms_stride: usize, n_chunks: usize, chunk_size: usize, first_frame: u64, n_threads: c_int) c_int;
 pub extern "c" fn fvad_vad_batch_total_segments(b: *const VadBatch) usize;
 pub extern "c" fn fvad_vad_batch_segments(b: *const VadBatch, out: [*]SpeechSegment, cap: usize, offsets: [*]usize) c_int;
 pub extern "c" fn fvad_vad_batch_audit(b: *const VadBatch, stream: usize, out: *VadAudit) c_int;

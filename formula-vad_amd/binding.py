@@ -220,6 +220,7 @@ SIGNATURES = {
     "fvad_vad_batch_create": (C.c_int, [C.POINTER(VadConfig), sz, sz, sz, sz, C.POINTER(vp)]),
     "fvad_vad_batch_destroy": (None, [vp]),
     "fvad_vad_batch_run": (C.c_int, [vp, c_float_p, sz, sz, c_float_p, sz, sz, sz, C.c_int]),
+    "fvad_vad_batch_run_part": (C.c_int, [vp, c_float_p, sz, sz, c_float_p, sz, sz, sz, C.c_uint64, C.c_int]),
     "fvad_vad_batch_total_segments": (sz, [vp]),
     "fvad_vad_batch_segments": (C.c_int, [vp, C.POINTER(SpeechSegment), sz, C.POINTER(sz)]),
     "fvad_vad_batch_audit": (C.c_int, [vp, sz, C.POINTER(VadAudit)]),
@@ -826,6 +827,27 @@ class VadBatch:
         check(lib().fvad_vad_batch_segments(self.h, arr, max(n, 1), offs), "fvad_vad_batch_segments")
         flat = [(a.sample_from, a.sample_to, a.avg_channel_vol_ratio, a.vad_met_sec) for a in arr[:n]]
         return [flat[offs[s]:offs[s + 1]] for s in range(self.n_streams)]
+
+    def _segments(self):
+        n = lib().fvad_vad_batch_total_segments(self.h)
+        arr = (SpeechSegment * max(n, 1))()
+        offs = (sz * (self.n_streams + 1))()
+        check(lib().fvad_vad_batch_segments(self.h, arr, max(n, 1), offs), "fvad_vad_batch_segments")
+        flat = [(a.sample_from, a.sample_to, a.avg_channel_vol_ratio, a.vad_met_sec) for a in arr[:n]]
+        return [flat[offs[s]:offs[s + 1]] for s in range(self.n_streams)]
+
+    def run_part(self, band, chunk_rms, first_frame, n_threads=1, chunk_size=24000, want_segments=True):
+        """fvad_vad_batch_run_part: `band` [lanes][n_frames] holds the frames from `first_frame` on, `chunk_rms` [lanes][n_chunks] the
+        chunks from the one that frame starts in (float32 views with a contiguous last axis: nothing is copied; a part off the
+        chunk grid is refused by the library).  -> the segments of everything run so far (or None)."""
+        assert band.dtype == np.float32 and chunk_rms.dtype == np.float32
+        assert (band.shape[1] <= 1 or band.strides[1] == 4) and (chunk_rms.shape[1] <= 1 or chunk_rms.strides[1] == 4)
+        assert band.shape[0] == chunk_rms.shape[0] == self.n_streams * self.n_channels
+        bp = C.cast(band.ctypes.data, c_float_p)
+        rp = C.cast(chunk_rms.ctypes.data, c_float_p)
+        check(lib().fvad_vad_batch_run_part(self.h, bp, band.strides[0] // 4, band.shape[1], rp, chunk_rms.strides[0] // 4, chunk_rms.shape[1],
+                                            chunk_size, first_frame, n_threads), "fvad_vad_batch_run_part")
+        return self._segments() if want_segments else None
 
     def audit(self, stream):
         a = VadAudit()

@@ -489,6 +489,9 @@ struct fvad_vad_batch {
     size_t sample_rate, n_channels, fft_size, n_streams;
     std::vector<std::vector<fvad_speech_segment>> segs;
     std::vector<fvad_vad_audit> audits;
+    // a run in parts (fvad_vad_batch_run_part): the streams' machines live on between the parts
+    std::vector<std::unique_ptr<fvad::VadMachine>> machines;
+    uint64_t next_frame = 0;
 };
 
 int fvad_vad_batch_create(const fvad_vad_config* cfg, size_t sample_rate, size_t n_channels, size_t fft_size, size_t n_streams,
@@ -506,14 +509,22 @@ int fvad_vad_batch_create(const fvad_vad_config* cfg, size_t sample_rate, size_t
 }
 void fvad_vad_batch_destroy(fvad_vad_batch* b) { delete b; }
 
-int fvad_vad_batch_run(fvad_vad_batch* b, const float* band, size_t band_stride, size_t n_frames, const float* chunk_rms,
-                       size_t rms_stride, size_t n_chunks, size_t chunk_size, int n_threads)
+int fvad_vad_batch_run_part(fvad_vad_batch* b, const float* band, size_t band_stride, size_t n_frames, const float* chunk_rms,
+                            size_t rms_stride, size_t n_chunks, size_t chunk_size, uint64_t first_frame, int n_threads)
 {
     if (!b || (n_frames && !band) || (n_chunks && !chunk_rms) || chunk_size == 0) return FVAD_ERR_INVALID_ARGUMENT;
-    if (n_frames * b->fft_size > n_chunks * chunk_size) return FVAD_ERR_INVALID_ARGUMENT; // a frame without its chunk's ratio
+    // parts follow each other without gaps, and a part starts where a chunk starts (its first chunk is chunk_rms' first column)
+    if (first_frame != 0 && (first_frame != b->next_frame || b->machines.size() != b->n_streams)) return FVAD_ERR_INVALID_ARGUMENT;
+    if ((first_frame * b->fft_size) % chunk_size) return FVAD_ERR_INVALID_ARGUMENT;
+    const uint64_t first_chunk = first_frame * b->fft_size / chunk_size;
+    if ((first_frame + n_frames) * b->fft_size > (first_chunk + n_chunks) * chunk_size) return FVAD_ERR_INVALID_ARGUMENT; // a frame without its chunk's ratio
     const size_t C = b->n_channels;
+    if (first_frame == 0) { // fresh machines (VADMachine.init per pipeline, VADPipeline.zig:60-75)
+        b->machines.clear();
+        for (size_t s = 0; s < b->n_streams; ++s) b->machines.emplace_back(new fvad::VadMachine(b->cfg, b->sample_rate, C, b->fft_size));
+    }
     auto run_stream = [&](size_t s) {
-        fvad::VadMachine m(b->cfg, b->sample_rate, C, b->fft_size);
+        fvad::VadMachine& m = *b->machines[s];
         std::vector<float> ratio(n_chunks), ch(C), vols(C);
         for (size_t k = 0; k < n_chunks; ++k) {
             for (size_t c = 0; c < C; ++c) ch[c] = chunk_rms[(s * C + c) * rms_stride + k];
@@ -525,29 +536,38 @@ int fvad_vad_batch_run(fvad_vad_batch* b, const float* band, size_t band_stride,
         }
         for (size_t f = 0; f < n_frames; ++f) {
             fvad::Metadata md;
-            const uint64_t from = (uint64_t)f * b->fft_size, to = from + b->fft_size;
+            const uint64_t from = (first_frame + f) * b->fft_size, to = from + b->fft_size;
             for (uint64_t c = from / chunk_size; c * chunk_size < to; ++c) {
                 const uint64_t lo = std::max<uint64_t>(from, c * chunk_size), hi = std::min<uint64_t>(to, (c + 1) * chunk_size);
                 fvad::MetaResult r;
                 r.has_ratio = true;
-                r.volume_ratio = ratio[(size_t)c];
+                r.volume_ratio = ratio[(size_t)(c - first_chunk)];
                 md.push(r, (float)(hi - lo));
             }
             const fvad::MetaResult fr = md.to_result();
             for (size_t c = 0; c < C; ++c) vols[c] = band[(s * C + c) * band_stride + f];
             m.run(from, vols.data(), fr.has_ratio, fr.volume_ratio);
         }
-        b->segs[s] = std::move(m.segments);
+        b->segs[s] = m.segments; // (everything so far: a segment is appended when it closes)
         b->audits[s] = m.audit;
     };
     const int nt = (int)std::min<size_t>((size_t)std::max(n_threads, 1), b->n_streams);
-    if (nt <= 1) { for (size_t s = 0; s < b->n_streams; ++s) run_stream(s); return FVAD_OK; }
-    std::vector<std::thread> th;
-    std::atomic<size_t> next{0};
-    for (int t = 0; t < nt; ++t)
-        th.emplace_back([&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= b->n_streams) break; run_stream(i); } });
-    for (auto& t : th) t.join();
+    if (nt <= 1) { for (size_t s = 0; s < b->n_streams; ++s) run_stream(s); }
+    else {
+        std::vector<std::thread> th;
+        std::atomic<size_t> next{0};
+        for (int t = 0; t < nt; ++t)
+            th.emplace_back([&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= b->n_streams) break; run_stream(i); } });
+        for (auto& t : th) t.join();
+    }
+    b->next_frame = first_frame + n_frames;
     return FVAD_OK;
+}
+
+int fvad_vad_batch_run(fvad_vad_batch* b, const float* band, size_t band_stride, size_t n_frames, const float* chunk_rms,
+                       size_t rms_stride, size_t n_chunks, size_t chunk_size, int n_threads)
+{
+    return fvad_vad_batch_run_part(b, band, band_stride, n_frames, chunk_rms, rms_stride, n_chunks, chunk_size, 0, n_threads);
 }
 
 size_t fvad_vad_batch_total_segments(const fvad_vad_batch* b)

@@ -208,3 +208,105 @@ def run_time_split_rank_graph(ctx, pcm, c0, c1, window=496, lanes=4, want_denois
             ctx.device_free(d)
     return {"denoised": den, "chunk_rms": rms, "band_sum": band, "first_frame_index": f_lo * FFT, "replays": replays,
             "lane_starts": starts}
+
+
+# ------------------------------------------------------------------ one long batch in time slices, the host VAD beside the GPU
+def run_sliced_with_vad(ctx, d_pcm, n_lanes, lane_stride, n_chunks, vad_batch, slice_chunks=None, n_threads=16,
+                        pcm_i16=False, max_launch=49152):
+    """A device-resident batch of `n_lanes` long lanes (`n_chunks` chunks each, lane l at d_pcm + l * lane_stride samples) as a
+    loop of time slices, with the host stage of slice k -- frame metadata + VAD state machines, `vad_batch.run_part`
+    (fvad_vad_batch_run_part) -- running beside the GPU's slice k + 1.  In one call the host stage comes after the last
+    kernel (a two-hour stream: 20 ms of GPU, then 36 ms of VADMachine on one core); here only the last slice's is exposed.
+
+    A slice is one fvad_engine_enqueue_device call (no_wait) over chunks [s0 - 16, s1) of every lane: it starts 16 chunks early
+    from zero history -- two chunks are what NSNet2's cross-chunk state needs (src/NSNet2.zig:188-203), sixteen keep the
+    1024-sample frame grid where the unsplit stream has it (lcm(24000, 1024) = 16 chunks = 375 frames; BufferedFFT.zig:149) --
+    and the halo's frames and chunks are dropped.  Within one kernel selection the band sums and RMS are the unsplit run's bit
+    for bit; by default `slice_chunks` makes a slice one launch of the size the unsplit run's launches have.
+    Returns (segments per stream, {"slices", "slice_chunks", "gpu_s", "host_tail_s"})."""
+    import ctypes as C
+    import threading
+    import time
+    from . import binding as fv
+    L = fv.lib()
+    H = ALIGN_CHUNKS
+    if slice_chunks is None:
+        slice_chunks = max(H, (max_launch // n_lanes - H) // H * H)
+    assert slice_chunks % H == 0 and slice_chunks > 0
+    S = min(slice_chunks, (n_chunks + H - 1) // H * H)
+    slices = [(s0, min(s0 + S, n_chunks)) for s0 in range(0, n_chunks, S)]
+    len_max = min(S + H, n_chunks)
+    fr_max = len_max * CHUNK // FFT
+    hip = C.CDLL("libamdhip64.so")
+    L.fvad_ctx_stream.restype = C.c_void_p
+    stream = C.c_void_p(L.fvad_ctx_stream(ctx.h))
+    opts = fv.EngineOpts()
+    L.fvad_engine_opts_default(C.byref(opts))
+    opts.no_wait = 1
+    enqueue = L.fvad_engine_enqueue_device_i16 if pcm_i16 else L.fvad_engine_enqueue_device
+    bytes_per_sample = 2 if pcm_i16 else 4
+    d_band = [ctx.device_alloc(n_lanes * fr_max * 4) for _ in range(2)]
+    d_rms = [ctx.device_alloc(n_lanes * len_max * 4) for _ in range(2)]
+    h_band = [ctx.host_alloc(n_lanes * fr_max) for _ in range(2)]
+    h_rms = [ctx.host_alloc(n_lanes * len_max) for _ in range(2)]
+    ev = [C.c_void_p(), C.c_void_p()]
+    for e in ev:
+        if hip.hipEventCreateWithFlags(C.byref(e), 0x2) != 0:
+            raise RuntimeError("hipEventCreate failed")
+    errs = []
+
+    def gpu_stage(k):
+        s0, s1 = slices[k]
+        start = max(s0 - H, 0)
+        n, slot = s1 - start, k & 1
+        fv.check(enqueue(ctx.h, C.c_void_p(d_pcm + start * CHUNK * bytes_per_sample), n_lanes, lane_stride, n * CHUNK, None,
+                         C.c_void_p(d_band[slot]), C.c_void_p(d_rms[slot]), C.byref(opts)), "fvad_engine_enqueue_device", ctx.h)
+        fr = n * CHUNK // FFT
+        fv.check(L.fvad_ctx_copy_to_host(ctx.h, h_band[slot].ctypes.data, C.c_void_p(d_band[slot]), n_lanes * fr * 4), "copy band sums", ctx.h)
+        fv.check(L.fvad_ctx_copy_to_host(ctx.h, h_rms[slot].ctypes.data, C.c_void_p(d_rms[slot]), n_lanes * n * 4), "copy rms", ctx.h)
+        hip.hipEventRecord(ev[slot], stream)
+
+    def host_stage(k):
+        try:
+            s0, s1 = slices[k]
+            start = max(s0 - H, 0)
+            n, slot = s1 - start, k & 1
+            fr = n * CHUNK // FFT
+            f0 = (s0 - start) * CHUNK // FFT                     # the halo's frames
+            f1 = fr if s1 == n_chunks else f0 + (s1 - s0) * CHUNK // FFT
+            band = h_band[slot][: n_lanes * fr].reshape(n_lanes, fr)[:, f0:f1]
+            rms = h_rms[slot][: n_lanes * n].reshape(n_lanes, n)[:, s0 - start:]
+            vad_batch.run_part(band, rms, s0 * CHUNK // FFT, n_threads=n_threads, want_segments=False)
+        except Exception as e:  # re-raised below, in the caller's thread
+            errs.append(e)
+
+    try:
+        t0 = time.perf_counter()
+        worker = None
+        gpu_stage(0)
+        for k in range(len(slices)):
+            if worker is not None:
+                worker.join()                                # host stage of slice k - 1: it frees slot (k + 1) & 1
+            if errs:
+                raise errs[0]
+            if k + 1 < len(slices):
+                gpu_stage(k + 1)
+            if hip.hipEventSynchronize(ev[k & 1]) != 0:
+                raise RuntimeError("hipEventSynchronize failed")
+            worker = threading.Thread(target=host_stage, args=(k,))
+            worker.start()
+        t_gpu = time.perf_counter() - t0
+        worker.join()
+        if errs:
+            raise errs[0]
+        t_all = time.perf_counter() - t0
+        segs = vad_batch._segments()
+    finally:
+        ctx.synchronize()
+        for e in ev:
+            hip.hipEventDestroy(e)
+        for d in d_band + d_rms:
+            ctx.device_free(d)
+        for h in h_band + h_rms:
+            ctx.host_free(h)
+    return segs, {"slices": len(slices), "slice_chunks": S, "gpu_s": t_gpu, "host_tail_s": t_all - t_gpu}

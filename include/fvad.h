@@ -418,6 +418,15 @@ void fvad_vad_batch_destroy(fvad_vad_batch *b);
 int fvad_vad_batch_run(fvad_vad_batch *b, const float *band, size_t band_stride, size_t n_frames,
                        const float *chunk_rms, size_t rms_stride, size_t n_chunks, size_t chunk_size,
                        int n_threads);
+/* The same in parts: frames [first_frame, first_frame + n_frames) of every stream, the streams' machines living on between
+ * the calls, so that a host can run the VAD of the part it has while the GPU produces the next one.  first_frame = 0 starts
+ * from fresh machines (fvad_vad_batch_run is this with first_frame = 0); a later part must start where the previous one
+ * ended, on a chunk boundary (first_frame * fft_size a multiple of chunk_size: at 48 kHz and fft_size 1024 every 375 frames
+ * = 16 chunks), and band / chunk_rms point at the part's first frame / first chunk.  Segments and audits (below) cover
+ * everything run so far.  Bit-identical to one fvad_vad_batch_run over all the frames. */
+int fvad_vad_batch_run_part(fvad_vad_batch *b, const float *band, size_t band_stride, size_t n_frames,
+                            const float *chunk_rms, size_t rms_stride, size_t n_chunks, size_t chunk_size,
+                            uint64_t first_frame, int n_threads);
 size_t fvad_vad_batch_total_segments(const fvad_vad_batch *b);
 /* all segments, stream after stream; offsets[s] .. offsets[s + 1] are stream s's (offsets has n_streams + 1 entries) */
 int fvad_vad_batch_segments(const fvad_vad_batch *b, fvad_speech_segment *out, size_t cap,

@@ -747,6 +747,40 @@ def test_engine_host_buffer_pipelining_is_invisible(fv, gpu_ctx, pkg):
     gpu_ctx.set_option("run_groups", "")
 
 
+def test_time_slices_with_the_host_vad_beside_the_gpu(fv, gpu_ctx, pkg):
+    # shard.run_sliced_with_vad: a long device-resident batch as time slices (each starts 16 chunks early from zero history),
+    # fvad_vad_batch_run_part of slice k beside the GPU's slice k + 1: the segments of one call + one fvad_vad_batch_run
+    base, _ = pkg.synth.make_stream(100.0, seed=33)
+    n_l, n_ch = 5, 400
+    pcm = np.stack([np.resize(np.roll(base[0], 7001 * i), n_ch * 24000) for i in range(n_l)]).astype(np.float32)
+    n_samp = n_ch * 24000
+    n_fr = n_samp // 1024
+    d_pcm = gpu_ctx.device_alloc(pcm.nbytes); gpu_ctx.to_device(d_pcm, pcm)
+    d_band = gpu_ctx.device_alloc(n_l * n_fr * 4); d_rms = gpu_ctx.device_alloc(n_l * n_ch * 4)
+    try:
+        for opts in ({"reproducible": "1"}, {}):
+            with gpu_ctx.options(**opts):
+                gpu_ctx.enqueue_device(d_pcm, n_l, n_samp, n_samp, None, d_band, d_rms)
+                band = np.empty((n_l, n_fr), np.float32); rms = np.empty((n_l, n_ch), np.float32)
+                gpu_ctx.to_host(band, d_band); gpu_ctx.to_host(rms, d_rms)
+                whole = fv.VadBatch(n_l)
+                want = whole.run(band, rms, n_threads=2)
+                assert sum(len(w) for w in want) >= 5
+                for sl in (96, 160, 400):
+                    vb = fv.VadBatch(n_l)
+                    got, info = pkg.shard.run_sliced_with_vad(gpu_ctx, d_pcm, n_l, n_samp, n_ch, vb, slice_chunks=sl, n_threads=2)
+                    assert info["slices"] == -(-n_ch // sl)
+                    assert got == want, (opts, sl)
+                    if opts:
+                        for s_ in range(n_l):
+                            assert vb.audit(s_) == whole.audit(s_)
+                    vb.close()
+                whole.close()
+    finally:
+        for d in (d_pcm, d_band, d_rms):
+            gpu_ctx.device_free(d)
+
+
 def test_launch_plans(fv, gpu_ctx):
     # a call whose launch size is left to the engine is cut into launches that fill the chip and a remainder (plan_launches):
     # the plans behind docs/LAB_NOTES.md's table, and the invariants of every plan

@@ -629,6 +629,54 @@ def test_vad_batch_equals_oracle_pipeline(fv, pkg):
     b.close()
 
 
+def test_vad_batch_in_parts_equals_one_run(fv):
+    # fvad_vad_batch_run_part: the machines live on between the parts, so a host can run the VAD of what it has while the GPU
+    # produces the rest.  Random part boundaries on the common grid of chunks and frames (every 375 frames = 16 chunks), mono and
+    # stereo, speech bursts that straddle boundaries: segments and the margin audit equal one run over everything, bit for bit
+    rng = np.random.default_rng(12)
+    for nch in (1, 2):
+        n_streams, n_units = 3, 40                                   # 40 x 16 chunks = 320 s
+        n_frames, n_chunks = n_units * 375, n_units * 16
+        band = (0.004 + 0.002 * rng.random((n_streams * nch, n_frames))).astype(np.float32)
+        for s in range(n_streams * nch):                             # bursts of "speech": the band sum jumps for 1..6 s
+            t = 200
+            while t < n_frames - 400:
+                d = int(rng.integers(47, 280))
+                band[s, t:t + d] += np.float32(0.05) * rng.random(d).astype(np.float32) + np.float32(0.03)
+                t += d + int(rng.integers(150, 900))
+        rms = (0.01 + 0.05 * rng.random((n_streams * nch, n_chunks))).astype(np.float32)
+        whole = fv.VadBatch(n_streams, n_channels=nch)
+        want = whole.run(band, rms, n_threads=2)
+        assert sum(len(w) for w in want) >= 3
+        for trial in range(3):
+            cuts = sorted(set(int(x) for x in rng.integers(1, n_units, 5)))
+            edges = [0] + cuts + [n_units]
+            parts = fv.VadBatch(n_streams, n_channels=nch)
+            got = None
+            for u0, u1 in zip(edges, edges[1:]):
+                got = parts.run_part(band[:, u0 * 375: u1 * 375], rms[:, u0 * 16: u1 * 16], u0 * 375, n_threads=1 + trial)
+            assert got == want, (nch, edges)
+            for s in range(n_streams):
+                assert parts.audit(s) == whole.audit(s)
+            # a part that does not follow the previous one, or that starts off the chunk grid, is refused
+            with pytest.raises(fv.FvadError):
+                parts.run_part(band[:, 375:750], rms[:, 16:32], 375)
+            parts.close()
+        off = fv.VadBatch(n_streams, n_channels=nch)
+        off.run_part(band[:, :100], rms[:, :5], 0)
+        with pytest.raises(fv.FvadError):
+            off.run_part(band[:, 100:200], rms[:, 4:9], 100)         # 100 frames do not end on a chunk boundary
+        with pytest.raises(fv.FvadError):
+            off.run_part(band[:, :375], rms[:, :15], 0)              # a frame without its chunk's ratio
+        off.close()
+        # ... and run() after parts starts from fresh machines again
+        again = fv.VadBatch(n_streams, n_channels=nch)
+        again.run_part(band[:, : 375 * 7], rms[:, : 16 * 7], 0)
+        assert again.run(band, rms) == want
+        again.close()
+        whole.close()
+
+
 def test_wav_write_round_trips(fv, tmp_path):
     # AudioBuffer.saveToFile for WAV: float32 is lossless; PCM16 is lrintf(clip(x) * 32767) and comes back as s / 32768
     rng = np.random.default_rng(4)
