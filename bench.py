@@ -258,14 +258,12 @@ def run_cfg4(args, pkg, fv, ctx, torch, dist, rank, world, cdev, steps=None, war
     # The rank's streams as time slices, the host VAD of slice k beside the GPU's slice k + 1 (shard.run_sliced_with_vad): a slice
     # is one launch of at most 49152 chunks, and at least four slices even for two or three streams (their VAD is 36 ms per
     # two-hour stream on one core: a third of a rank's step if it ran behind the kernels)
-    H16 = pkg.shard.ALIGN_CHUNKS
-    slice_chunks = max(H16, min((49152 // max(n_l, 1) - H16) // H16 * H16, -(-n_chunks // (4 * H16)) * H16))
 
     def step():
         t0 = time.perf_counter()
         all_segs = []
         if n_l and not args.cfg4_one_call:
-            all_segs, info = pkg.shard.run_sliced_with_vad(ctx, d_pcm, n_l, n_samp, n_chunks, vb, slice_chunks=slice_chunks, n_threads=vad_threads)
+            all_segs, info = pkg.shard.run_sliced_with_vad(ctx, d_pcm, n_l, n_samp, n_chunks, vb, n_threads=vad_threads)
             t1 = t0 + info["gpu_s"]
         elif n_l:
             fv.check(L.fvad_engine_enqueue_device(ctx.h, d_pcm, n_l, n_samp, n_samp, None, d_band, d_rms, None), "cfg4 enqueue", ctx.h)

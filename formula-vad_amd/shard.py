@@ -222,7 +222,7 @@ def run_sliced_with_vad(ctx, d_pcm, n_lanes, lane_stride, n_chunks, vad_batch, s
     from zero history -- two chunks are what NSNet2's cross-chunk state needs (src/NSNet2.zig:188-203), sixteen keep the
     1024-sample frame grid where the unsplit stream has it (lcm(24000, 1024) = 16 chunks = 375 frames; BufferedFFT.zig:149) --
     and the halo's frames and chunks are dropped.  Within one kernel selection the band sums and RMS are the unsplit run's bit
-    for bit; by default `slice_chunks` makes a slice one launch of the size the unsplit run's launches have.
+    for bit; by default a slice is one launch of the size the unsplit run's launches have, and there are at least four slices.
     Returns (segments per stream, {"slices", "slice_chunks", "gpu_s", "host_tail_s"})."""
     import ctypes as C
     import threading
@@ -230,8 +230,9 @@ def run_sliced_with_vad(ctx, d_pcm, n_lanes, lane_stride, n_chunks, vad_batch, s
     from . import binding as fv
     L = fv.lib()
     H = ALIGN_CHUNKS
-    if slice_chunks is None:
-        slice_chunks = max(H, (max_launch // n_lanes - H) // H * H)
+    if slice_chunks is None: # one launch of the largest size per slice, but at least four slices: a few long lanes would otherwise be
+        # ONE slice with all of their VAD behind it (two-hour streams: 36 ms each on one core against ~30 ms of GPU per stream)
+        slice_chunks = max(H, min((max_launch // n_lanes - H) // H * H, -(-n_chunks // (4 * H)) * H))
     assert slice_chunks % H == 0 and slice_chunks > 0
     S = min(slice_chunks, (n_chunks + H - 1) // H * H)
     slices = [(s0, min(s0 + S, n_chunks)) for s0 in range(0, n_chunks, S)]
