@@ -246,14 +246,7 @@ def run_sliced_with_vad(ctx, d_pcm, n_lanes, lane_stride, n_chunks, vad_batch, s
     opts.no_wait = 1
     enqueue = L.fvad_engine_enqueue_device_i16 if pcm_i16 else L.fvad_engine_enqueue_device
     bytes_per_sample = 2 if pcm_i16 else 4
-    d_band = [ctx.device_alloc(n_lanes * fr_max * 4) for _ in range(2)]
-    d_rms = [ctx.device_alloc(n_lanes * len_max * 4) for _ in range(2)]
-    h_band = [ctx.host_alloc(n_lanes * fr_max) for _ in range(2)]
-    h_rms = [ctx.host_alloc(n_lanes * len_max) for _ in range(2)]
-    ev = [C.c_void_p(), C.c_void_p()]
-    for e in ev:
-        if hip.hipEventCreateWithFlags(C.byref(e), 0x2) != 0:
-            raise RuntimeError("hipEventCreate failed")
+    d_band, d_rms, h_band, h_rms, ev = [], [], [], [], []   # released in `finally`, however many of them were made
     errs = []
 
     def gpu_stage(k):
@@ -281,7 +274,17 @@ def run_sliced_with_vad(ctx, d_pcm, n_lanes, lane_stride, n_chunks, vad_batch, s
         except Exception as e:  # re-raised below, in the caller's thread
             errs.append(e)
 
+    worker = None
     try:
+        for _ in range(2):
+            d_band.append(ctx.device_alloc(n_lanes * fr_max * 4))
+            d_rms.append(ctx.device_alloc(n_lanes * len_max * 4))
+            h_band.append(ctx.host_alloc(n_lanes * fr_max))
+            h_rms.append(ctx.host_alloc(n_lanes * len_max))
+            e = C.c_void_p()
+            if hip.hipEventCreateWithFlags(C.byref(e), 0x2) != 0:   # hipEventDisableTiming
+                raise RuntimeError("hipEventCreate failed")
+            ev.append(e)
         t0 = time.perf_counter()
         worker = None
         gpu_stage(0)
@@ -303,6 +306,8 @@ def run_sliced_with_vad(ctx, d_pcm, n_lanes, lane_stride, n_chunks, vad_batch, s
         t_all = time.perf_counter() - t0
         segs = vad_batch._segments()
     finally:
+        if worker is not None:
+            worker.join()
         ctx.synchronize()
         for e in ev:
             hip.hipEventDestroy(e)
