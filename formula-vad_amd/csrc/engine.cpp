@@ -177,6 +177,7 @@ static int apply_option(fvad_ctx* ctx, const std::string& name, const char* valu
         tn.gru_lat_tiles = (int)c;
     } else if (name == "k4_plain_loads") { if (!to_bool(tn.k4_plain_loads)) return FVAD_ERR_INVALID_ARGUMENT; }
     else if (name == "no_pipeline") { if (!to_bool(tn.no_pipeline)) return FVAD_ERR_INVALID_ARGUMENT; }
+    else if (name == "trace_run") { if (!to_bool(tn.trace_run)) return FVAD_ERR_INVALID_ARGUMENT; }
     else if (name == "run_groups") { // "a,b,c": sixteenths per lane group of fvad_engine_run (sum 16, at most 7 groups); unset = planned
         if (!unset) {
             int sum = 0, n = 0, cur = 0;
@@ -287,7 +288,7 @@ int fvad_ctx_create(int device, fvad_ctx** out)
     if (get_vad_plan(ctx, kVadFft, &pl) != FVAD_OK) { fvad_ctx_destroy(ctx); return FVAD_ERR_HIP; }
     // the tuning variables FVAD_<NAME> are read here, once; a bad value fails the creation rather than being ignored
     for (const char* opt : {"nn_math", "gru_kernel", "gemm_kernel", "h3_waves", "max_chunks", "copy_threads", "ws_spin_ticks",
-                            "no_pipeline", "run_groups", "trace_kernels", "reproducible"}) {
+                            "no_pipeline", "run_groups", "trace_run", "trace_kernels", "reproducible"}) {
         std::string env = std::string("FVAD_") + opt;
         for (char& c : env) c = (char)toupper((unsigned char)c);
         const char* v = getenv(env.c_str());

@@ -482,7 +482,7 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
         return staged_copy(ctx, d2h, false, s_out);
     };
 
-    static const bool trace_run = getenv("FVAD_TRACE_RUN") != nullptr; // timeline of the call on stderr (tools/pcie_run.py)
+    const bool trace_run = ctx->tune.trace_run; // timeline of the call on stderr (context option trace_run / FVAD_TRACE_RUN=1 at fvad_ctx_create; tools/pcie_run.py)
     const auto t_start = std::chrono::steady_clock::now();
     auto stamp = [&](const char* what, int g) {
         if (trace_run) fprintf(stderr, "[run] %8.3f ms  %s %d\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), what, g);

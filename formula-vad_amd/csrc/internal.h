@@ -166,6 +166,7 @@ struct Tuning {
     int h3_waves = 0;            // 0 / 8 / 12
     long max_chunks = 49152;     // chunks per launch when the caller passes 0
     bool no_pipeline = false;    // host-buffer path: single lane group
+    bool trace_run = false;      // host-buffer path: a timeline of every fvad_engine_run call on stderr (groups staged / enqueued / finished / drained)
     std::string run_groups;      // host-buffer path: the lane groups' sizes in sixteenths of the call ("4,4,4,4"); empty = planned
     int gru_lat_tiles = 0;       // row tiles per workgroup of gru_lat (1, 2, 3: the same bits); 0 = by launch size (the cost model)
     bool k4_plain_loads = false; // vadfft1024_band_kernel: stage frames with plain 8-byte loads even when they are 16-byte aligned (the path

@@ -317,7 +317,7 @@ const char *fvad_ctx_last_nn_path(const fvad_ctx *ctx);
  * Testing / tuning aids, none needed in production: name = "reproducible" | "nn_math" ("f32" | "f16x3" | "bf16x3": overrides
  * fvad_ctx_set_nn_math) | "gru_kernel" ("v3w12" | "v3w8" | "v3w4" | "v4w8" | "v5w0" | "v6w0") | "gemm_kernel" ("v1" |
  * "v3" | "v3nofold") | "h3_waves" ("8" | "12") | "max_chunks" | "copy_threads" | "no_pipeline" | "run_groups" ("1,3,4,8": the lane groups of
- * fvad_engine_run's host-buffer pipeline in sixteenths of the call, at most seven, instead of the planned ones) | "trace_kernels" |
+ * fvad_engine_run's host-buffer pipeline in sixteenths of the call, at most seven, instead of the planned ones) | "trace_run" (a timeline of every fvad_engine_run call on stderr) | "trace_kernels" |
  * "ws_spin_ticks" | "ws2_variant" (diagnostic bit mask; the timing-only bits exist in the diagnostics build alone) |
  * "ws2_waits" | "ws2_calibrate" (below) | "k4_plain_loads" (the band FFT's staging path of unaligned frames) | "gru_lat_tiles" ("1" | "2" | "3": row tiles per
  * workgroup of the low-latency recurrence instead of the cost model's choice; same bits); value NULL or ""
