@@ -173,21 +173,30 @@ def _run_instances(ctx, plan, audio):
     min_bin = int(np.round(np.float32(vm.get("speech_min_freq", 500.0)) / bin_w))
     max_bin = int(np.round(np.float32(vm.get("speech_max_freq", 2000.0)) / bin_w))
     res = ctx.engine_run(lanes, min_bin=min_bin, max_bin=max_bin, fft_size=plan["fft_size"])
-    # host stage: the library's batched form (frame metadata + VAD state machine), one call per instance
-    # (instances differ in length and channel count)
-    out = []
-    k = 0
-    for pcm in audio:
-        C_ = pcm.shape[0]
-        r = res[k:k + C_]
-        k += C_
+    # host stage: the library's batched form (frame metadata + VAD state machine), one call per instance (instances differ
+    # in length and channel count) -- the instances side by side on host threads, like the reference's thread per file
+    # (simulator.zig:221-232): a two-hour stream's state machine is 36 ms on one core, 21 of them one after the other were
+    # as long as the GPU's part of the plan
+    from concurrent.futures import ThreadPoolExecutor
+    first = np.cumsum([0] + [pcm.shape[0] for pcm in audio])
+
+    def host_stage(i):
+        C_ = audio[i].shape[0]
+        r = res[first[i]:first[i] + C_]
         band = np.ascontiguousarray(np.stack([x["band_sum"] for x in r]))      # [channel][frame]
         rms = np.ascontiguousarray(np.stack([x["chunk_rms"] for x in r]))
         vb = fv.VadBatch(1, n_channels=C_, fft_size=plan["fft_size"], overrides=vm)
-        segs = vb.run(band, rms)[0] if band.shape[1] else []
-        out.append((segs, vb.audit(0)))
-        vb.close()
-    return out
+        try:
+            segs = vb.run(band, rms)[0] if band.shape[1] else []
+            return segs, vb.audit(0)
+        finally:
+            vb.close()
+
+    n_workers = max(1, min(len(audio), os.cpu_count() or 1, 16))
+    if n_workers == 1:
+        return [host_stage(i) for i in range(len(audio))]
+    with ThreadPoolExecutor(max_workers=n_workers) as pool:
+        return list(pool.map(host_stage, range(len(audio))))
 
 
 def run_plan(plan_path, ctx=None, synth_seed=None, out=sys.stdout, devices=None):
