@@ -904,8 +904,10 @@ def wav_read_i16(path):
     nch, nfr, sr = sz(), sz(), sz()
     check(lib().fvad_wav_read_i16(path.encode(), C.byref(pp), C.byref(nch), C.byref(nfr), C.byref(sr)), "fvad_wav_read_i16")
     try:
-        out = np.stack([np.ctypeslib.as_array(pp[c], shape=(nfr.value,)).copy() for c in range(nch.value)]) \
-            if nfr.value else np.zeros((nch.value, 0), np.int16)
+        out = np.empty((nch.value, nfr.value), np.int16)    # one copy per channel (stacking copies of the channels was three)
+        for c in range(nch.value):
+            if nfr.value:
+                out[c] = np.ctypeslib.as_array(pp[c], shape=(nfr.value,))
     finally:
         lib().fvad_wav_free_i16(pp, nch.value)
     return out, sr.value

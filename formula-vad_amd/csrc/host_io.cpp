@@ -14,23 +14,30 @@
 #include "../../include/fvad.h"
 
 namespace {
+// unaligned little-endian loads as plain typed accesses (a chunk's body may start anywhere in the file); the loops below vectorise
+typedef int16_t i16u __attribute__((aligned(1), may_alias));
+typedef float f32u __attribute__((aligned(1), may_alias));
 uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 } // namespace
 
 namespace {
-struct WavInfo { std::vector<uint8_t> buf; int fmt_tag = 0, channels = 0, bits = 0; uint32_t rate = 0; const uint8_t* data = nullptr; size_t data_bytes = 0; };
+struct WavInfo {
+    // (malloc, not a vector: a vector would zero-fill the 100+ MB it is about to read over)
+    struct Bytes { uint8_t* p = nullptr; size_t n = 0; ~Bytes() { free(p); } uint8_t* data() { return p; } size_t size() const { return n; }
+                   bool resize(size_t k) { free(p); p = (uint8_t*)malloc(k ? k : 1); n = p ? k : 0; return p != nullptr; } } buf;
+    int fmt_tag = 0, channels = 0, bits = 0; uint32_t rate = 0; const uint8_t* data = nullptr; size_t data_bytes = 0; };
 
 int wav_parse(const char* path, WavInfo& w)
 {
     FILE* fp = fopen(path, "rb");
     if (!fp) return FVAD_ERR_IO;
-    std::vector<uint8_t>& buf = w.buf;
+    WavInfo::Bytes& buf = w.buf;
     fseek(fp, 0, SEEK_END);
     const long sz = ftell(fp);
     fseek(fp, 0, SEEK_SET);
     if (sz < 12) { fclose(fp); return FVAD_ERR_MODEL_FORMAT; }
-    buf.resize((size_t)sz);
+    if (!buf.resize((size_t)sz)) { fclose(fp); return FVAD_ERR_ALLOC_FAILED; }
     const size_t got = fread(buf.data(), 1, (size_t)sz, fp);
     fclose(fp);
     if (got != (size_t)sz) return FVAD_ERR_IO;
@@ -82,13 +89,20 @@ int fvad_wav_read(const char* path, float*** channel_pcm, size_t* n_channels, si
         out[c] = (float*)malloc(sizeof(float) * (frames ? frames : 1));
         if (!out[c]) { fvad_wav_free(out, (size_t)channels); return FVAD_ERR_ALLOC_FAILED; }
     }
-    // de-interleave (AudioFileStream.zig:88-95)
-    for (size_t i = 0; i < frames; ++i)
-        for (int c = 0; c < channels; ++c) {
-            const uint8_t* s = data + i * frame_bytes + (size_t)c * (bits / 8);
-            if (pcm16) out[c][i] = (float)(int16_t)rd16(s) * (1.0f / 32768.0f);
-            else { uint32_t u = rd32(s); float f; memcpy(&f, &u, 4); out[c][i] = f; }
+    // de-interleave (AudioFileStream.zig:88-95): per channel, unaligned typed loads (little-endian host like every target of this
+    // library) in loops the compiler vectorises -- the byte-by-byte form read 1 GB/s
+    for (int c = 0; c < channels; ++c) {
+        float* o = out[c];
+        if (pcm16) {
+            const uint8_t* s = data + (size_t)c * 2;
+            for (size_t i = 0; i < frames; ++i) o[i] = (float)*(const i16u*)(s + i * frame_bytes) * (1.0f / 32768.0f);
+        } else if (channels == 1) {
+            memcpy(o, data, frames * 4);
+        } else {
+            const uint8_t* s = data + (size_t)c * 4;
+            for (size_t i = 0; i < frames; ++i) o[i] = *(const f32u*)(s + i * frame_bytes);
         }
+    }
     *channel_pcm = out;
     *n_channels = (size_t)channels;
     *n_frames = frames;
@@ -118,8 +132,12 @@ int fvad_wav_read_i16(const char* path, int16_t*** channel_pcm, size_t* n_channe
         out[c] = (int16_t*)malloc(sizeof(int16_t) * (frames ? frames : 1));
         if (!out[c]) { fvad_wav_free_i16(out, (size_t)w.channels); return FVAD_ERR_ALLOC_FAILED; }
     }
-    for (size_t i = 0; i < frames; ++i) // de-interleave (AudioFileStream.zig:88-95), samples untouched
-        for (int c = 0; c < w.channels; ++c) out[c][i] = (int16_t)rd16(w.data + i * frame_bytes + (size_t)c * 2);
+    for (int c = 0; c < w.channels; ++c) { // de-interleave (AudioFileStream.zig:88-95), samples untouched
+        if (w.channels == 1) { memcpy(out[c], w.data, frames * 2); continue; }
+        const uint8_t* s = w.data + (size_t)c * 2;
+        int16_t* o = out[c];
+        for (size_t i = 0; i < frames; ++i) o[i] = *(const i16u*)(s + i * frame_bytes);
+    }
     *channel_pcm = out;
     *n_channels = (size_t)w.channels;
     *n_frames = frames;

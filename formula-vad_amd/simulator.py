@@ -214,17 +214,27 @@ def run_plan(plan_path, ctx=None, synth_seed=None, out=sys.stdout, devices=None)
         ctxs = [_make_ctx(plan, d, synth_seed) for d in (devices or [0])]
     else:
         ctxs = [ctx]
-    audio, refs = [], []
-    for inst in plan["instances"]:
+    def read_instance(inst):
         try:    # PCM16 files stay 16-bit all the way to the GPU (half the PCIe / HBM bytes; converted by the kernel
             pcm, sr = fv.wav_read_i16(inst["audio_path"])   # that reads them, bit-identical to converting first)
         except fv.FvadError:
             pcm, sr = fv.wav_read(inst["audio_path"])
         if sr != 48000:
             raise fv.FvadError(-9, f"{inst['name']}: sample rate {sr}")   # VADPipeline.zig:55-58
-        audio.append(pcm)
         with open(inst["ref_path"], "rb") as f:
-            refs.append(fv.parse_audacity(f.read()))
+            return pcm, fv.parse_audacity(f.read())
+
+    # the files side by side (the reference opens them on a thread each, SimulationInstance.zig:144-152): reading and
+    # de-interleaving a two-hour file is most of a plan's wall time once the GPU does the rest
+    from concurrent.futures import ThreadPoolExecutor
+    n_readers = max(1, min(len(plan["instances"]), os.cpu_count() or 1, 8))
+    if n_readers == 1:
+        loaded = [read_instance(i) for i in plan["instances"]]
+    else:
+        with ThreadPoolExecutor(max_workers=n_readers) as pool:
+            loaded = list(pool.map(read_instance, plan["instances"]))
+    audio = [a for a, _ in loaded]
+    refs = [r for _, r in loaded]
     t0 = time.perf_counter()
     n_ctx = len(ctxs)
     parts = [[i for i in range(len(audio)) if i % n_ctx == d] for d in range(n_ctx)]
