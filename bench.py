@@ -813,7 +813,9 @@ def main():
     ctx.close()
 
 
-BATCH_CURVE_POINTS = ((1, 1), (8, 1), (2, 41), (16, 16), (64, 16), (128, 16), (128, 32), (128, 64), (128, 96), (128, 128), (384, 128))
+# (5120 and 20480 chunks sit just above a size that fills the chip with one round of workgroups: the launch planner's cases)
+BATCH_CURVE_POINTS = ((1, 1), (8, 1), (2, 41), (16, 16), (64, 16), (128, 16), (128, 32), (128, 40), (128, 64), (128, 96), (128, 128), (128, 160),
+                      (384, 128))
 
 
 def batch_curve(fv, ctx, host_pcm, points=BATCH_CURVE_POINTS, budget_s=0.4):
