@@ -40,8 +40,8 @@ int ensure_pin(fvad_ctx* ctx, Workspace::PinRing& ring)
 int staged_copy(fvad_ctx* ctx, const std::vector<CopySeg>& segs, bool to_device, hipStream_t st)
 {
     Workspace::PinRing& ring = to_device ? ctx->ws.ring_in : ctx->ws.ring_out;
-    size_t total = 0, total_padded = 0;
-    for (const CopySeg& s : segs) { total += s.bytes; total_padded += (s.bytes + 63) & ~(size_t)63; }
+    size_t total_padded = 0;
+    for (const CopySeg& s : segs) total_padded += (s.bytes + 63) & ~(size_t)63;
     if (total_padded <= kPinSmallBytes) {
         // Small transfers -- every live push: hipMemcpyAsync to or from pageable memory blocks the calling thread (a
         // device -> host copy until everything queued before it has run: two of them in a row cost a push ~25 us of

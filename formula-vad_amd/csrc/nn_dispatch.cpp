@@ -575,7 +575,7 @@ int run_nn(fvad_ctx* ctx, long n_pad, int T, int skip, long n_real)
     // ahead (panel_gemm_s_kernel); fc1 is folded into the first GRU's input projection like in the large-batch
     // family; gi rows are tile-major
     const int fam = rows > 2048 ? 1 : 0, snt = fam ? 4 : 2;
-    const int nb_gi = (75 + snt - 1) / snt, nb_fc = (38 + snt - 1) / snt, nb_fc4 = (11 + snt - 1) / snt;
+    const int nb_gi = (75 + snt - 1) / snt, nb_fc = (38 + snt - 1) / snt; // (fc4 runs in 2-tile blocks whatever the family: below)
     const GruChoice gcs = pick_gru(ctx, n_pad, T, false);
     // one row tile per group (up to 96 sequences: BASELINE config 3's 82 chunks, every live push): the pipelined kernel computes
     // layer 1's input projection too, and the GEMM launch in front of it disappears
