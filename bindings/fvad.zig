@@ -717,6 +717,12 @@ pub const VadBatchHost = struct {
     }
 
     /// all segments, stream after stream; offsets[s] .. offsets[s + 1] are stream s's (offsets.len == n_streams + 1)
+    /// The same in parts (frames from `first_frame` on; the machines live on between the calls): the host stage of the time
+    /// slice that is back while the GPU works on the next one.  A part starts on a chunk boundary (every 375 frames at 48 kHz).
+    pub fn runPart(self: VadBatchHost, band: []const f32, band_stride: usize, n_frames: usize, chunk_rms: []const f32, rms_stride: usize, n_chunks: usize, first_frame: u64, n_threads: c_int) !void {
+        try check(fvad_vad_batch_run_part(self.handle, band.ptr, band_stride, n_frames, chunk_rms.ptr, rms_stride, n_chunks, fvad_nsnet2_chunk_size(48000), first_frame, n_threads));
+    }
+
     pub fn segments(self: VadBatchHost, allocator: std.mem.Allocator, offsets: []usize) ![]SpeechSegment {
         std.debug.assert(offsets.len == self.n_streams + 1);
         const n = fvad_vad_batch_total_segments(self.handle);
