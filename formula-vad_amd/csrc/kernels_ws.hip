@@ -1086,14 +1086,19 @@ __global__ __launch_bounds__(1024) void gru_ws2k_kernel(const float* __restrict_
 // publishes its tile; ONE barrier per row tile.  The flags are polled once per step (all RT row tiles of a step are
 // published before a flag is raised).  Layer 1's gi comes from the GEMM in front (tile-major rows), two row tiles ahead in
 // the helper's registers.  Hand-off form, bounded spins, error word, fallback launch: gru_ws2k_kernel's.
-constexpr unsigned WS2M_WAIT = 150; // 10 ns ticks before a step's first poll
+// 10 ns ticks before a step's first poll.  Swept through the context option ws2_waits (its low half reaches this kernel): the pipelined
+// recurrence at 256 / 1024 / 1536 chunks 717 / 1893 / 2627 us at 0.5 us, 679 / 1853 / 2617 at 1.0, 657 / 1841 / 2553 at 1.5 (rounds 4-5),
+// 639 / 1823 / 2572 at 2.0, 655 / 1826 / 2586 at 2.5, 709 / 1862 / 2612 at 3.5: timing only, the digests are the same
+constexpr unsigned WS2M_WAIT = 200;
 __global__ __launch_bounds__(1024) void gru_ws2m_kernel(const float* __restrict__ gi1, const float* __restrict__ R1frag,
                                                         const float* __restrict__ bR1, const float* __restrict__ W2frag,
                                                         const float* __restrict__ bW2, const float* __restrict__ R2frag,
                                                         const float* __restrict__ bR2, float* __restrict__ hout2,
                                                         float* hx1, float* hx2, unsigned* flags1, unsigned* flags2,
-                                                        unsigned* err, int T, int RT, int n_rt, unsigned long long spin_ticks, int variant)
+                                                        unsigned* err, int T, int RT, int n_rt, unsigned long long spin_ticks, int variant,
+                                                        unsigned first_poll_wait)
 {
+    // first_poll_wait: 10 ns ticks before a step's first poll (the launcher passes WS2M_WAIT, or the context option ws2_waits' low half)
     // diagnostics build only (timing, wrong results): variant & 4096 no operand fetch behind a step's first row tile, 8192 no gate
     // math (zeros are published), 16384 no products
     // dynamic LDS, in float4s: hb[2 buffers][A: 25 blocks of h1 | B: 25 blocks of h2][64]; xch[2 buffers][12 blocks][64]: a row
@@ -1200,7 +1205,7 @@ __global__ __launch_bounds__(1024) void gru_ws2m_kernel(const float* __restrict_
     };
     // wavefront 14: wait (timed first poll) until layer 1 has published need1 steps and layer 2 need2; false on the deadline
     auto poll = [&](unsigned need1, unsigned need2) -> bool {
-        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + WS2M_WAIT;
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + first_poll_wait;
         while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(1);
         const unsigned need = lane < 32 ? need1 : need2;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -1516,7 +1521,7 @@ int fvad_launch_gru_ws2(const float* gi1, const float* feat, const float* W1frag
         const size_t lds_m = (size_t)(4 * GRU_J * 64 + 24 * 64 + RT * 128 + 48 + 1) * 16; // >= 129 KB: one workgroup per CU
         if (hipFuncSetAttribute((const void*)gru_ws2m_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m) != hipSuccess) return -2;
         hipLaunchKernelGGL(gru_ws2m_kernel, dim3((unsigned)(G * 38)), dim3(1024), lds_m, stream, gi1, R1frag, bR1, W2frag, bW2, R2frag, bR2,
-                           hout2, hx1, hx2, flags, flags + 256, err, T, RT, n_rt, spin_ticks, variant);
+                           hout2, hx1, hx2, flags, flags + 256, err, T, RT, n_rt, spin_ticks, variant, (waits & 0xFFFFu) ? (waits & 0xFFFFu) : WS2M_WAIT);
         return 0;
     }
     // more than half of a CU's 160 KB of LDS: one workgroup per CU (all workgroups of the launch spin on each other)
