@@ -345,7 +345,9 @@ int fvad_engine_run(fvad_ctx* ctx, fvad_lane* lanes, size_t n_lanes, const fvad_
     for (const CopySeg& c : h2d) h2d_bytes += c.bytes;
     int G = 1;
     std::vector<int> parts;
-    if (!opts.on_device && n_lanes >= 8 && h2d_bytes >= (64u << 20) && !ctx->tune.no_pipeline) {
+    // (two lanes are enough: a group is at least one lane, and a few long lanes -- four two-hour files -- are the case where
+    // staging everything first costs most; the planned sixteenths merge into as many groups as the lanes allow)
+    if (!opts.on_device && n_lanes >= 2 && h2d_bytes >= (64u << 20) && !ctx->tune.no_pipeline) {
         // rates of this call's formats, chunks per ms (one chunk: 96 000 bytes as f32, 48 000 as PCM16): pageable memory through
         // the page-locked ring ~41 GB/s in, ~37 GB/s out; page-locked user memory at the link's 51 GB/s (tools/drain_rate.hip)
         bool in16 = false, in_pinned = false, out32 = false, out16 = false, out_pinned = false;
